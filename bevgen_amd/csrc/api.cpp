@@ -1,0 +1,237 @@
+// extern "C" surface of libbevgen_hip (declared in include/bevgen_hip.h): argument validation, exception -> error-code
+// translation.  No torch types cross this boundary: raw pointers, sizes and a hipStream_t.
+#include "model.h"
+
+using namespace bevgen;
+
+struct bevgen_ctx : public Ctx {};
+
+static thread_local std::string g_create_error;
+
+template <class F>
+static int guarded(bevgen_ctx* ctx, F&& f) {
+    try {
+        if (!ctx) return BEVGEN_ERR_INVALID;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        f();
+        return BEVGEN_OK;
+    } catch (const Error& e) {
+        if (ctx) ctx->last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->last_error = e.what();
+        return BEVGEN_ERR_INTERNAL;
+    }
+}
+
+static void need_final(bevgen_ctx* c) {
+    if (!c->finalized) fail(BEVGEN_ERR_STATE, "bevgen_finalize must be called after loading tensors and before compute calls");
+}
+
+extern "C" {
+
+int bevgen_abi_version(void) { return BEVGEN_ABI_VERSION; }
+
+int bevgen_create(const bevgen_cfg* cfg, int device, bevgen_ctx** out) {
+    try {
+        BG_REQUIRE(cfg && out, "bevgen_create: null argument");
+        BG_REQUIRE(cfg->abi_version == BEVGEN_ABI_VERSION, "bevgen_create: ABI version %d, library is %d", cfg->abi_version, BEVGEN_ABI_VERSION);
+        BG_REQUIRE(cfg->route == BEVGEN_ROUTE_MASKGIT || cfg->route == BEVGEN_ROUTE_AR, "bevgen_create: unknown route %d", cfg->route);
+        BG_REQUIRE(cfg->precision == BEVGEN_PRECISION_FP32, "bevgen_create: only BEVGEN_PRECISION_FP32 is available in this build");
+        int ndev = 0;
+        HIP_CHECK(hipGetDeviceCount(&ndev));
+        BG_REQUIRE(device >= 0 && device < ndev, "bevgen_create: device %d not present (%d visible)", device, ndev);
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        BG_REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, "bevgen_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                   prop.gcnArchName);
+        HIP_CHECK(hipSetDevice(device));
+        auto* c = new bevgen_ctx();
+        c->cfg = *cfg;
+        c->device = device;
+        *out = c;
+        return BEVGEN_OK;
+    } catch (const Error& e) {
+        g_create_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return BEVGEN_ERR_INTERNAL;
+    }
+}
+
+void bevgen_destroy(bevgen_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    delete ctx;
+}
+
+const char* bevgen_last_error(const bevgen_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int bevgen_load_tensor(bevgen_ctx* ctx, const char* name, const void* h, int dtype, int ndim, const int64_t* shape) {
+    return guarded(ctx, [&] { ctx_load_tensor(*ctx, name, h, dtype, ndim, shape); });
+}
+
+int bevgen_set_tables(bevgen_ctx* ctx, const int64_t* fwd, const float* mask, const int64_t* layout, const float* prob, const float* plane) {
+    return guarded(ctx, [&] {
+        const auto& g = ctx->cfg;
+        const int64_t T = (int64_t)g.cam_latent_h * g.cam_latent_w, N = T * g.num_cams, L = g.seq_len, nb = L / g.sparse_block_size;
+        if (fwd) { const int64_t s[1] = {N}; ctx_load_tensor(*ctx, "table.forward_shuffle_idx", fwd, BEVGEN_DTYPE_I64, 1, s); }
+        if (mask) { const int64_t s[2] = {L, L}; ctx_load_tensor(*ctx, "table.attention_mask", mask, BEVGEN_DTYPE_F32, 2, s); }
+        if (layout) { const int64_t s[3] = {g.num_heads, nb, nb}; ctx_load_tensor(*ctx, "table.layout", layout, BEVGEN_DTYPE_I64, 3, s); }
+        if (prob) { const int64_t s[2] = {L, L}; ctx_load_tensor(*ctx, "table.prob_matrix", prob, BEVGEN_DTYPE_F32, 2, s); }
+        if (plane) { const int64_t s[2] = {3, T}; ctx_load_tensor(*ctx, "table.image_plane", plane, BEVGEN_DTYPE_F32, 2, s); }
+    });
+}
+
+int bevgen_finalize(bevgen_ctx* ctx) {
+    return guarded(ctx, [&] { ctx_finalize(*ctx); });
+}
+
+int bevgen_muse_forward(bevgen_ctx* ctx, const int64_t* ids, const int64_t* cond, const float* I_inv, const float* E_inv, int B, float* logits, float* embed, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(ids && cond && I_inv && E_inv, "muse_forward: null input");
+        BG_REQUIRE(B >= 1 && (ctx->cfg.max_batch <= 0 || B <= ctx->cfg.max_batch), "muse_forward: batch %d exceeds max_batch %d", B, ctx->cfg.max_batch);
+        muse_forward(*ctx, ids, cond, I_inv, E_inv, B, logits, embed, (hipStream_t)stream);
+    });
+}
+
+int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
+                            int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(cond && I_inv && E_inv && out && sched, "maskgit_generate: null argument");
+        BG_REQUIRE(B >= 1 && (ctx->cfg.max_batch <= 0 || B <= ctx->cfg.max_batch), "maskgit_generate: batch %d exceeds max_batch %d", B, ctx->cfg.max_batch);
+        BG_REQUIRE(topk_k >= 1 && topk_k <= ctx->cfg.vocab_size, "maskgit_generate: topk_k=%d out of range", topk_k);
+        for (int i = 0; i < timesteps; ++i)
+            BG_REQUIRE(sched[i] >= 1 && sched[i] <= ctx->cfg.cam_latent_h * ctx->cfg.cam_latent_w, "maskgit_generate: mask_schedule[%d]=%d out of range", i, sched[i]);
+        maskgit_generate(*ctx, cond, I_inv, E_inv, B, timesteps, sched, temperature, topk_k, critic_noise_scale, gumbel_u, critic_u, init_ids, out, (hipStream_t)stream);
+    });
+}
+
+int bevgen_sparse_self_attention(bevgen_ctx* ctx, const float* q, const float* k, const float* v, const int64_t* layout, const float* mask, const float* add, int B,
+                                 int H, int L, int block, float* out, void* stream) {
+    return guarded(ctx, [&] {
+        BG_REQUIRE(q && k && v && layout && mask && out, "sparse_self_attention: null argument");
+        BG_REQUIRE(B >= 1 && H >= 1 && L >= 1 && block >= 1, "sparse_self_attention: bad sizes");
+        sparse_self_attention_op(*ctx, q, k, v, layout, mask, add, B, H, L, block, out, (hipStream_t)stream);
+    });
+}
+
+int bevgen_ar_prefill(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, const float* E_inv, int B, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(cond && I_inv && E_inv, "ar_prefill: null input");
+        ar_prefill(*ctx, cond, I_inv, E_inv, B, (hipStream_t)stream);
+    });
+}
+
+int bevgen_ar_logits(bevgen_ctx* ctx, float* logits, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(logits, "ar_logits: null output");
+        ar_logits(*ctx, logits, (hipStream_t)stream);
+    });
+}
+
+int bevgen_ar_decode_step(bevgen_ctx* ctx, const int64_t* tok, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(tok, "ar_decode_step: null token pointer");
+        ar_decode_step(*ctx, tok, (hipStream_t)stream);
+    });
+}
+
+int bevgen_ar_sample(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
+                     const float* noise_u, int samples_per_layout, int64_t* out, float* step_logits, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(cond && I_inv && E_inv && out, "ar_sample: null argument");
+        BG_REQUIRE(temperature > 0.f, "ar_sample: temperature must be positive");
+        ar_sample(*ctx, cond, I_inv, E_inv, B, steps, top_k, temperature, greedy, noise_u, samples_per_layout, out, step_logits, (hipStream_t)stream);
+    });
+}
+
+int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* ids, int n, int denormalize, float* out, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(ids && out && n >= 1, "vq_decode: bad arguments");
+        vq_decode(*ctx, ids, n, denormalize, out, (hipStream_t)stream);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ operator-level entry points
+int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float* bias, const float* residual, float* c, int M, int N, int K, int act_gelu, int skinny,
+                   void* stream) {
+    return guarded(ctx, [&] {
+        GemmArgs g;
+        g.A = a; g.B = w; g.C = c; g.R = residual; g.bias_n = bias;
+        g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
+        g.act = act_gelu ? ACT_GELU : ACT_NONE;
+        if (skinny) launch_gemm_skinny(g, (hipStream_t)stream);
+        else launch_gemm(g, (hipStream_t)stream);
+    });
+}
+
+int bevgen_op_layernorm(bevgen_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, void* stream) {
+    return guarded(ctx, [&] { launch_layernorm(x, D, gamma, beta, y, D, rows, D, eps, (hipStream_t)stream); });
+}
+
+int bevgen_op_geglu_layernorm(bevgen_ctx* ctx, const float* h, const float* gamma, float* y, int rows, int F, int ldy, void* stream) {
+    return guarded(ctx, [&] { launch_geglu_layernorm(h, 2 * F, gamma, y, ldy, rows, F, 1e-5f, (hipStream_t)stream); });
+}
+
+int bevgen_op_attention(bevgen_ctx* ctx, const float* q, const float* k, const float* v, const float* bias, int ldbias, int B, int H, int Nq, int Nk_pad, float scale,
+                        float* out, void* stream) {
+    return guarded(ctx, [&] {
+        AttnArgs a{};
+        a.Q = q; a.K = k; a.V = v; a.bias = bias; a.R = nullptr; a.O = out;
+        a.B = B; a.H = H; a.Nq = Nq; a.Nk_pad = Nk_pad;
+        a.q_bstride = (long)H * Nq * 64; a.q_hstride = (long)Nq * 64;
+        a.kv_bstride = (long)H * Nk_pad * 64; a.kv_hstride = (long)Nk_pad * 64;
+        a.ldbias = ldbias; a.bias_head_stride = 0; a.scale = scale;
+        a.o_bstride = (long)Nq * H * 64; a.o_qstride = (long)H * 64; a.o_hstride = 64;
+        launch_attention(a, (hipStream_t)stream);
+    });
+}
+
+int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* q, const void* kc, const void* vc, int kv_dtype, const float* bias, int ldbias, const uint8_t* keep,
+                               int ldkeep, long keep_head_stride, int B, int H, int n, int Lmax, float scale, float* out, void* stream) {
+    return guarded(ctx, [&] {
+        DecodeAttnArgs a;
+        a.q = q; a.ldq = H * 64; a.kcache = kc; a.vcache = vc; a.kv_dtype = kv_dtype;
+        a.bias = bias; a.ldbias = ldbias; a.keep = keep; a.ldkeep = ldkeep; a.keep_head_stride = keep_head_stride;
+        a.O = out; a.ldo = H * 64; a.B = B; a.H = H; a.n = n; a.Lmax = Lmax; a.scale = scale;
+        launch_decode_attention(a, (hipStream_t)stream);
+    });
+}
+
+int bevgen_op_conv3x3(bevgen_ctx* ctx, const float* x, const float* w, const float* bias, const float* residual, float* y, int n, int H, int W, int Cin, int Cout,
+                      int up, void* stream) {
+    return guarded(ctx, [&] {
+        GemmArgs g;
+        const int oh = up ? 2 * H : H, ow = up ? 2 * W : W;
+        g.mode = MODE_CONV3;
+        g.A = x; g.B = w; g.C = y; g.R = residual; g.bias_n = bias;
+        g.M = n * oh * ow; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout; g.ldr = Cout;
+        g.conv_h = oh; g.conv_w = ow; g.conv_cin = Cin; g.conv_up = up;
+        launch_gemm(g, (hipStream_t)stream);
+    });
+}
+
+int bevgen_op_groupnorm(bevgen_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int n, int hw, int C, int swish, void* stream) {
+    return guarded(ctx, [&] {
+        ctx->arena.reserve(groupnorm_ws_bytes(n, hw) + (size_t)n * 64 * sizeof(float) + 1024);
+        ctx->arena.reset();
+        float* stats = ctx->arena.get<float>((size_t)n * 64);
+        void* ws = ctx->arena.alloc(groupnorm_ws_bytes(n, hw));
+        launch_groupnorm_stats(x, stats, ws, n, hw, C, 1e-6f, (hipStream_t)stream);
+        launch_groupnorm_apply(x, stats, gamma, beta, y, n, hw, C, swish, (hipStream_t)stream);
+    });
+}
+
+int bevgen_decode_attention_splits(int B, int H, int n) { return decode_attention_splits(B, H, n); }
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// Route A: autoregressive sparse-causal transformer with camera bias, run as prefill + KV-cache decode.
+//   GPT.forward                      transformer/mingpt_sparse.py:319-391
+//   Block.forward                    :240-253   (x = ln1(x); x = x + attn(x); x = x + mlp(ln2(x)) - residual from ln1(x), no out-proj)
+//   CustomSparseSelfAttention        :185-212   + SparseSelfAttention.forward transformer/sparse_self_attention.py:103-177
+//   Net2NetTransformer.sample        stage2/cond_transformer_multi_view.py:154-227
+//
+// The reference re-runs the whole L-token forward for every generated token (ar_lm:198).  Image rows are causal in decode
+// order and condition rows only see condition columns (mask_generator.py:148, 202-206), so the logits of step s depend only on
+// rows <= K-1+s: we compute the K condition rows once (prefill), keep K/V of every layer, and per step push exactly one new
+// row through the stack (validity verified against the reference).
+#include "model.h"
+
+namespace bevgen {
+
+namespace {
+
+void gemm(const float* A, int lda, const float* W, int ldb, const float* bias, float* C, int ldc, int M, int N, int K, int act, const float* R, int ldr, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.B = W; g.C = C; g.R = R; g.bias_n = bias;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.act = act;
+    launch_gemm(g, s);
+}
+
+size_t cache_elem_bytes(const Ctx& c) { return c.cfg.precision == BEVGEN_PRECISION_BF16 ? 2 : 4; }
+int cache_dtype(const Ctx& c) { return c.cfg.precision == BEVGEN_PRECISION_BF16 ? 1 : 0; }
+
+struct StepWs {
+    float *x, *xn, *qkv, *x2, *h, *m1, *dec_ws, *gemm_ws, *logits;
+    int64_t* tok;
+    int splits;
+};
+
+StepWs step_ws(Ctx& c, int B) {
+    // fixed layout at the start of the per-call arena (so a captured graph keeps seeing the same addresses)
+    StepWs w;
+    Arena& a = c.arena;
+    const int D = c.D;
+    w.x = a.get<float>((size_t)B * D);
+    w.xn = a.get<float>((size_t)B * D);
+    w.qkv = a.get<float>((size_t)B * 3 * D);
+    w.x2 = a.get<float>((size_t)B * D);
+    w.h = a.get<float>((size_t)B * D);
+    w.m1 = a.get<float>((size_t)B * 4 * D);
+    w.splits = decode_attention_splits(B, c.H, c.L);
+    w.dec_ws = reinterpret_cast<float*>(a.alloc(decode_attention_ws_bytes(B, c.H, w.splits)));
+    size_t gw = std::max(std::max(gemm_skinny_ws_bytes(B, 3 * D, D), gemm_skinny_ws_bytes(B, 4 * D, D)),
+                         std::max(gemm_skinny_ws_bytes(B, D, 4 * D), gemm_skinny_ws_bytes(B, c.V, D)));
+    w.gemm_ws = reinterpret_cast<float*>(a.alloc(gw));
+    w.logits = a.get<float>((size_t)B * c.V);
+    w.tok = a.get<int64_t>((size_t)B);
+    return w;
+}
+
+size_t step_ws_bytes(const Ctx& c, int B) {
+    const int D = c.D;
+    size_t f = (size_t)B * D * 4 + (size_t)B * 3 * D + (size_t)B * 4 * D + (size_t)B * c.V;
+    const int S = decode_attention_splits(B, c.H, c.L);
+    size_t gw = std::max(std::max(gemm_skinny_ws_bytes(B, 3 * D, D), gemm_skinny_ws_bytes(B, 4 * D, D)),
+                         std::max(gemm_skinny_ws_bytes(B, D, 4 * D), gemm_skinny_ws_bytes(B, c.V, D)));
+    return f * sizeof(float) + decode_attention_ws_bytes(B, c.H, S) + gw + B * sizeof(int64_t) + 16 * 256;
+}
+
+void small_gemm(const float* A, int lda, const float* W, int ldb, const float* bias, float* C, int ldc, int M, int N, int K, int act, const float* R, int ldr,
+                float* ws, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.B = W; g.C = C; g.R = R; g.bias_n = bias;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.act = act;
+    if (M <= 64) launch_gemm_skinny_ws(g, ws, s);
+    else launch_gemm(g, s);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ operator seam
+void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const float* v, const int64_t* layout, const float* mask, const float* add, int B, int H,
+                              int L, int block, float* out, hipStream_t s) {
+    BG_REQUIRE(L % block == 0, "Sequence Length, %d, needs to be dividable by Block size %d!", L, block);  // ssa:54-57
+    const int Lpad = (int)round_up(L, 32);
+    const size_t keep_b = (size_t)H * L * L;
+    const size_t bias_b = (size_t)H * L * Lpad * sizeof(float);
+    const size_t kv_b = Lpad != L ? (size_t)2 * B * H * Lpad * 64 * sizeof(float) : 0;
+    c.arena.reserve(keep_b + bias_b + kv_b + 8 * 256);
+    c.arena.reset();
+    uint8_t* keep = c.arena.get<uint8_t>(keep_b);
+    float* bias = c.arena.get<float>((size_t)H * L * Lpad);
+    launch_build_keep(mask, layout, keep, H, L, block, s);
+    launch_build_masked_bias(add, keep, (long)L * L, L, bias, H, L, L, Lpad, L, 0.125f, s);
+    const float *kp = k, *vp = v;
+    if (Lpad != L) {
+        float* kpad = c.arena.get<float>((size_t)B * H * Lpad * 64);
+        float* vpad = c.arena.get<float>((size_t)B * H * Lpad * 64);
+        HIP_CHECK(hipMemsetAsync(kpad, 0, (size_t)B * H * Lpad * 64 * sizeof(float), s));
+        HIP_CHECK(hipMemsetAsync(vpad, 0, (size_t)B * H * Lpad * 64 * sizeof(float), s));
+        HIP_CHECK(hipMemcpy2DAsync(kpad, (size_t)Lpad * 256, k, (size_t)L * 256, (size_t)L * 256, (size_t)B * H, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpy2DAsync(vpad, (size_t)Lpad * 256, v, (size_t)L * 256, (size_t)L * 256, (size_t)B * H, hipMemcpyDeviceToDevice, s));
+        kp = kpad; vp = vpad;
+    }
+    AttnArgs a{};
+    a.Q = q; a.K = kp; a.V = vp; a.bias = bias; a.R = nullptr; a.O = out;
+    a.B = B; a.H = H; a.Nq = L; a.Nk_pad = Lpad;
+    a.q_bstride = (long)H * L * 64; a.q_hstride = (long)L * 64;
+    a.kv_bstride = (long)H * Lpad * 64; a.kv_hstride = (long)Lpad * 64;
+    a.ldbias = Lpad; a.bias_head_stride = (long)L * Lpad; a.scale = 0.125f;
+    a.o_bstride = (long)H * L * 64; a.o_qstride = 64; a.o_hstride = (long)L * 64;  // [B,H,L,64] like the reference op
+    launch_attention(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ prefill
+void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s) {
+    const auto& g = c.cfg;
+    BG_REQUIRE(g.route == BEVGEN_ROUTE_AR, "context was not created for the autoregressive route");
+    BG_REQUIRE(B >= 1, "batch must be positive");
+    const int D = c.D, H = c.H, K = c.K, L = c.L;
+    auto& st = c.ars;
+    // persistent per-batch state
+    const size_t cache_b = (size_t)g.num_layers * B * H * L * 64 * cache_elem_bytes(c);
+    const size_t img_b = g.image_embed ? (size_t)B * g.num_cams * c.T * D * sizeof(float) : 0;
+    const size_t need = 2 * cache_b + img_b + (size_t)B * g.num_cams * D * sizeof(float) + (size_t)B * D * sizeof(float) + 16 * 256;
+    c.persist.reserve(need);
+    c.persist.reset();
+    st.B = B;
+    st.step = 0;
+    st.kcache = c.persist.alloc(cache_b);
+    st.vcache = c.persist.alloc(cache_b);
+    st.img_embed = g.image_embed ? reinterpret_cast<float*>(c.persist.alloc(img_b)) : nullptr;
+    st.c_embed = c.persist.get<float>((size_t)B * g.num_cams * D);
+    st.hidden = c.persist.get<float>((size_t)B * D);
+    st.d_step = c.persist.get<int>(1);
+    HIP_CHECK(hipMemsetAsync(st.kcache, 0, cache_b, s));
+    HIP_CHECK(hipMemsetAsync(st.vcache, 0, cache_b, s));
+    HIP_CHECK(hipMemsetAsync(st.d_step, 0, sizeof(int), s));
+
+    // workspace: the decode-step buffers first (stable addresses), then the prefill activations
+    const size_t rows = (size_t)B * K;
+    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)B * H * K * 64) * sizeof(float) + 16 * 256;
+    c.arena.reserve(step_ws_bytes(c, B) + pre_b);
+    c.arena.reset();
+    (void)step_ws(c, B);
+    float* x = c.arena.get<float>(rows * D);
+    float* xn = c.arena.get<float>(rows * D);
+    float* x2 = c.arena.get<float>(rows * D);
+    float* h = c.arena.get<float>(rows * D);
+    float* qkv = c.arena.get<float>(rows * 3 * D);
+    float* m1 = c.arena.get<float>(rows * 4 * D);
+    float* Q = c.arena.get<float>((size_t)B * H * K * 64);
+
+    if (g.image_embed)
+        launch_camera_embed(I_inv, E_inv, c.image_plane, c.pf("img_embed.weight"), c.pf("cam_embed.weight"), st.img_embed, st.c_embed, B, g.num_cams, c.T, D, s);
+    launch_cond_embed(cond, c.pf("cond_tok_emb.weight"), c.pf("cond_pos_emb"), g.bev_embed ? c.pf("bev_grid") : nullptr, g.bev_embed ? c.pf("bev_embed.weight") : nullptr,
+                      g.bev_embed ? c.pf("bev_embed.bias") : nullptr, g.bev_embed ? c.pf("bev_cam_pos_emb") : nullptr, st.c_embed, x, B, g.num_cams, K, D,
+                      g.cond_vocab_size, s);
+    BG_REQUIRE(cache_dtype(c) == 0, "prefill with a bf16 KV cache is not implemented yet");
+    const size_t layer_elems = (size_t)B * H * L * 64;
+    for (int i = 0; i < g.num_layers; ++i) {
+        const ArLayer& l = c.ar[i];
+        float* kc = reinterpret_cast<float*>(st.kcache) + i * layer_elems;
+        float* vc = reinterpret_cast<float*>(st.vcache) + i * layer_elems;
+        launch_layernorm(x, D, l.ln1_w, l.ln1_b, xn, D, (int)rows, D, 1e-5f, s);
+        gemm(xn, D, l.wqkv, D, l.bqkv, qkv, 3 * D, (int)rows, 3 * D, D, ACT_NONE, nullptr, 0, s);
+        launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, B, H, K, 0, L, s);
+        AttnArgs a{};
+        a.Q = Q; a.K = kc; a.V = vc; a.bias = c.prefill_bias; a.R = xn; a.O = x2;
+        a.B = B; a.H = H; a.Nq = K; a.Nk_pad = c.Kpad;
+        a.q_bstride = (long)H * K * 64; a.q_hstride = (long)K * 64;
+        a.kv_bstride = (long)H * L * 64; a.kv_hstride = (long)L * 64;
+        a.ldbias = c.Kpad; a.bias_head_stride = c.keep_heads > 1 ? (long)K * c.Kpad : 0; a.scale = 0.125f;
+        a.o_bstride = (long)K * D; a.o_qstride = D; a.o_hstride = 64;
+        BG_REQUIRE(c.Kpad <= L, "condition length padded to %d exceeds the cache length %d", c.Kpad, L);
+        launch_attention(a, s);  // x2 = ln1(x) + attn
+        launch_layernorm(x2, D, l.ln2_w, l.ln2_b, h, D, (int)rows, D, 1e-5f, s);
+        gemm(h, D, l.mlp0_w, D, l.mlp0_b, m1, 4 * D, (int)rows, 4 * D, D, ACT_GELU, nullptr, 0, s);
+        gemm(m1, 4 * D, l.mlp2_w, 4 * D, l.mlp2_b, x, D, (int)rows, D, 4 * D, ACT_NONE, x2, D, s);
+    }
+    launch_gather_rows(x, st.hidden, B, K - 1, K, D, s);
+}
+
+void ar_logits(Ctx& c, float* logits, hipStream_t s) {
+    auto& st = c.ars;
+    BG_REQUIRE(st.B > 0, "bevgen_ar_prefill must be called first");
+    c.arena.reset();
+    StepWs w = step_ws(c, st.B);
+    launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, st.B, c.D, 1e-5f, s);
+    small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, logits, c.V, st.B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, s);
+}
+
+// one new row through all layers; position / bias row / cache slot are derived from the device-side step counter
+static void decode_step_launch(Ctx& c, StepWs& w, const int64_t* tok, hipStream_t s) {
+    const auto& g = c.cfg;
+    auto& st = c.ars;
+    const int D = c.D, H = c.H, B = st.B, L = c.L;
+    launch_ar_step_embed(tok, c.pf("x_tok_emb.weight"), st.img_embed, c.pf("x_pos_emb"), c.fwd_idx, st.d_step, w.x, B, g.num_cams, c.T, D, g.vocab_size + 1, s);
+    const size_t layer_bytes = (size_t)B * H * L * 64 * cache_elem_bytes(c);
+    const float* xin = w.x;
+    for (int i = 0; i < g.num_layers; ++i) {
+        const ArLayer& l = c.ar[i];
+        char* kc = reinterpret_cast<char*>(st.kcache) + i * layer_bytes;
+        char* vc = reinterpret_cast<char*>(st.vcache) + i * layer_bytes;
+        launch_layernorm(xin, D, l.ln1_w, l.ln1_b, w.xn, D, B, D, 1e-5f, s);
+        small_gemm(w.xn, D, l.wqkv, D, l.bqkv, w.qkv, 3 * D, B, 3 * D, D, ACT_NONE, nullptr, 0, w.gemm_ws, s);
+        // cache slot = K + step
+        {
+            // d_step counts fed image tokens; the new row sits at sequence position K + step
+            launch_ar_kv_append(w.qkv, kc, vc, cache_dtype(c), B, H, c.K, st.d_step, L, s);
+        }
+        DecodeAttnArgs a;
+        a.q = w.qkv; a.ldq = 3 * D;
+        a.kcache = kc; a.vcache = vc;
+        a.bias = c.attn_bias; a.ldbias = L;
+        a.keep = c.keep; a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
+        a.R = w.xn; a.ldr = D; a.O = w.x2; a.ldo = D;
+        a.B = B; a.H = H; a.n = c.K + 1; a.d_n = st.d_step; a.Lmax = L;
+        a.scale = 0.125f; a.kv_dtype = cache_dtype(c);
+        launch_decode_attention_ws(a, w.dec_ws, w.splits, s);
+        launch_layernorm(w.x2, D, l.ln2_w, l.ln2_b, w.h, D, B, D, 1e-5f, s);
+        small_gemm(w.h, D, l.mlp0_w, D, l.mlp0_b, w.m1, 4 * D, B, 4 * D, D, ACT_GELU, nullptr, 0, w.gemm_ws, s);
+        small_gemm(w.m1, 4 * D, l.mlp2_w, 4 * D, l.mlp2_b, w.x, D, B, D, 4 * D, ACT_NONE, w.x2, D, w.gemm_ws, s);
+        xin = w.x;
+    }
+    HIP_CHECK(hipMemcpyAsync(st.hidden, w.x, (size_t)B * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    launch_increment(st.d_step, s);
+}
+
+void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s) {
+    auto& st = c.ars;
+    BG_REQUIRE(st.B > 0, "bevgen_ar_prefill must be called first");
+    BG_REQUIRE(st.step < c.N, "all %d image tokens have already been decoded", c.N);
+    c.arena.reset();
+    StepWs w = step_ws(c, st.B);
+    decode_step_launch(c, w, tok, s);
+    st.step += 1;
+}
+
+void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
+               const float* noise_u, int samples_per_layout, int64_t* out, float* step_logits, hipStream_t s) {
+    (void)samples_per_layout;
+    BG_REQUIRE(steps >= 1 && steps <= c.N, "steps=%d out of range [1,%d]", steps, c.N);
+    BG_REQUIRE(greedy || noise_u, "stochastic sampling needs explicit uniform noise d_noise_u [steps, B]");
+    ar_prefill(c, cond, I_inv, E_inv, B, s);
+    auto& st = c.ars;
+    c.arena.reset();
+    StepWs w = step_ws(c, B);
+    launch_fill_i64(out, (long)B * c.N, c.cfg.vocab_size, s);  // x = vocab_size everywhere (ar_lm:157)
+    for (int step = 0; step < steps; ++step) {
+        launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, B, c.D, 1e-5f, s);
+        float* lg = step_logits ? step_logits + (size_t)step * B * c.V : w.logits;
+        small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, lg, c.V, B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, s);
+        launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u + (size_t)step * B, w.tok, B, c.V, top_k, temperature, s);
+        launch_store_tokens(w.tok, c.fwd_idx, st.d_step, out, B, c.N, s);
+        if (step + 1 < steps) {
+            decode_step_launch(c, w, w.tok, s);
+            st.step += 1;
+        }
+    }
+}
+
+}  // namespace bevgen

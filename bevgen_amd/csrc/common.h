@@ -1,0 +1,64 @@
+// Shared declarations for libbevgen_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <stdexcept>
+#include <cstdio>
+#include <cstdarg>
+
+namespace bevgen {
+
+// -------- error handling: C++ exceptions inside, translated to int codes at the C-ABI --------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+#define HIP_CHECK(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) ::bevgen::fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
+
+#define BG_REQUIRE(cond, ...)                      \
+    do {                                           \
+        if (!(cond)) ::bevgen::fail(-1, __VA_ARGS__); \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+constexpr float kNegBig = -1.0e30f;  // "minus infinity" that never produces inf-inf NaNs in online softmax
+
+// -------- wave-level helpers (wave = 64 lanes) --------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// erf-based GELU (torch nn.GELU() / F.gelu default)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+}  // namespace bevgen

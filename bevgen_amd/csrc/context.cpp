@@ -1,0 +1,255 @@
+// Context lifecycle: tensor registry (reference state_dict names), derived device data built in bevgen_finalize.
+#include <cstring>
+
+#include "model.h"
+
+namespace bevgen {
+
+// ------------------------------------------------------------------------------------------------ arena
+void Arena::reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    if (base) HIP_CHECK(hipFree(base));
+    base = nullptr;
+    cap = 0;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&base), bytes));
+    cap = bytes;
+    off = 0;
+}
+void* Arena::alloc(size_t bytes) {
+    const size_t a = (off + 255) & ~size_t(255);
+    if (a + bytes > cap) fail(BEVGEN_ERR_INTERNAL, "workspace arena exhausted: need %zu more bytes (capacity %zu)", a + bytes - cap, cap);
+    off = a + bytes;
+    if (off > high) high = off;
+    return base + a;
+}
+void Arena::release() {
+    if (base) hipFree(base);
+    base = nullptr;
+    cap = off = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ctx
+Ctx::~Ctx() {
+    for (auto& kv : params)
+        if (kv.second.ptr) hipFree(kv.second.ptr);
+    for (void* p : owned) hipFree(p);
+    arena.release();
+    persist.release();
+}
+const DevTensor* Ctx::find(const std::string& name) const {
+    auto it = params.find(name);
+    return it == params.end() ? nullptr : &it->second;
+}
+const DevTensor& Ctx::need(const std::string& name) const {
+    auto it = params.find(name);
+    if (it == params.end()) fail(BEVGEN_ERR_INVALID, "missing tensor '%s' (load it with bevgen_load_tensor before bevgen_finalize)", name.c_str());
+    return it->second;
+}
+void* Ctx::own(size_t bytes) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    owned.push_back(p);
+    return p;
+}
+
+static size_t dtype_size(int dt) {
+    switch (dt) {
+        case BEVGEN_DTYPE_F32: return 4;
+        case BEVGEN_DTYPE_I64: return 8;
+        case BEVGEN_DTYPE_U8: return 1;
+        case BEVGEN_DTYPE_F64: return 8;
+    }
+    fail(BEVGEN_ERR_INVALID, "unknown dtype %d", dt);
+}
+
+void ctx_load_tensor(Ctx& c, const char* name, const void* h, int dtype, int ndim, const int64_t* shape) {
+    BG_REQUIRE(name && h && ndim >= 0 && ndim <= 8, "load_tensor: bad arguments");
+    HIP_CHECK(hipSetDevice(c.device));
+    DevTensor t;
+    t.dtype = dtype;
+    long n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+    BG_REQUIRE(n > 0, "load_tensor('%s'): empty tensor", name);
+    std::vector<float> conv;
+    const void* src = h;
+    if (dtype == BEVGEN_DTYPE_F64) {  // tables such as the legacy prob_matrix are float64 in the reference; arithmetic casts them to fp32
+        conv.resize(n);
+        const double* d = reinterpret_cast<const double*>(h);
+        for (long i = 0; i < n; ++i) conv[i] = (float)d[i];
+        src = conv.data();
+        t.dtype = BEVGEN_DTYPE_F32;
+    }
+    t.bytes = (size_t)n * dtype_size(t.dtype);
+    auto it = c.params.find(name);
+    if (it != c.params.end()) {
+        hipFree(it->second.ptr);
+        c.params.erase(it);
+    }
+    HIP_CHECK(hipMalloc(&t.ptr, t.bytes));
+    HIP_CHECK(hipMemcpy(t.ptr, src, t.bytes, hipMemcpyHostToDevice));
+    if (std::string(name) == "table.forward_shuffle_idx") {
+        BG_REQUIRE(t.dtype == BEVGEN_DTYPE_I64, "table.forward_shuffle_idx must be int64");
+        c.h_fwd_idx.assign(reinterpret_cast<const int64_t*>(h), reinterpret_cast<const int64_t*>(h) + n);
+    }
+    c.params[name] = std::move(t);
+    c.finalized = false;
+}
+
+static void expect_shape(const Ctx& c, const std::string& name, std::initializer_list<int64_t> shape) {
+    const DevTensor& t = c.need(name);
+    long n = 1;
+    for (auto d : shape) n *= d;
+    if (t.numel() != n) {
+        std::string got;
+        for (auto d : t.shape) got += std::to_string(d) + ",";
+        fail(BEVGEN_ERR_INVALID, "tensor '%s' has %ld elements (shape [%s]) but the configuration needs %ld", name.c_str(), t.numel(), got.c_str(), n);
+    }
+}
+
+static void finalize_muse(Ctx& c) {
+    const auto& g = c.cfg;
+    const std::string p = "transformer.";
+    const int D = c.D, H = c.H, F = c.F;
+    BG_REQUIRE(H * 64 == D || true, "unused");
+    expect_shape(c, p + "token_emb.weight", {g.vocab_size + 1, D});
+    expect_shape(c, p + "pos_emb.weight", {c.N, D});
+    expect_shape(c, p + "cond_token_emb.weight", {g.cond_vocab_size, D});
+    expect_shape(c, p + "cond_pos_emb.weight", {c.K, D});
+    expect_shape(c, p + "to_logits.weight", {g.vocab_size, D});
+    expect_shape(c, p + "transformer_blocks.norm.gamma", {D});
+    expect_shape(c, "token_critic.to_pred.weight", {1, D});
+    expect_shape(c, "token_critic.to_pred.bias", {1});
+    const int inner = H * 64;
+    c.Fpad = (int)round_up(F, 32);
+    c.muse.resize(g.num_layers);
+    for (int i = 0; i < g.num_layers; ++i) {
+        MuseLayer& l = c.muse[i];
+        for (int j = 0; j < 2; ++j) {
+            const std::string q = p + "transformer_blocks.layers." + std::to_string(i) + "." + std::to_string(j) + ".";
+            expect_shape(c, q + "to_q.weight", {inner, D});
+            expect_shape(c, q + "to_kv.weight", {2 * inner, D});
+            expect_shape(c, q + "to_out.weight", {D, inner});
+            expect_shape(c, q + "null_kv", {2, H, 1, 64});
+            l.norm_g[j] = c.pf(q + "norm.gamma");
+            l.to_q[j] = c.pf(q + "to_q.weight");
+            l.to_kv[j] = c.pf(q + "to_kv.weight");
+            l.to_out[j] = c.pf(q + "to_out.weight");
+            l.q_scale[j] = c.pf(q + "q_scale");
+            l.k_scale[j] = c.pf(q + "k_scale");
+            l.null_kv[j] = c.pf(q + "null_kv");
+        }
+        const std::string q = p + "transformer_blocks.layers." + std::to_string(i) + ".2.";
+        expect_shape(c, q + "1.weight", {2 * F, D});
+        expect_shape(c, q + "4.weight", {D, F});
+        expect_shape(c, q + "3.gamma", {F});
+        l.ff_g0 = c.pf(q + "0.gamma");
+        l.ff_w1 = c.pf(q + "1.weight");
+        l.ff_g3 = c.pf(q + "3.gamma");
+        l.ff_w4_padded = reinterpret_cast<float*>(c.own((size_t)D * c.Fpad * sizeof(float)));
+        launch_pad_rows(c.pf(q + "4.weight"), F, l.ff_w4_padded, c.Fpad, D, F, 0);
+    }
+    // attention bias matrices with the null-key column
+    c.NkS_pad = (int)round_up(c.N + 1, 32);
+    c.NkC_pad = (int)round_up(c.K + 1, 32);
+    c.ldS = c.NkS_pad;
+    c.ldC = c.NkC_pad;
+    c.bias_self = reinterpret_cast<float*>(c.own((size_t)c.N * c.ldS * sizeof(float)));
+    c.bias_cross = reinterpret_cast<float*>(c.own((size_t)c.N * c.ldC * sizeof(float)));
+    BG_REQUIRE(c.L == c.N + c.K, "Route M requires num_pad_tokens == 0 (sparse_block_size 1): L=%d, N+K=%d (muse_maskgit_pytorch.py:152-154 slices the bias at K)", c.L, c.N + c.K);
+    launch_build_muse_bias(c.attn_bias, c.L, c.K, c.N, c.bias_self, c.ldS, c.bias_cross, c.ldC, 0);
+}
+
+static void finalize_ar(Ctx& c) {
+    const auto& g = c.cfg;
+    const int D = c.D;
+    expect_shape(c, "x_tok_emb.weight", {g.vocab_size + 1, D});
+    expect_shape(c, "cond_tok_emb.weight", {g.cond_vocab_size, D});
+    expect_shape(c, "x_pos_emb", {1, c.N, D});
+    expect_shape(c, "cond_pos_emb", {1, c.K, D});
+    expect_shape(c, "head.weight", {g.vocab_size, D});
+    c.ar.resize(g.num_layers);
+    for (int i = 0; i < g.num_layers; ++i) {
+        ArLayer& l = c.ar[i];
+        const std::string q = "blocks." + std::to_string(i) + ".";
+        for (const char* n : {"query", "key", "value"}) expect_shape(c, q + "attention." + n + ".weight", {D, D});
+        expect_shape(c, q + "mlp.0.weight", {4 * D, D});
+        expect_shape(c, q + "mlp.2.weight", {D, 4 * D});
+        l.ln1_w = c.pf(q + "ln1.weight"); l.ln1_b = c.pf(q + "ln1.bias");
+        l.ln2_w = c.pf(q + "ln2.weight"); l.ln2_b = c.pf(q + "ln2.bias");
+        l.mlp0_w = c.pf(q + "mlp.0.weight"); l.mlp0_b = c.pf(q + "mlp.0.bias");
+        l.mlp2_w = c.pf(q + "mlp.2.weight"); l.mlp2_b = c.pf(q + "mlp.2.bias");
+        l.wqkv = reinterpret_cast<float*>(c.own((size_t)3 * D * D * sizeof(float)));
+        l.bqkv = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
+        launch_fuse_qkv(c.pf(q + "attention.query.weight"), c.pf(q + "attention.key.weight"), c.pf(q + "attention.value.weight"),
+                        c.pf(q + "attention.query.bias"), c.pf(q + "attention.key.bias"), c.pf(q + "attention.value.bias"), l.wqkv, l.bqkv, D, 0);
+    }
+    // visibility mask: allowed AND layout block present.  Heads with identical layouts share one plane.
+    const int blk = g.sparse_block_size, nb = c.L / blk;
+    const DevTensor& lay = c.need("table.layout");
+    BG_REQUIRE(lay.dtype == BEVGEN_DTYPE_I64 && lay.numel() == (long)c.H * nb * nb, "table.layout must be int64 [H=%d, %d, %d]", c.H, nb, nb);
+    expect_shape(c, "table.attention_mask", {c.L, c.L});
+    std::vector<int64_t> hl(lay.numel());
+    HIP_CHECK(hipMemcpy(hl.data(), lay.ptr, lay.bytes, hipMemcpyDeviceToHost));
+    bool same = true;
+    for (int h = 1; h < c.H && same; ++h) same = std::memcmp(hl.data(), hl.data() + (size_t)h * nb * nb, (size_t)nb * nb * sizeof(int64_t)) == 0;
+    c.keep_heads = same ? 1 : c.H;
+    c.keep = reinterpret_cast<uint8_t*>(c.own((size_t)c.keep_heads * c.L * c.L));
+    launch_build_keep(c.pf("table.attention_mask"), reinterpret_cast<const int64_t*>(lay.ptr), c.keep, c.keep_heads, c.L, blk, 0);
+    // prefill bias over the condition rows: scale*(bias) where visible, -1e30 elsewhere
+    c.Kpad = (int)round_up(c.K, 32);
+    c.prefill_bias = reinterpret_cast<float*>(c.own((size_t)c.keep_heads * c.K * c.Kpad * sizeof(float)));
+    launch_build_masked_bias(c.attn_bias, c.keep, (long)c.L * c.L, c.L, c.prefill_bias, c.keep_heads, c.K, c.K, c.Kpad, c.L, 0.125f, 0);
+}
+
+void ctx_finalize(Ctx& c) {
+    HIP_CHECK(hipSetDevice(c.device));
+    const auto& g = c.cfg;
+    // free previously derived buffers (re-finalize after reloading weights)
+    for (void* p : c.owned) hipFree(p);
+    c.owned.clear();
+    c.T = g.cam_latent_h * g.cam_latent_w;
+    c.N = c.T * g.num_cams;
+    c.K = g.num_cond_tokens;
+    c.L = g.seq_len;
+    c.D = g.dim;
+    c.H = g.num_heads;
+    c.V = g.vocab_size;
+    c.F = g.ff_inner;
+    if (g.num_layers > 0) {
+        BG_REQUIRE(c.D == c.H * 64, "head dimension must be 64 (dim=%d, heads=%d)", c.D, c.H);
+        BG_REQUIRE(c.D % 32 == 0, "dim must be a multiple of 32");
+        BG_REQUIRE(c.L >= c.N + c.K && c.L % g.sparse_block_size == 0, "seq_len %d inconsistent with N+K=%d / block %d", c.L, c.N + c.K, g.sparse_block_size);
+        const std::string p = g.route == BEVGEN_ROUTE_MASKGIT ? "transformer." : "";
+        if (g.image_embed) {
+            expect_shape(c, "table.image_plane", {3, c.T});
+            c.image_plane = c.pf("table.image_plane");
+            expect_shape(c, p + "img_embed.weight", {c.D, 4});
+            expect_shape(c, p + "cam_embed.weight", {c.D, 4});
+        }
+        if (g.bev_embed) {
+            BG_REQUIRE(g.image_embed, "bev_embed requires image_embed (the camera origin embedding comes from cam_embed, mingpt_sparse.py:336-338)");
+            expect_shape(c, p + "bev_embed.weight", {c.D, 2});
+            expect_shape(c, p + "bev_cam_pos_emb", {1, g.num_cams, c.K, c.D});
+            BG_REQUIRE(c.need(p + "bev_grid").numel() == 3L * c.K, "bev_grid must be [3, K]");
+        }
+        expect_shape(c, "table.forward_shuffle_idx", {c.N});
+        c.fwd_idx = reinterpret_cast<const int64_t*>(c.need("table.forward_shuffle_idx").ptr);
+        c.attn_bias = nullptr;
+        if (g.camera_bias) {
+            expect_shape(c, p + "camera_bias_emb", {(int64_t)c.L * (c.L + 1) / 2});
+            expect_shape(c, "table.prob_matrix", {c.L, c.L});
+            c.attn_bias = reinterpret_cast<float*>(c.own((size_t)c.L * c.L * sizeof(float)));
+            launch_build_attn_bias(c.pf(p + "camera_bias_emb"), c.pf("table.prob_matrix"), c.attn_bias, c.L, 0);
+        } else if (g.route == BEVGEN_ROUTE_MASKGIT) {
+            c.attn_bias = reinterpret_cast<float*>(c.own((size_t)c.L * c.L * sizeof(float)));
+            launch_build_attn_bias(nullptr, nullptr, c.attn_bias, c.L, 0);
+        }
+        if (g.route == BEVGEN_ROUTE_MASKGIT) finalize_muse(c);
+        else finalize_ar(c);
+    }
+    if (g.vq_ch > 0) vq_finalize(c);
+    HIP_CHECK(hipDeviceSynchronize());
+    c.finalized = true;
+}
+
+}  // namespace bevgen

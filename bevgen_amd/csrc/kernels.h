@@ -1,0 +1,139 @@
+// Kernel launch interfaces of libbevgen_hip (internal; the public C-ABI is include/bevgen_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bevgen {
+
+// ---------------------------------------------------------------- gemm.hip
+enum { MODE_PLAIN = 0, MODE_CONV3 = 1 };
+enum { ACT_NONE = 0, ACT_GELU = 1 };
+
+struct GemmArgs {
+    const float* A = nullptr;  // [M,K] row-major (lda)   | MODE_CONV3: NHWC input [n, Hin, Win, Cin]
+    const float* B = nullptr;  // [N,K] row-major (ldb)   | MODE_CONV3: weights [Cout][3][3][Cin]
+    float* C = nullptr;        // [M,N] row-major (ldc)
+    const float* R = nullptr;  // optional residual [M,N] (ldr), added after the activation
+    const float* bias_n = nullptr;  // optional [N]
+    const float* bias_m = nullptr;  // optional [M]
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldb = 0, ldc = 0, ldr = 0;
+    int batch = 1;
+    long strideA = 0, strideB = 0, strideC = 0, strideR = 0;
+    float alpha = 1.f;
+    int act = ACT_NONE;
+    int mode = MODE_PLAIN;
+    // MODE_CONV3: output spatial size (conv_h x conv_w), input channels, fused nearest-2x upsample of the input
+    int conv_h = 0, conv_w = 0, conv_cin = 0, conv_up = 0;
+};
+void launch_gemm(const GemmArgs& g, hipStream_t stream);
+
+// Skinny GEMM for decode steps (M <= 64 rows, weight-streaming bound): C[M,N] = A[M,K] B[N,K]^T + bias, act, residual
+void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream);               // library-owned split-K workspace (op tests)
+int gemm_skinny_ksplit(int M, int N, int K);
+size_t gemm_skinny_ws_bytes(int M, int N, int K);
+void launch_gemm_skinny_ws(const GemmArgs& g, float* ws, hipStream_t stream);  // caller-owned workspace (model path)
+
+// ---------------------------------------------------------------- norm.hip
+// y[row, :] = LayerNorm(x[row, :]) * gamma (+ beta); rows of width D; ldx/ldy row strides; columns [D, ldy) of y are zero-filled
+void launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int rows, int D, float eps, hipStream_t s);
+// GEGLU + LayerNorm (muse_net:71-88): h[row, 0:F] = a, h[row, F:2F] = gate -> y = LN(gate * gelu(a)) * gamma ; y row stride ldy (zero padded)
+void launch_geglu_layernorm(const float* h, int ldh, const float* gamma, float* y, int ldy, int rows, int F, float eps, hipStream_t s);
+// GroupNorm(32 groups, eps) statistics over NHWC [n, hw, C] -> stats[n*32*2] = (mean, rstd)
+size_t groupnorm_ws_bytes(int n, int hw);
+void launch_groupnorm_stats(const float* x, float* stats, void* ws /*groupnorm_ws_bytes*/, int n, int hw, int C, float eps, hipStream_t s);
+// y = (x-mean)*rstd*gamma+beta, optionally followed by swish (x*sigmoid(x)); NHWC
+void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s);
+
+// ---------------------------------------------------------------- attention.hip
+// Flash attention, fp32 MFMA, head dim 64:  O = softmax(scale * Q K^T + bias) V
+//   Q [B,H,Nq,64] (row stride 64), K/V [B,H,Nk_pad,64] with Nk_pad % 32 == 0 (rows >= Nk zero),
+//   bias [*, ldb] rows indexed by query, cols by key; entries for key >= Nk must be <= -1e30 (mask baked in);
+//   bias may be null only if Nk % 32 == 0.  bias_head_stride = elements between heads (0 = shared by all heads).
+//   O (+ optional residual R, same layout) is addressed through o_*stride: [B,Nq,H*64] -> (Nq*H*64, H*64, 64); [B,H,Nq,64] -> (H*Nq*64, 64, Nq*64).
+struct AttnArgs {
+    const float* Q; const float* K; const float* V; const float* bias; const float* R; float* O;
+    int B, H, Nq, Nk_pad;
+    long q_bstride, q_hstride;    // elements between batches / heads of Q
+    long kv_bstride, kv_hstride;  // same for K and V
+    int ldbias; long bias_head_stride;
+    float scale;
+    long o_bstride, o_qstride, o_hstride;  // O (and R) element index = b*o_bstride + q*o_qstride + head*o_hstride + d
+};
+void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// Decode attention (Route A, one new query row per sequence): see attention.hip
+struct DecodeAttnArgs {
+    const float* q = nullptr;        // [B, H*64] this step's query rows (row stride ldq)
+    int ldq = 0;
+    const void* kcache = nullptr;    // [B, H, Lmax, 64] storage dtype
+    const void* vcache = nullptr;
+    const float* bias = nullptr;     // [L, ldbias] camera-bias matrix (unscaled; row = n-1 is used) or null
+    int ldbias = 0;
+    const uint8_t* keep = nullptr;   // [H or 1][L][ldkeep] 1 = visible (allowed AND layout block present); null = all visible
+    long keep_head_stride = 0;
+    int ldkeep = 0;
+    const float* R = nullptr;        // residual [B, H*64] (row stride ldr) or null
+    float* O = nullptr;              // [B, H*64] (row stride ldo)
+    int ldr = 0, ldo = 0;
+    int B = 0, H = 0;
+    int n = 0;                       // context length (keys 0..n-1); if d_n != null the length is *d_n + n
+    const int* d_n = nullptr;        // device-side step counter (hipGraph replay)
+    int Lmax = 0;
+    float scale = 1.f;               // dh^-0.5, applied to (q.k + bias)
+    int kv_dtype = 0;                // 0 = fp32, 1 = bf16
+    int shared_prefix = 0;           // reserved: leading keys shared by groups of `group` consecutive sequences
+    int group = 1;
+};
+int decode_attention_splits(int B, int H, int n_max);
+size_t decode_attention_ws_bytes(int B, int H, int S);
+void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipStream_t s);
+void launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- embed.hip
+// Geometric camera embeddings (gpt:336-349 / muse_net:314-327)
+//   c_embed[b,c,:] = Wcam[D,4] * E_inv[b,c,:,3];  img[b,c,t,:] = normalize(Wimg * (E_inv [I_inv pix_t; 1]) - c_embed) (+1e-7)
+void launch_camera_embed(const float* I_inv, const float* E_inv, const float* plane /*[3,T]*/, const float* Wimg, const float* Wcam,
+                         float* img /*[B,C,T,D]*/, float* c_embed /*[B,C,D]*/, int B, int C, int T, int D, hipStream_t s);
+// context[b,k,:] = cond_tok[cond_ids[b,k]] + (grid[k,:]*Wbev + bbev - sum_c(bev_cam_pos[c,k,:] + c_embed[b,c,:])) + cond_pos[k,:]
+void launch_cond_embed(const int64_t* cond_ids, const float* cond_tok, const float* cond_pos, const float* bev_grid /*[3,K] or null*/,
+                       const float* Wbev, const float* bbev, const float* bev_cam_pos /*[C,K,D]*/, const float* c_embed /*[B,C,D]*/,
+                       float* out, int B, int C, int K, int D, int cond_vocab, hipStream_t s);
+// x[b,n,:] = (tok_emb[ids[b,n]] + img[b,n,:]) + pos[n,:]        (muse_net:309-331)
+void launch_token_embed(const int64_t* ids, const float* tok_emb, const float* img /*or null*/, const float* pos, float* x,
+                        int B, int N, int D, int vocab_rows, hipStream_t s);
+
+// Route M q/k/v preparation (muse_net:132-146): l2norm + per-dim scale, null-kv prepended, head-major layout
+//   qraw [B*Nq, H*64] -> Q [B,H,Nq,64];  kvraw [B*Nk, 2*H*64] (k first, v second) -> K,V [B,H,Nk_pad,64] rows 1..Nk (row 0 = null kv)
+void launch_muse_q_prep(const float* qraw, const float* q_scale, float* Q, int B, int H, int Nq, hipStream_t s);
+void launch_muse_kv_prep(const float* kvraw, const float* null_kv /*[2,H,1,64]*/, const float* k_scale, float* K, float* V,
+                         int B, int H, int Nk, int Nk_pad, hipStream_t s);
+// Route A: split fused qkv rows [rows, 3*H*64] (q|k|v) -> Q [B,H,n,64] (optional) and cache rows [B,H,Lmax,64] at position pos0..pos0+n
+void launch_ar_qkv_scatter(const float* qkv, float* Q /*[B,H,n,64] or null*/, void* kcache, void* vcache, int kv_dtype,
+                           int B, int H, int n, int pos0, int Lmax, hipStream_t s);
+// Route A decode: pos0 read from a device counter (graph-replayable)
+void launch_ar_kv_append(const float* qkv, void* kcache, void* vcache, int kv_dtype, int B, int H, int pos0, const int* d_pos, int Lmax, hipStream_t s);
+
+// ---------------------------------------------------------------- sampler.hip
+// MaskGit re-masking (muse_net:569-574): the n_mask highest scores of each row (ties: lower index first) get mask_id; init ids re-imposed
+void launch_remask(int64_t* ids, const float* scores, const int64_t* init_ids /*or null*/, int rows, int T, int n_mask, int64_t mask_id, hipStream_t s);
+// MaskGit token pick (muse_net:587-599): top-k filter, /max(temp,1e-10), + gumbel(u), argmax; only masked positions are overwritten
+void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float* gumbel_u /*or null*/, int rows, int V, int k, float temperature,
+                         int64_t mask_id, hipStream_t s);
+// Self-critic scores (muse_net:392-396, 602-611): scores = embed . w + b + ((u - 0.5) * noise_scale) * frac
+void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u /*or null*/, float noise_scale, float frac,
+                          float* scores, int rows, int D, hipStream_t s);
+// Route A token pick (ar_lm:204-219): logits/temperature, top-k (ties kept), softmax, argmax or inverse-CDF draw with explicit u
+void launch_ar_pick(const float* logits, int ldl, const float* u /*or null*/, int64_t* out, int rows, int V, int top_k, float temperature, hipStream_t s);
+
+// ---------------------------------------------------------------- vq.hip
+void launch_codebook_gather(const int64_t* ids, const float* codebook, float* out, int rows, int dim, int n_embed, hipStream_t s);
+// NHWC [n,hw,C] -> NCHW [n,C,hw] with optional per-channel x*std+mean and clamp to [0,1] (bev_utils/util.py:97-118)
+void launch_nhwc_to_nchw(const float* x, float* y, int n, int hw, int C, int ldc, const float* mean, const float* stdv, int clamp01, hipStream_t s);
+void launch_row_softmax(float* x, int rows, int cols, float scale, hipStream_t s);
+
+// misc
+void launch_fill(float* p, long n, float v, hipStream_t s);
+void launch_add(const float* a, const float* b, float* c, long n, hipStream_t s);
+
+}  // namespace bevgen

@@ -1,0 +1,142 @@
+// Context and model-level orchestration of libbevgen_hip (internal).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/bevgen_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace bevgen {
+
+struct DevTensor {
+    void* ptr = nullptr;
+    int dtype = 0;
+    std::vector<int64_t> shape;
+    size_t bytes = 0;
+    long numel() const { long n = 1; for (auto d : shape) n *= d; return n; }
+    const float* f() const { return reinterpret_cast<const float*>(ptr); }
+};
+
+// Bump allocator over one device slab: workspace of a call is carved from it, nothing is allocated on the sampling path.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, high = 0;
+    void reserve(size_t bytes);
+    void reset() { off = 0; }
+    void* alloc(size_t bytes);
+    template <class T> T* get(size_t count) { return reinterpret_cast<T*>(alloc(count * sizeof(T))); }
+    void release();
+};
+
+struct MuseLayer {
+    // self (0) and cross (1) attention, feed-forward
+    const float *norm_g[2], *to_q[2], *to_kv[2], *to_out[2], *q_scale[2], *k_scale[2], *null_kv[2];
+    const float *ff_g0, *ff_w1, *ff_g3;
+    float* ff_w4_padded;  // [D, Fpad], owned
+};
+
+struct ArLayer {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    float *wqkv, *bqkv;  // fused [3D, D], [3D], owned
+    const float *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
+};
+
+struct ConvW { float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };  // w re-laid [Cout][kh][kw][Cin] (owned)
+struct ResBlockW { const float *n1w, *n1b, *n2w, *n2b; ConvW c1, c2, nin; bool has_nin = false; int cin = 0, cout = 0; };
+struct AttnBlockW { const float *nw, *nb; ConvW q, k, v, proj; int c = 0; };
+struct UpLevelW { std::vector<ResBlockW> blocks; std::vector<AttnBlockW> attns; bool has_up = false; ConvW up; };
+
+struct Ctx {
+    bevgen_cfg cfg{};
+    int device = 0;
+    std::string last_error;
+    bool finalized = false;
+    std::unordered_map<std::string, DevTensor> params;
+    std::vector<void*> owned;  // derived device buffers freed at destroy
+    Arena arena;               // per-call workspace
+    Arena persist;             // per-batch state that must survive between C calls (Route A KV cache etc.)
+
+    // ---- derived sizes
+    int T = 0, N = 0, K = 0, L = 0, D = 0, H = 0, V = 0, F = 0, Fpad = 0;
+    // ---- shared tables (device)
+    const float* image_plane = nullptr;  // [3,T]
+    const int64_t* fwd_idx = nullptr;    // [N]
+    std::vector<int64_t> h_fwd_idx;
+    float* attn_bias = nullptr;          // [L,L] = tril_scatter(camera_bias_emb) + prob_matrix (0 if !camera_bias)
+
+    // ---- Route M
+    std::vector<MuseLayer> muse;
+    float *bias_self = nullptr, *bias_cross = nullptr;  // [N, ldS] / [N, ldC] with the null-key column and masks baked in
+    int ldS = 0, ldC = 0, NkS_pad = 0, NkC_pad = 0;
+
+    // ---- Route A
+    std::vector<ArLayer> ar;
+    uint8_t* keep = nullptr;       // [Hk, L, L]
+    int keep_heads = 1;
+    float* prefill_bias = nullptr; // [Hk, K, Kpad]
+    int Kpad = 0;
+    // per-batch decode state (lives in `persist`)
+    struct ArState {
+        int B = 0, step = 0;        // step = number of image tokens already fed
+        float *img_embed = nullptr, *c_embed = nullptr;  // [B,C,T,D], [B,C,D]
+        void *kcache = nullptr, *vcache = nullptr;       // [layers][B,H,L,64]
+        float* hidden = nullptr;                         // [B,D] newest row after the last layer
+        int* d_step = nullptr;                           // device copy of `step`
+    } ars;
+
+    // ---- VQGAN decoder
+    bool has_vq = false;
+    const float* codebook = nullptr;
+    ConvW post_quant, conv_in, conv_out;
+    ResBlockW mid1, mid2;
+    AttnBlockW mid_attn;
+    std::vector<UpLevelW> up;  // index = level (0 = full resolution)
+    const float *norm_out_w = nullptr, *norm_out_b = nullptr;
+    float *denorm_mean = nullptr, *denorm_std = nullptr;
+
+    ~Ctx();
+    const DevTensor& need(const std::string& name) const;
+    const DevTensor* find(const std::string& name) const;
+    const float* pf(const std::string& name) const { return need(name).f(); }
+    void* own(size_t bytes);  // hipMalloc tracked for destroy
+};
+
+// context.cpp
+void ctx_load_tensor(Ctx& c, const char* name, const void* h, int dtype, int ndim, const int64_t* shape);
+void ctx_finalize(Ctx& c);
+// muse.cpp
+void muse_forward(Ctx& c, const int64_t* ids, const int64_t* cond, const float* I_inv, const float* E_inv, int B, float* logits, float* embed, hipStream_t s);
+void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
+                      int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, hipStream_t s);
+// ar.cpp
+void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const float* v, const int64_t* layout, const float* mask, const float* add, int B, int H,
+                              int L, int block, float* out, hipStream_t s);
+void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s);
+void ar_logits(Ctx& c, float* logits, hipStream_t s);
+void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s);
+void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
+               const float* noise_u, int samples_per_layout, int64_t* out, float* step_logits, hipStream_t s);
+// vqdec.cpp
+void vq_finalize(Ctx& c);
+void vq_decode(Ctx& c, const int64_t* ids, int n, int denorm, float* out, hipStream_t s);
+// tables.hip
+void launch_build_attn_bias(const float* tril_emb /*or null*/, const float* prob /*or null*/, float* out, int L, hipStream_t s);
+void launch_build_muse_bias(const float* attn_bias, int L, int K, int N, float* bias_self, int ldS, float* bias_cross, int ldC, hipStream_t s);
+void launch_build_keep(const float* allowed, const int64_t* layout, uint8_t* keep, int heads, int L, int block, hipStream_t s);
+void launch_build_masked_bias(const float* add /*[L,L] or null*/, const uint8_t* keep, long keep_head_stride, int ldkeep, float* out, int heads, int rows, int cols,
+                              int ldout, int ldadd, float scale, hipStream_t s);
+void launch_ar_step_embed(const int64_t* tok, const float* tok_emb, const float* img_embed, const float* pos_emb, const int64_t* fwd_idx, const int* d_step,
+                          float* x, int B, int C, int T, int D, int vocab_rows, hipStream_t s);
+void launch_store_tokens(const int64_t* tok, const int64_t* fwd_idx, const int* d_step, int64_t* out, int B, int N, hipStream_t s);
+void launch_gather_rows(const float* x, float* out, int B, int row, int rows_per_batch, int D, hipStream_t s);
+void launch_increment(int* p, hipStream_t s);
+void launch_relayout_conv_weight(const float* w_oihw, float* w_ohwi, int cout, int cin, int kh, int kw, hipStream_t s);
+void launch_fuse_qkv(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, float* w, float* b, int D, hipStream_t s);
+void launch_pad_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t s);
+void launch_fill_i64(int64_t* p, long n, int64_t v, hipStream_t s);
+
+}  // namespace bevgen

@@ -1,0 +1,183 @@
+// Route M: MaskGit bidirectional decoder.
+//   TransformerMultiView.forward      stage2/muse_maskgit_pytorch.py:283-371
+//   TransformerBlocks / Attention     :171-202 / :90-169        FeedForward :78-88
+//   MaskGit.generate                  :511-627                   SelfCritic  :388-396
+//
+// What is hoisted out of the 18-iteration loop (all of it is arithmetic the reference repeats identically 72 times per call):
+//   * geometric image embedding + condition (BEV) embedding          (depend only on cameras / cond ids)
+//   * cross-attention K/V of every layer (to_kv(context) + l2norm)    (context is never updated)
+//   * the attention-bias matrices                                     (built once in bevgen_finalize)
+// and what is dropped: the classifier-free-guidance "null" forwards (bit-identical to the conditional ones in eval mode,
+// muse_net:352) and the critic forward after the last iteration (its scores are never read).
+#include "model.h"
+
+namespace bevgen {
+
+namespace {
+
+struct MuseWs {
+    int B = 0;
+    long rows = 0;
+    float *img = nullptr, *c_embed = nullptr, *context = nullptr;
+    std::vector<float*> crossK, crossV;
+    float *x = nullptr, *xn = nullptr, *qraw = nullptr, *kvraw = nullptr, *Q = nullptr, *Ks = nullptr, *Vs = nullptr, *att = nullptr, *h = nullptr, *g = nullptr;
+};
+
+size_t muse_ws_bytes(const Ctx& c, int B) {
+    const size_t rows = (size_t)B * c.N;
+    const size_t crows = (size_t)B * c.K;
+    size_t f = 0;
+    f += rows * c.D * 2;                 // img, x
+    f += (size_t)B * c.cfg.num_cams * c.D + crows * c.D;
+    f += (size_t)c.cfg.num_layers * 2 * B * c.H * c.NkC_pad * 64;
+    f += rows * c.D * 3;                 // xn, qraw, att
+    f += std::max(rows, crows) * 2 * c.D; // kvraw
+    f += rows * c.D;                     // Q
+    f += (size_t)2 * B * c.H * c.NkS_pad * 64;
+    f += rows * 2 * c.F + rows * c.Fpad;
+    f += rows * (c.V + 1);               // logits, scores (generate)
+    return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256;
+}
+
+void gemm(const float* A, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s) {
+    GemmArgs g;
+    g.A = A; g.B = W; g.C = C; g.R = R;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    launch_gemm(g, s);
+}
+
+// per-batch constants: embeddings + cross-attention K/V
+void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s) {
+    const auto& g = c.cfg;
+    const std::string p = "transformer.";
+    w.B = B;
+    w.rows = (long)B * c.N;
+    Arena& a = c.arena;
+    a.reserve(muse_ws_bytes(c, B));
+    a.reset();
+    const int D = c.D, H = c.H;
+    w.img = g.image_embed ? a.get<float>((size_t)w.rows * D) : nullptr;
+    w.c_embed = g.image_embed ? a.get<float>((size_t)B * g.num_cams * D) : nullptr;
+    w.context = a.get<float>((size_t)B * c.K * D);
+    w.x = a.get<float>((size_t)w.rows * D);
+    w.xn = a.get<float>((size_t)w.rows * D);
+    w.qraw = a.get<float>((size_t)w.rows * D);
+    w.att = a.get<float>((size_t)w.rows * D);
+    w.kvraw = a.get<float>((size_t)std::max<long>(w.rows, (long)B * c.K) * 2 * D);
+    w.Q = a.get<float>((size_t)w.rows * D);
+    const size_t kvS = (size_t)B * H * c.NkS_pad * 64;
+    w.Ks = a.get<float>(kvS);
+    w.Vs = a.get<float>(kvS);
+    w.h = a.get<float>((size_t)w.rows * 2 * c.F);
+    w.g = a.get<float>((size_t)w.rows * c.Fpad);
+    HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
+    HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
+
+    if (g.image_embed)
+        launch_camera_embed(I_inv, E_inv, c.image_plane, c.pf(p + "img_embed.weight"), c.pf(p + "cam_embed.weight"), w.img, w.c_embed, B, g.num_cams, c.T, D, s);
+    launch_cond_embed(cond, c.pf(p + "cond_token_emb.weight"), c.pf(p + "cond_pos_emb.weight"), g.bev_embed ? c.pf(p + "bev_grid") : nullptr,
+                      g.bev_embed ? c.pf(p + "bev_embed.weight") : nullptr, g.bev_embed ? c.pf(p + "bev_embed.bias") : nullptr,
+                      g.bev_embed ? c.pf(p + "bev_cam_pos_emb") : nullptr, w.c_embed, w.context, B, g.num_cams, c.K, D, g.cond_vocab_size, s);
+
+    // cross-attention keys/values: to_kv(context) (context is NOT layer-normed, muse_net:128-132), null kv prepended, k l2-normalised
+    const size_t kvC = (size_t)B * H * c.NkC_pad * 64;
+    w.crossK.resize(g.num_layers);
+    w.crossV.resize(g.num_layers);
+    for (int i = 0; i < g.num_layers; ++i) {
+        w.crossK[i] = a.get<float>(kvC);
+        w.crossV[i] = a.get<float>(kvC);
+        HIP_CHECK(hipMemsetAsync(w.crossK[i], 0, kvC * sizeof(float), s));
+        HIP_CHECK(hipMemsetAsync(w.crossV[i], 0, kvC * sizeof(float), s));
+        const MuseLayer& l = c.muse[i];
+        gemm(w.context, D, l.to_kv[1], D, w.kvraw, 2 * D, B * c.K, 2 * D, D, nullptr, 0, s);
+        launch_muse_kv_prep(w.kvraw, l.null_kv[1], l.k_scale[1], w.crossK[i], w.crossV[i], B, H, c.K, c.NkC_pad, s);
+    }
+}
+
+// one transformer pass over the current ids: leaves LayerNorm(x) (= `embed`, muse_net:202) in w.xn
+void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
+    const auto& g = c.cfg;
+    const std::string p = "transformer.";
+    const int D = c.D, H = c.H, B = w.B, N = c.N;
+    const int rows = (int)w.rows;
+    launch_token_embed(ids, c.pf(p + "token_emb.weight"), w.img, c.pf(p + "pos_emb.weight"), w.x, B, N, D, g.vocab_size + 1, s);
+    for (int i = 0; i < g.num_layers; ++i) {
+        const MuseLayer& l = c.muse[i];
+        // ---- self attention
+        launch_layernorm(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
+        gemm(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+        gemm(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
+        launch_muse_q_prep(w.qraw, l.q_scale[0], w.Q, B, H, N, s);
+        launch_muse_kv_prep(w.kvraw, l.null_kv[0], l.k_scale[0], w.Ks, w.Vs, B, H, N, c.NkS_pad, s);
+        AttnArgs a{};
+        a.Q = w.Q; a.K = w.Ks; a.V = w.Vs; a.bias = c.bias_self; a.R = nullptr; a.O = w.att;
+        a.B = B; a.H = H; a.Nq = N; a.Nk_pad = c.NkS_pad;
+        a.q_bstride = (long)H * N * 64; a.q_hstride = (long)N * 64;
+        a.kv_bstride = (long)H * c.NkS_pad * 64; a.kv_hstride = (long)c.NkS_pad * 64;
+        a.ldbias = c.ldS; a.bias_head_stride = 0; a.scale = 8.0f;
+        a.o_bstride = (long)N * D; a.o_qstride = D; a.o_hstride = 64;
+        launch_attention(a, s);
+        gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);  // x = to_out(att) + x
+        // ---- cross attention
+        launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
+        gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+        launch_muse_q_prep(w.qraw, l.q_scale[1], w.Q, B, H, N, s);
+        a.K = w.crossK[i]; a.V = w.crossV[i]; a.bias = c.bias_cross; a.Nk_pad = c.NkC_pad;
+        a.kv_bstride = (long)H * c.NkC_pad * 64; a.kv_hstride = (long)c.NkC_pad * 64;
+        a.ldbias = c.ldC;
+        launch_attention(a, s);
+        gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
+        // ---- feed forward
+        launch_layernorm(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
+        gemm(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
+        launch_geglu_layernorm(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+        gemm(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s);
+    }
+    launch_layernorm(w.x, D, c.pf(p + "transformer_blocks.norm.gamma"), nullptr, w.xn, D, rows, D, 1e-5f, s);
+}
+
+}  // namespace
+
+void muse_forward(Ctx& c, const int64_t* ids, const int64_t* cond, const float* I_inv, const float* E_inv, int B, float* logits, float* embed, hipStream_t s) {
+    BG_REQUIRE(c.cfg.route == BEVGEN_ROUTE_MASKGIT, "context was not created for the MaskGit route");
+    BG_REQUIRE(B >= 1, "batch must be positive");
+    MuseWs w;
+    muse_prepare(c, w, cond, I_inv, E_inv, B, s);
+    muse_blocks(c, w, ids, s);
+    const int rows = (int)w.rows;
+    if (embed) HIP_CHECK(hipMemcpyAsync(embed, w.xn, (size_t)rows * c.D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (logits) gemm(w.xn, c.D, c.pf("transformer.to_logits.weight"), c.D, logits, c.V, rows, c.V, c.D, nullptr, 0, s);
+}
+
+void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
+                      int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, hipStream_t s) {
+    BG_REQUIRE(c.cfg.route == BEVGEN_ROUTE_MASKGIT, "context was not created for the MaskGit route");
+    BG_REQUIRE(B >= 1 && timesteps >= 1 && sched, "bad generate arguments");
+    MuseWs w;
+    muse_prepare(c, w, cond, I_inv, E_inv, B, s);
+    const int rows = (int)w.rows;            // B*C*T token rows
+    const int seqs = B * c.cfg.num_cams;     // rows of the [B*C, T] id matrix
+    const int T = c.T, V = c.V, D = c.D;
+    float* logits = c.arena.get<float>((size_t)rows * V);
+    float* scores = c.arena.get<float>((size_t)rows);
+    const int64_t mask_id = c.cfg.vocab_size;
+    int64_t* ids = out;  // generation happens in the caller's output buffer
+    launch_fill_i64(ids, rows, mask_id, s);
+    launch_fill(scores, rows, 0.f, s);
+    for (int step = 0; step < timesteps; ++step) {
+        const int steps_until_x0 = timesteps - 1 - step;
+        const double frac = (double)steps_until_x0 / (double)timesteps;
+        launch_remask(ids, scores, init_ids, seqs, T, sched[step], mask_id, s);
+        muse_blocks(c, w, ids, s);
+        gemm(w.xn, D, c.pf("transformer.to_logits.weight"), D, logits, V, rows, V, D, nullptr, 0, s);
+        launch_maskgit_pick(ids, logits, V, gumbel_u ? gumbel_u + (size_t)step * rows * V : nullptr, rows, V, topk_k, (float)((double)temperature * frac), mask_id, s);
+        if (step + 1 < timesteps) {  // the critic scores only select what the NEXT iteration re-masks
+            muse_blocks(c, w, ids, s);
+            launch_critic_scores(w.xn, D, c.pf("token_critic.to_pred.weight"), c.pf("token_critic.to_pred.bias"),
+                                 critic_u ? critic_u + (size_t)step * rows : nullptr, critic_noise_scale, (float)frac, scores, rows, D, s);
+        }
+    }
+}
+
+}  // namespace bevgen

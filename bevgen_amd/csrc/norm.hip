@@ -1,0 +1,224 @@
+// Normalisation kernels: LayerNorm (Route A nn.LayerNorm, Route M gamma-only LayerNorm muse_net:62-69), fused GEGLU+LayerNorm
+// (muse_net:71-88), GroupNorm(32, eps=1e-6)(+swish) of the VQGAN decoder (stage1/model.py:29-35), row softmax.
+// All are HBM/L2-bandwidth bound: one wave per row, 16-byte accesses where alignment allows, statistics two-pass in fp32
+// (GroupNorm partial sums in fp64, reduced in a fixed order -> run-to-run deterministic).
+#include "common.h"
+#include "kernels.h"
+
+namespace bevgen {
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y, int ldy, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * ldx;
+    float* yr = y + (long)row * ldy;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += xr[i];
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+    for (int i = lane; i < D; i += 64) { const float d = xr[i] - mean; v = fmaf(d, d, v); }
+    const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+    for (int i = lane; i < D; i += 64) {
+        float o = (xr[i] - mean) * rstd * gamma[i];
+        if (beta) o += beta[i];
+        yr[i] = o;
+    }
+    for (int i = D + lane; i < ldy; i += 64) yr[i] = 0.f;
+}
+
+void launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int rows, int D, float eps, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU + LayerNorm
+constexpr int GEGLU_MAX_PER_LANE = 48;  // F <= 3072
+
+__global__ __launch_bounds__(256) void geglu_layernorm_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ gamma,
+                                                              float* __restrict__ y, int ldy, int rows, int F, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* a = h + (long)row * ldh;
+    const float* gate = a + F;
+    float g[GEGLU_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < GEGLU_MAX_PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        g[j] = 0.f;
+        if (i < F) {
+            g[j] = gate[i] * gelu_erf(a[i]);
+            s += g[j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)F;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < GEGLU_MAX_PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < F) { const float d = g[j] - mean; v = fmaf(d, d, v); }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)F + eps);
+    float* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int j = 0; j < GEGLU_MAX_PER_LANE; ++j) {
+        const int i = lane + 64 * j;
+        if (i < F) yr[i] = (g[j] - mean) * rstd * gamma[i];
+        else if (i < ldy) yr[i] = 0.f;
+    }
+}
+
+void launch_geglu_layernorm(const float* h, int ldh, const float* gamma, float* y, int ldy, int rows, int F, float eps, hipStream_t s) {
+    BG_REQUIRE(F <= 64 * GEGLU_MAX_PER_LANE && ldy <= 64 * GEGLU_MAX_PER_LANE, "geglu_layernorm: inner width %d too large", F);
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(geglu_layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm (NHWC, 32 groups)
+constexpr int GN_GROUPS = 32;
+constexpr int GN_PIX_PER_BLOCK = 1024;
+
+// stage 1: per (image, pixel chunk) partial (sum, sumsq) of every group, fp64, fixed reduction order
+__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int hw, int C, int chunks) {
+    __shared__ double sh[256][4][2];
+    __shared__ double chs[1024][2];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, n = blockIdx.y;
+    const int q4 = C >> 2;                 // float4 per pixel
+    const int cq = tid % q4, psub = tid / q4, pstep = 256 / q4;
+    const int p_begin = chunk * GN_PIX_PER_BLOCK;
+    const int p_end = min(hw, p_begin + GN_PIX_PER_BLOCK);
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float* base = x + ((long)n * hw) * C + cq * 4;
+    for (int p = p_begin + psub; p < p_end; p += pstep) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (long)p * C);
+        s[0] += v.x; ss[0] += (double)v.x * v.x;
+        s[1] += v.y; ss[1] += (double)v.y * v.y;
+        s[2] += v.z; ss[2] += (double)v.z * v.z;
+        s[3] += v.w; ss[3] += (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sh[tid][i][0] = s[i]; sh[tid][i][1] = ss[i]; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {  // per-channel sums over the pixel sub-lanes, in order
+        const int q = c >> 2, i = c & 3;
+        double a = 0, b = 0;
+        for (int ps = 0; ps < pstep; ++ps) { a += sh[ps * q4 + q][i][0]; b += sh[ps * q4 + q][i][1]; }
+        chs[c][0] = a; chs[c][1] = b;
+    }
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+        const int cpg = C / GN_GROUPS;
+        double a = 0, b = 0;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chs[c][0]; b += chs[c][1]; }
+        double* o = part + (((long)n * chunks + chunk) * GN_GROUPS + tid) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
+__global__ void groupnorm_finalize_kernel(const double* __restrict__ part, float* __restrict__ stats, int chunks, double count, float eps, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // n*32 + g
+    if (i >= total) return;
+    const int n = i / GN_GROUPS, g = i % GN_GROUPS;
+    double a = 0, b = 0;
+    for (int c = 0; c < chunks; ++c) {
+        const double* p = part + (((long)n * chunks + c) * GN_GROUPS + g) * 2;
+        a += p[0]; b += p[1];
+    }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+size_t groupnorm_ws_bytes(int n, int hw) { return (size_t)n * cdiv(hw, GN_PIX_PER_BLOCK) * GN_GROUPS * 2 * sizeof(double); }
+
+void launch_groupnorm_stats(const float* x, float* stats, void* ws, int n, int hw, int C, float eps, hipStream_t s) {
+    BG_REQUIRE(C % GN_GROUPS == 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "groupnorm: unsupported channel count %d", C);
+    const int chunks = cdiv(hw, GN_PIX_PER_BLOCK);
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(chunks, n), dim3(256), 0, s, x, part, hw, C, chunks);
+    LAUNCH_CHECK();
+    const int total = n * GN_GROUPS;
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, part, stats, chunks,
+                       (double)hw * (C / GN_GROUPS), eps, total);
+    LAUNCH_CHECK();
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ y, long total4, int hw, int C, int do_swish) {
+    const int cpg = C / GN_GROUPS;
+    const int q4 = C >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % q4);
+        const long pix = i / q4;
+        const int n = (int)(pix / hw);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cq * 4 + k;
+            const float* st = stats + ((long)n * GN_GROUPS + c / cpg) * 2;
+            float o = (in[k] - st[0]) * st[1] * gamma[c] + beta[c];
+            if (do_swish) o = o / (1.f + expf(-o));
+            out[k] = o;
+        }
+        reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s) {
+    const long total4 = (long)n * hw * C / 4;
+    const int blocks = (int)std::min<long>((total4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, total4, hw, C, do_swish);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------ row softmax (VQGAN AttnBlock, s1model:179-181)
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x, int rows, int cols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + row * cols;
+    float mx = kNegBig;
+    for (int i = lane; i < cols; i += 64) mx = fmaxf(mx, xr[i] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < cols; i += 64) sum += expf(xr[i] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < cols; i += 64) xr[i] = expf(xr[i] * scale - mx) * inv;
+}
+
+void launch_row_softmax(float* x, int rows, int cols, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, cols, scale);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------ misc
+__global__ void fill_kernel(float* p, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill(float* p, long n, float v, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, p, n, v);
+    LAUNCH_CHECK();
+}
+__global__ void add_kernel(const float* a, const float* b, float* c, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) c[i] = a[i] + b[i];
+}
+void launch_add(const float* a, const float* b, float* c, long n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(add_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, a, b, c, n);
+    LAUNCH_CHECK();
+}
+
+}  // namespace bevgen

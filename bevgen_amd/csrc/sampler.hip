@@ -1,0 +1,211 @@
+// Token sampling kernels.
+//
+//   MaskGit (Route M): re-masking by critic score, top-k filtered gumbel-argmax, self-critic scores
+//                      muse_maskgit_pytorch.py:443-458 (helpers), :564-611 (generate loop)
+//   Autoregressive (Route A): temperature, top-k (ties kept), softmax, greedy / inverse-CDF draw
+//                      cond_transformer_multi_view.py:138-142, 204-219
+// One wave per vocabulary row; the k-th largest logit is found by a 32-step bitwise search on the order-preserving integer image
+// of the floats (no sort, no LDS), counting with wave reductions.
+#include "common.h"
+#include "kernels.h"
+
+namespace bevgen {
+
+constexpr int VPL_MAX = 16;  // vocabulary <= 1024 (64 lanes x 16)
+
+__device__ __forceinline__ uint32_t ordered_key(float x) {  // monotone float -> uint32
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// k-th largest key of the wave's values (ties counted): largest t with count(key >= t) >= k
+__device__ __forceinline__ uint32_t kth_largest_key(const uint32_t (&key)[VPL_MAX], const bool (&valid)[VPL_MAX], int k) {
+    uint32_t t = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = t | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < VPL_MAX; ++j) cnt += (valid[j] && key[j] >= cand) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (cnt >= k) t = cand;
+    }
+    return t;
+}
+
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {  // largest value, lowest index on ties
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- re-masking
+__global__ __launch_bounds__(256) void remask_kernel(int64_t* __restrict__ ids, const float* __restrict__ scores, const int64_t* __restrict__ init_ids,
+                                                     int T, int n_mask, int64_t mask_id) {
+    extern __shared__ float sc[];
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) sc[i] = scores[(long)row * T + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        const float s = sc[i];
+        int rank = 0;
+        for (int j = 0; j < T; ++j) rank += (sc[j] > s || (sc[j] == s && j < i)) ? 1 : 0;
+        int64_t v = ids[(long)row * T + i];
+        if (rank < n_mask) v = mask_id;
+        if (init_ids) {
+            const int64_t iv = init_ids[(long)row * T + i];
+            if (iv != mask_id) v = iv;
+        }
+        ids[(long)row * T + i] = v;
+    }
+}
+
+void launch_remask(int64_t* ids, const float* scores, const int64_t* init_ids, int rows, int T, int n_mask, int64_t mask_id, hipStream_t s) {
+    hipLaunchKernelGGL(remask_kernel, dim3(rows), dim3(256), T * sizeof(float), s, ids, scores, init_ids, T, n_mask, mask_id);
+    LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------- MaskGit token pick
+__global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__ ids, const float* __restrict__ logits, int ldl, const float* __restrict__ gumbel_u,
+                                                           long rows, int V, int k, float temp_div, int64_t mask_id) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    if (ids[row] != mask_id) return;  // only masked positions are replaced (muse_net:593-599)
+    const float* lr = logits + row * ldl;
+    float x[VPL_MAX];
+    uint32_t key[VPL_MAX];
+    bool valid[VPL_MAX];
+#pragma unroll
+    for (int j = 0; j < VPL_MAX; ++j) {
+        const int i = lane + 64 * j;
+        valid[j] = i < V;
+        x[j] = valid[j] ? lr[i] : 0.f;
+        key[j] = ordered_key(x[j]);
+    }
+    uint32_t thr = 0;
+    if (gumbel_u) thr = kth_largest_key(key, valid, k);  // without noise the arg-max is unaffected by the top-k filter
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < VPL_MAX; ++j) {
+        const int i = lane + 64 * j;
+        if (!valid[j] || key[j] < thr) continue;
+        float v = x[j] / temp_div;
+        if (gumbel_u) {
+            const float u = gumbel_u[row * V + i];
+            const float l1 = logf(fmaxf(u, 1e-20f));
+            v += -logf(fmaxf(-l1, 1e-20f));
+        }
+        if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+    }
+    wave_argmax(best, bidx);
+    if (lane == 0) ids[row] = bidx;
+}
+
+void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float* gumbel_u, int rows, int V, int k, float temperature, int64_t mask_id, hipStream_t s) {
+    BG_REQUIRE(V <= 64 * VPL_MAX, "maskgit_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
+    const float temp_div = fmaxf(temperature, 1e-10f);
+    hipLaunchKernelGGL(maskgit_pick_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, logits, ldl, gumbel_u, (long)rows, V, k, temp_div, mask_id);
+    LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------- self-critic scores
+__global__ __launch_bounds__(256) void critic_scores_kernel(const float* __restrict__ embed, int lde, const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ u, float noise_scale, float frac, float* __restrict__ scores, long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* e = embed + row * lde;
+    float acc = 0.f;
+    for (int i = lane * 4; i < D; i += 256) {
+        const float4 ev = *reinterpret_cast<const float4*>(e + i);
+        const float4 wv = *reinterpret_cast<const float4*>(w + i);
+        acc = fmaf(ev.x, wv.x, acc); acc = fmaf(ev.y, wv.y, acc); acc = fmaf(ev.z, wv.z, acc); acc = fmaf(ev.w, wv.w, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float sc = acc + b[0];
+        const float uu = u ? u[row] : 0.5f;
+        sc += ((uu - 0.5f) * noise_scale) * frac;
+        scores[row] = sc;
+    }
+}
+
+void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u, float noise_scale, float frac, float* scores, int rows, int D, hipStream_t s) {
+    BG_REQUIRE(D % 4 == 0, "critic_scores: D must be a multiple of 4");
+    hipLaunchKernelGGL(critic_scores_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, embed, lde, w, b, u, noise_scale, frac, scores, (long)rows, D);
+    LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------- Route A token pick
+// lane owns the contiguous index range [lane*VPL, lane*VPL + VPL) so that the cumulative distribution runs in index order
+__global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ u, int64_t* __restrict__ out, int V, int top_k, float temperature) {
+    const int lane = threadIdx.x;
+    const long row = blockIdx.x;
+    const float* lr = logits + row * ldl;
+    const int per = (V + 63) / 64;
+    float x[VPL_MAX];
+    uint32_t key[VPL_MAX];
+    bool valid[VPL_MAX];
+#pragma unroll
+    for (int j = 0; j < VPL_MAX; ++j) {
+        const int i = lane * per + j;
+        valid[j] = j < per && i < V;
+        x[j] = valid[j] ? lr[i] / temperature : -INFINITY;
+        key[j] = ordered_key(x[j]);
+    }
+    if (top_k > 0 && top_k < V) {
+        const uint32_t thr = kth_largest_key(key, valid, top_k);
+#pragma unroll
+        for (int j = 0; j < VPL_MAX; ++j)
+            if (valid[j] && key[j] < thr) x[j] = -INFINITY;  // values below the k-th largest -> -inf, ties kept (ar_lm:141)
+    }
+    float mx = -INFINITY;
+    int midx = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < VPL_MAX; ++j)
+        if (valid[j] && x[j] > mx) { mx = x[j]; midx = lane * per + j; }
+    wave_argmax(mx, midx);
+    if (!u) {
+        if (lane == 0) out[row] = midx;
+        return;
+    }
+    // inverse-CDF draw: first index whose cumulative probability exceeds u * total
+    float e[VPL_MAX], local = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL_MAX; ++j) {
+        e[j] = valid[j] ? expf(x[j] - mx) : 0.f;
+        local += e[j];
+    }
+    float incl = local;  // inclusive scan across lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const float total = __shfl(incl, 63, 64);
+    const float target = u[row] * total;
+    float run = incl - local;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < VPL_MAX; ++j) {
+        if (!valid[j]) continue;
+        run += e[j];
+        cnt += (run <= target) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) out[row] = min(cnt, V - 1);
+}
+
+void launch_ar_pick(const float* logits, int ldl, const float* u, int64_t* out, int rows, int V, int top_k, float temperature, hipStream_t s) {
+    BG_REQUIRE(V <= 64 * VPL_MAX, "ar_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
+    hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, out, V, top_k, temperature);
+    LAUNCH_CHECK();
+}
+
+}  // namespace bevgen

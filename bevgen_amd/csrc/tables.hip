@@ -1,0 +1,160 @@
+// Setup-time device kernels: derived tables built once in bevgen_finalize (attention-bias matrices, visibility masks,
+// weight re-layouts) and the tiny per-step helpers of the Route A decode loop.
+#include "common.h"
+#include "model.h"
+
+namespace bevgen {
+
+// attn_bias = tril_scatter(camera_bias_emb) + prob_matrix    (mingpt_sparse.py:375-380 / muse_maskgit_pytorch.py:343-348)
+// torch.tril_indices(L, L) enumerates (r, c<=r) row-major, so entry (r,c) is element r(r+1)/2 + c of the parameter.
+__global__ void build_attn_bias_kernel(const float* __restrict__ emb, const float* __restrict__ prob, float* __restrict__ out, int L) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)L * L) return;
+    const int r = (int)(i / L), c = (int)(i % L);
+    float v = (emb && c <= r) ? emb[(long)r * (r + 1) / 2 + c] : 0.f;
+    if (prob) v += prob[i];
+    out[i] = v;
+}
+void launch_build_attn_bias(const float* emb, const float* prob, float* out, int L, hipStream_t s) {
+    hipLaunchKernelGGL(build_attn_bias_kernel, dim3(cdiv((long)L * L, 256)), dim3(256), 0, s, emb, prob, out, L);
+    LAUNCH_CHECK();
+}
+
+// Route M (muse_maskgit_pytorch.py:150-156): self  bias = pad_left0(attn_bias[K:, K:]),  cross bias = pad_left0(attn_bias[K:, :K]);
+// columns beyond the real keys get -1e30 so that the flash kernel needs no key-bound test.
+__global__ void build_muse_bias_kernel(const float* __restrict__ ab, int L, int K, int N, float* __restrict__ bs, int ldS, float* __restrict__ bc, int ldC) {
+    const int q = blockIdx.x;
+    for (int j = threadIdx.x; j < ldS; j += blockDim.x)
+        bs[(long)q * ldS + j] = j == 0 ? 0.f : (j <= N ? ab[(long)(K + q) * L + K + j - 1] : kNegBig);
+    for (int j = threadIdx.x; j < ldC; j += blockDim.x)
+        bc[(long)q * ldC + j] = j == 0 ? 0.f : (j <= K ? ab[(long)(K + q) * L + j - 1] : kNegBig);
+}
+void launch_build_muse_bias(const float* ab, int L, int K, int N, float* bs, int ldS, float* bc, int ldC, hipStream_t s) {
+    hipLaunchKernelGGL(build_muse_bias_kernel, dim3(N), dim3(256), 0, s, ab, L, K, N, bs, ldS, bc, ldC);
+    LAUNCH_CHECK();
+}
+
+// Route A visibility: keep[h][r][c] = attention_mask[r][c] != 0  AND  layout[h][r/blk][c/blk] != 0   (sparse_self_attention.py:153-173)
+__global__ void build_keep_kernel(const float* __restrict__ allowed, const int64_t* __restrict__ layout, uint8_t* __restrict__ keep, int L, int block) {
+    const int h = blockIdx.y;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)L * L) return;
+    const int r = (int)(i / L), c = (int)(i % L);
+    const int nb = L / block;
+    const bool present = layout[((long)h * nb + r / block) * nb + c / block] != 0;
+    keep[(long)h * L * L + i] = (present && allowed[i] != 0.f) ? 1 : 0;
+}
+void launch_build_keep(const float* allowed, const int64_t* layout, uint8_t* keep, int heads, int L, int block, hipStream_t s) {
+    hipLaunchKernelGGL(build_keep_kernel, dim3(cdiv((long)L * L, 256), heads), dim3(256), 0, s, allowed, layout, keep, L, block);
+    LAUNCH_CHECK();
+}
+
+// out[h][r][c] = keep ? scale * add[r][c] : -1e30   (c >= cols -> -1e30): bias operand of the flash kernel for Route A
+__global__ void build_masked_bias_kernel(const float* __restrict__ add, const uint8_t* __restrict__ keep, long keep_head_stride, int ldkeep, float* __restrict__ out,
+                                         int rows, int cols, int ldout, int ldadd, float scale) {
+    const int r = blockIdx.x, h = blockIdx.y;
+    for (int c = threadIdx.x; c < ldout; c += blockDim.x) {
+        float v = kNegBig;
+        if (c < cols && keep[h * keep_head_stride + (long)r * ldkeep + c]) v = add ? scale * add[(long)r * ldadd + c] : 0.f;
+        out[((long)h * rows + r) * ldout + c] = v;
+    }
+}
+void launch_build_masked_bias(const float* add, const uint8_t* keep, long keep_head_stride, int ldkeep, float* out, int heads, int rows, int cols, int ldout,
+                              int ldadd, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(build_masked_bias_kernel, dim3(rows, heads), dim3(256), 0, s, add, keep, keep_head_stride, ldkeep, out, rows, cols, ldout, ldadd, scale);
+    LAUNCH_CHECK();
+}
+
+// Route A decode: x[b,:] = (x_tok_emb[tok[b]] + img_embed[b, cam, cell]) + x_pos_emb[j],  j = forward_shuffle_idx[step]
+// (mingpt_sparse.py:331-365 restricted to the one new row; the step lives on the device so the launch is graph-replayable)
+__global__ __launch_bounds__(256) void ar_step_embed_kernel(const int64_t* __restrict__ tok, const float* __restrict__ tok_emb, const float* __restrict__ img_embed,
+                                                            const float* __restrict__ pos_emb, const int64_t* __restrict__ fwd_idx, const int* __restrict__ d_step,
+                                                            float* __restrict__ x, int C, int T, int D, int vocab_rows) {
+    const int b = blockIdx.x;
+    const long j = fwd_idx[*d_step];
+    long id = tok[b];
+    id = id < 0 ? 0 : (id >= vocab_rows ? vocab_rows - 1 : id);
+    for (int o = threadIdx.x; o < D; o += 256) {
+        float v = tok_emb[id * D + o];
+        if (img_embed) v += img_embed[((long)b * C * T + j) * D + o];
+        x[(long)b * D + o] = v + pos_emb[j * D + o];
+    }
+}
+void launch_ar_step_embed(const int64_t* tok, const float* tok_emb, const float* img_embed, const float* pos_emb, const int64_t* fwd_idx, const int* d_step,
+                          float* x, int B, int C, int T, int D, int vocab_rows, hipStream_t s) {
+    hipLaunchKernelGGL(ar_step_embed_kernel, dim3(B), dim3(256), 0, s, tok, tok_emb, img_embed, pos_emb, fwd_idx, d_step, x, C, T, D, vocab_rows);
+    LAUNCH_CHECK();
+}
+
+// out[b, fwd_idx[step]] = tok[b]   (x[:, i, k] = ix, cond_transformer_multi_view.py:219)
+__global__ void store_tokens_kernel(const int64_t* __restrict__ tok, const int64_t* __restrict__ fwd_idx, const int* __restrict__ d_step, int64_t* __restrict__ out, int B, int N) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[(long)b * N + fwd_idx[*d_step]] = tok[b];
+}
+void launch_store_tokens(const int64_t* tok, const int64_t* fwd_idx, const int* d_step, int64_t* out, int B, int N, hipStream_t s) {
+    hipLaunchKernelGGL(store_tokens_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, tok, fwd_idx, d_step, out, B, N);
+    LAUNCH_CHECK();
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int row, int rows_per_batch, int D) {
+    const int b = blockIdx.x;
+    for (int o = threadIdx.x; o < D; o += blockDim.x) out[(long)b * D + o] = x[((long)b * rows_per_batch + row) * D + o];
+}
+void launch_gather_rows(const float* x, float* out, int B, int row, int rows_per_batch, int D, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, s, x, out, row, rows_per_batch, D);
+    LAUNCH_CHECK();
+}
+
+__global__ void increment_kernel(int* p) { *p += 1; }
+void launch_increment(int* p, hipStream_t s) {
+    hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(1), 0, s, p);
+    LAUNCH_CHECK();
+}
+
+// conv kernels: [Cout][Cin][kh][kw] (torch) -> [Cout][kh][kw][Cin] (K-contiguous over (tap, channel) for the implicit GEMM)
+__global__ void relayout_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int cout, int cin, int kh, int kw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)cout * cin * kh * kw;
+    if (i >= total) return;
+    const int ci = (int)(i % cin);
+    long t = i / cin;
+    const int x = (int)(t % kw); t /= kw;
+    const int y = (int)(t % kh);
+    const int co = (int)(t / kh);
+    o[i] = w[(((long)co * cin + ci) * kh + y) * kw + x];
+}
+void launch_relayout_conv_weight(const float* w, float* o, int cout, int cin, int kh, int kw, hipStream_t s) {
+    hipLaunchKernelGGL(relayout_conv_weight_kernel, dim3(cdiv((long)cout * cin * kh * kw, 256)), dim3(256), 0, s, w, o, cout, cin, kh, kw);
+    LAUNCH_CHECK();
+}
+
+__global__ void fuse_qkv_kernel(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, float* w, float* b, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long dd = (long)D * D;
+    if (i < dd) { w[i] = wq[i]; w[dd + i] = wk[i]; w[2 * dd + i] = wv[i]; }
+    if (i < D) { b[i] = bq[i]; b[D + i] = bk[i]; b[2 * D + i] = bv[i]; }
+}
+void launch_fuse_qkv(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, float* w, float* b, int D, hipStream_t s) {
+    hipLaunchKernelGGL(fuse_qkv_kernel, dim3(cdiv((long)D * D, 256)), dim3(256), 0, s, wq, wk, wv, bq, bk, bv, w, b, D);
+    LAUNCH_CHECK();
+}
+
+__global__ void pad_rows_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int cols) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < ld_dst; c += blockDim.x) dst[(long)r * ld_dst + c] = c < cols ? src[(long)r * ld_src + c] : 0.f;
+}
+void launch_pad_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(rows), dim3(256), 0, s, src, ld_src, dst, ld_dst, cols);
+    LAUNCH_CHECK();
+}
+
+__global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill_i64(int64_t* p, long n, int64_t v, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, p, n, v);
+    LAUNCH_CHECK();
+}
+
+}  // namespace bevgen

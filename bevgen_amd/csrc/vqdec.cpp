@@ -1,0 +1,268 @@
+// Stage-1 VQGAN decode:  ids -> codebook rows -> post_quant_conv -> Decoder -> (denormalise)
+//   VectorQuantizer2.get_codebook_entry   stage1/quantize.py:314-329
+//   VQModel.decode                        stage1/vqgan.py:118-121
+//   Decoder.forward                       stage1/model.py:506-537   ResnetBlock :117-137, AttnBlock :168-192, Upsample :49-53
+//   util.denormalize_tensor               bev_utils/util.py:97-118
+//
+// Activations are NHWC so that every convolution is an implicit GEMM with K = (tap, channel) contiguous:
+//   3x3 conv  -> gemm.hip MODE_CONV3 (im2col gather in the A-tile loader, nearest-2x upsample fused into the gather)
+//   1x1 conv  -> plain GEMM over pixels
+//   AttnBlock -> four 1x1 GEMMs + batched Q K^T / softmax / P V GEMMs (single head of width C, 256 tokens)
+// GroupNorm(32)+swish is a stats pass + an elementwise pass; residual adds ride in the GEMM epilogues.
+#include "model.h"
+
+namespace bevgen {
+
+namespace {
+
+const std::string kPrefix = "first_stage_model.";
+
+ConvW load_conv(Ctx& c, const std::string& name, int k) {
+    const DevTensor& w = c.need(kPrefix + name + ".weight");
+    BG_REQUIRE(w.shape.size() == 4 && w.shape[2] == k && w.shape[3] == k, "conv '%s' is not a %dx%d kernel", name.c_str(), k, k);
+    ConvW cw;
+    cw.cout = (int)w.shape[0];
+    cw.cin = (int)w.shape[1];
+    cw.k = k;
+    cw.b = c.pf(kPrefix + name + ".bias");
+    cw.w = reinterpret_cast<float*>(c.own(w.bytes));
+    launch_relayout_conv_weight(w.f(), cw.w, cw.cout, cw.cin, k, k, 0);
+    return cw;
+}
+
+ResBlockW load_res(Ctx& c, const std::string& p) {
+    ResBlockW r;
+    r.n1w = c.pf(kPrefix + p + "norm1.weight"); r.n1b = c.pf(kPrefix + p + "norm1.bias");
+    r.n2w = c.pf(kPrefix + p + "norm2.weight"); r.n2b = c.pf(kPrefix + p + "norm2.bias");
+    r.c1 = load_conv(c, p + "conv1", 3);
+    r.c2 = load_conv(c, p + "conv2", 3);
+    r.cin = r.c1.cin; r.cout = r.c1.cout;
+    r.has_nin = c.find(kPrefix + p + "nin_shortcut.weight") != nullptr;
+    if (r.has_nin) r.nin = load_conv(c, p + "nin_shortcut", 1);
+    BG_REQUIRE(r.has_nin == (r.cin != r.cout), "resnet block '%s': shortcut/channels mismatch", p.c_str());
+    return r;
+}
+
+AttnBlockW load_attn(Ctx& c, const std::string& p) {
+    AttnBlockW a;
+    a.nw = c.pf(kPrefix + p + "norm.weight"); a.nb = c.pf(kPrefix + p + "norm.bias");
+    a.q = load_conv(c, p + "q", 1); a.k = load_conv(c, p + "k", 1); a.v = load_conv(c, p + "v", 1); a.proj = load_conv(c, p + "proj_out", 1);
+    a.c = a.q.cin;
+    return a;
+}
+
+struct Act { float* p; int n, h, w, c; long elems() const { return (long)n * h * w * c; } };
+
+void conv3(const Act& x, const ConvW& w, float* y, const float* residual, int up, hipStream_t s) {
+    GemmArgs g;
+    const int oh = up ? x.h * 2 : x.h, ow = up ? x.w * 2 : x.w;
+    g.mode = MODE_CONV3;
+    g.A = x.p; g.B = w.w; g.C = y; g.R = residual; g.bias_n = w.b;
+    g.M = x.n * oh * ow; g.N = w.cout; g.K = 9 * w.cin;
+    g.lda = w.cin; g.ldb = 9 * w.cin; g.ldc = w.cout; g.ldr = w.cout;
+    g.conv_h = oh; g.conv_w = ow; g.conv_cin = w.cin; g.conv_up = up;
+    launch_gemm(g, s);
+}
+
+void conv1(const float* x, long rows, const ConvW& w, float* y, const float* residual, hipStream_t s) {
+    GemmArgs g;
+    g.A = x; g.B = w.w; g.C = y; g.R = residual; g.bias_n = w.b;
+    g.M = (int)rows; g.N = w.cout; g.K = w.cin;
+    g.lda = w.cin; g.ldb = w.cin; g.ldc = w.cout; g.ldr = w.cout;
+    launch_gemm(g, s);
+}
+
+struct DecWs {
+    float *a, *b, *t;   // ping-pong activations + temp (each max_act floats)
+    float* stats;       // [n*32*2]
+    void* gn_ws;
+    float *q, *k, *vT, *S;
+};
+
+void gn(const Act& x, const float* w, const float* b, float* y, int swish, DecWs& ws, hipStream_t s) {
+    launch_groupnorm_stats(x.p, ws.stats, ws.gn_ws, x.n, x.h * x.w, x.c, 1e-6f, s);
+    launch_groupnorm_apply(x.p, ws.stats, w, b, y, x.n, x.h * x.w, x.c, swish, s);
+}
+
+// x (in ws.a-or-b) -> out buffer `y`; uses ws.t and the other ping-pong buffer as scratch
+void resblock(const ResBlockW& r, Act& x, float* y, float* scratch, DecWs& ws, hipStream_t s) {
+    // h = conv1(swish(norm1(x)))
+    gn(x, r.n1w, r.n1b, ws.t, 1, ws, s);
+    Act t{ws.t, x.n, x.h, x.w, r.cin};
+    conv3(t, r.c1, scratch, nullptr, 0, s);
+    Act h1{scratch, x.n, x.h, x.w, r.cout};
+    gn(h1, r.n2w, r.n2b, ws.t, 1, ws, s);
+    Act t2{ws.t, x.n, x.h, x.w, r.cout};
+    const float* shortcut = x.p;
+    if (r.has_nin) {  // x = nin_shortcut(x)  (1x1), written over h1 (no longer needed after norm2)
+        conv1(x.p, (long)x.n * x.h * x.w, r.nin, scratch, nullptr, s);
+        shortcut = scratch;
+    }
+    conv3(t2, r.c2, y, shortcut, 0, s);  // y = x + conv2(...)
+    x = Act{y, x.n, x.h, x.w, r.cout};
+}
+
+void attnblock(const AttnBlockW& a, Act& x, float* y, DecWs& ws, hipStream_t s) {
+    const int hw = x.h * x.w, C = a.c, n = x.n;
+    const long rows = (long)n * hw;
+    Act t{ws.t, n, x.h, x.w, C};
+    gn(x, a.nw, a.nb, ws.t, 0, ws, s);
+    conv1(ws.t, rows, a.q, ws.q, nullptr, s);
+    conv1(ws.t, rows, a.k, ws.k, nullptr, s);
+    {   // vT[img] [C, hw] = Wv [C,C] * h_img^T + bias (per row)
+        GemmArgs g;
+        g.A = a.v.w; g.B = ws.t; g.C = ws.vT; g.bias_m = a.v.b;
+        g.M = C; g.N = hw; g.K = C; g.lda = C; g.ldb = C; g.ldc = hw;
+        g.batch = n; g.strideA = 0; g.strideB = (long)hw * C; g.strideC = (long)C * hw;
+        launch_gemm(g, s);
+    }
+    {   // S[img] [hw, hw] = q k^T
+        GemmArgs g;
+        g.A = ws.q; g.B = ws.k; g.C = ws.S;
+        g.M = hw; g.N = hw; g.K = C; g.lda = C; g.ldb = C; g.ldc = hw;
+        g.batch = n; g.strideA = (long)hw * C; g.strideB = (long)hw * C; g.strideC = (long)hw * hw;
+        launch_gemm(g, s);
+    }
+    launch_row_softmax(ws.S, (int)rows, hw, 1.0f / sqrtf((float)C), s);  // w_ * int(c)**-0.5, softmax over keys
+    {   // O[img] [hw, C] = P [hw,hw] * v [hw, C]  (B operand = vT [C, hw])
+        GemmArgs g;
+        g.A = ws.S; g.B = ws.vT; g.C = ws.q;  // reuse q as the output buffer
+        g.M = hw; g.N = C; g.K = hw; g.lda = hw; g.ldb = hw; g.ldc = C;
+        g.batch = n; g.strideA = (long)hw * hw; g.strideB = (long)C * hw; g.strideC = (long)hw * C;
+        launch_gemm(g, s);
+    }
+    conv1(ws.q, rows, a.proj, y, x.p, s);  // x + proj_out(h)
+    x = Act{y, n, x.h, x.w, C};
+}
+
+}  // namespace
+
+void vq_finalize(Ctx& c) {
+    const auto& g = c.cfg;
+    BG_REQUIRE(g.vq_num_levels >= 1 && g.vq_num_levels <= 8, "vq_num_levels out of range");
+    const DevTensor& cb = c.need(kPrefix + "quantize.embedding.weight");
+    BG_REQUIRE(cb.shape.size() == 2 && cb.shape[0] == g.vq_n_embed && cb.shape[1] == g.vq_embed_dim, "codebook must be [n_embed, embed_dim]");
+    c.codebook = cb.f();
+    c.post_quant = load_conv(c, "post_quant_conv", 1);
+    c.conv_in = load_conv(c, "decoder.conv_in", 3);
+    c.mid1 = load_res(c, "decoder.mid.block_1.");
+    c.mid_attn = load_attn(c, "decoder.mid.attn_1.");
+    c.mid2 = load_res(c, "decoder.mid.block_2.");
+    c.up.clear();
+    c.up.resize(g.vq_num_levels);
+    int res = g.vq_resolution >> (g.vq_num_levels - 1);
+    for (int lvl = g.vq_num_levels - 1; lvl >= 0; --lvl) {
+        UpLevelW& u = c.up[lvl];
+        for (int b = 0; b < g.vq_num_res_blocks + 1; ++b) {
+            const std::string p = "decoder.up." + std::to_string(lvl) + ".";
+            u.blocks.push_back(load_res(c, p + "block." + std::to_string(b) + "."));
+            if (res == g.vq_attn_resolution) u.attns.push_back(load_attn(c, p + "attn." + std::to_string(b) + "."));
+        }
+        u.has_up = lvl != 0;
+        if (u.has_up) {
+            u.up = load_conv(c, "decoder.up." + std::to_string(lvl) + ".upsample.conv", 3);
+            res *= 2;
+        }
+    }
+    c.norm_out_w = c.pf(kPrefix + "decoder.norm_out.weight");
+    c.norm_out_b = c.pf(kPrefix + "decoder.norm_out.bias");
+    c.conv_out = load_conv(c, "decoder.conv_out", 3);
+    const float mean[3] = {0.4265f, 0.4489f, 0.4769f}, stdv[3] = {0.2053f, 0.2206f, 0.2578f};
+    c.denorm_mean = reinterpret_cast<float*>(c.own(sizeof mean));
+    c.denorm_std = reinterpret_cast<float*>(c.own(sizeof stdv));
+    HIP_CHECK(hipMemcpy(c.denorm_mean, mean, sizeof mean, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(c.denorm_std, stdv, sizeof stdv, hipMemcpyHostToDevice));
+    c.has_vq = true;
+}
+
+void vq_decode(Ctx& c, const int64_t* ids, int n_total, int denorm, float* out, hipStream_t s) {
+    BG_REQUIRE(c.has_vq, "this context was created without a VQGAN decoder (vq_ch == 0)");
+    const auto& g = c.cfg;
+    const int lat = g.vq_resolution >> (g.vq_num_levels - 1);
+    const int R = g.vq_resolution;
+    BG_REQUIRE(!denorm || g.vq_out_ch == 3, "denormalize needs 3 output channels");
+    // widest activation per image: max over levels of res^2 * channels
+    long per_img = 0;
+    int max_c = 0;
+    {
+        int res = lat;
+        for (int lvl = g.vq_num_levels - 1; lvl >= 0; --lvl) {
+            const int ch = g.vq_ch * g.vq_ch_mult[lvl];
+            const int ch_in = lvl == g.vq_num_levels - 1 ? ch : g.vq_ch * g.vq_ch_mult[lvl + 1];
+            per_img = std::max<long>(per_img, (long)res * res * std::max(ch, ch_in));
+            max_c = std::max(max_c, std::max(ch, ch_in));
+            if (lvl != 0) res *= 2;
+        }
+    }
+    const int chunk_max = 16;
+    const int attn_c = max_c;
+    const long attn_hw = std::max<long>((long)g.vq_attn_resolution * g.vq_attn_resolution, (long)lat * lat);
+    const int chunk = std::min(n_total, chunk_max);
+    const size_t act_b = (size_t)per_img * chunk * sizeof(float);
+    const size_t need = 4 * act_b + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, R * R) +
+                        (size_t)chunk * attn_hw * (3 * attn_c + attn_hw) * sizeof(float) + (size_t)chunk * lat * lat * g.vq_embed_dim * sizeof(float) +
+                        (size_t)chunk * R * R * 4 * sizeof(float) + 32 * 256;
+    c.arena.reserve(need);
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = std::min(chunk, n_total - i0);
+        c.arena.reset();
+        DecWs ws;
+        ws.a = c.arena.get<float>((size_t)per_img * n);
+        ws.b = c.arena.get<float>((size_t)per_img * n);
+        ws.t = c.arena.get<float>((size_t)per_img * n);
+        ws.stats = c.arena.get<float>((size_t)n * 64);
+        ws.gn_ws = c.arena.alloc(groupnorm_ws_bytes(n, R * R));
+        ws.q = c.arena.get<float>((size_t)n * attn_hw * attn_c);
+        ws.k = c.arena.get<float>((size_t)n * attn_hw * attn_c);
+        ws.vT = c.arena.get<float>((size_t)n * attn_hw * attn_c);
+        ws.S = c.arena.get<float>((size_t)n * attn_hw * attn_hw);
+        float* zq = c.arena.get<float>((size_t)n * lat * lat * g.vq_embed_dim);
+        float* img = c.arena.get<float>((size_t)n * R * R * 4);
+
+        const long lrows = (long)n * lat * lat;
+        launch_codebook_gather(ids + (long)i0 * lat * lat, c.codebook, zq, (int)lrows, g.vq_embed_dim, g.vq_n_embed, s);
+        conv1(zq, lrows, c.post_quant, ws.t, nullptr, s);                       // post_quant_conv
+        Act x{ws.t, n, lat, lat, g.vq_z_channels};
+        conv3(x, c.conv_in, ws.a, nullptr, 0, s);                               // conv_in
+        x = Act{ws.a, n, lat, lat, c.conv_in.cout};
+        // three rotating activation buffers (input / scratch / output of a block) + ws.t for the normalised tensor
+        float* o = c.arena.get<float>((size_t)per_img * n);
+        auto res_step = [&](const ResBlockW& r) {
+            // buffers: x.p in {a,b,o}; pick scratch and y as the two others
+            float* bufs[3] = {ws.a, ws.b, o};
+            float* scratch = nullptr; float* y = nullptr;
+            for (float* b : bufs) { if (b != x.p) { if (!scratch) scratch = b; else y = b; } }
+            resblock(r, x, y, scratch, ws, s);
+        };
+        auto attn_step = [&](const AttnBlockW& ab) {
+            float* bufs[3] = {ws.a, ws.b, o};
+            float* y = nullptr;
+            for (float* b : bufs) if (b != x.p) { y = b; break; }
+            attnblock(ab, x, y, ws, s);
+        };
+        res_step(c.mid1);
+        attn_step(c.mid_attn);
+        res_step(c.mid2);
+        for (int lvl = g.vq_num_levels - 1; lvl >= 0; --lvl) {
+            const UpLevelW& u = c.up[lvl];
+            for (size_t b = 0; b < u.blocks.size(); ++b) {
+                res_step(u.blocks[b]);
+                if (!u.attns.empty()) attn_step(u.attns[b]);
+            }
+            if (u.has_up) {  // nearest 2x + 3x3 conv, fused
+                float* bufs[3] = {ws.a, ws.b, o};
+                float* y = nullptr;
+                for (float* b : bufs) if (b != x.p) { y = b; break; }
+                conv3(x, u.up, y, nullptr, 1, s);
+                x = Act{y, x.n, x.h * 2, x.w * 2, u.up.cout};
+            }
+        }
+        gn(x, c.norm_out_w, c.norm_out_b, ws.t, 1, ws, s);
+        Act t{ws.t, x.n, x.h, x.w, x.c};
+        conv3(t, c.conv_out, img, nullptr, 0, s);  // [n, R*R, out_ch]
+        launch_nhwc_to_nchw(img, out + (long)i0 * g.vq_out_ch * R * R, n, R * R, g.vq_out_ch, g.vq_out_ch, denorm ? c.denorm_mean : nullptr,
+                            denorm ? c.denorm_std : nullptr, denorm ? 1 : 0, s);
+    }
+}
+
+}  // namespace bevgen

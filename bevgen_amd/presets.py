@@ -16,7 +16,7 @@ VQ_DDCONFIG_F16 = dict(double_z=False, z_channels=256, resolution=256, in_channe
                        ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[16], dropout=0.0)
 VQ_DDCONFIG_F8_128 = dict(VQ_DDCONFIG_F16, resolution=128, ch_mult=[1, 1, 2, 4])  # config 1: 128x128 -> 16x16 latents
 VQ_DDCONFIG_TINY = dict(double_z=False, z_channels=64, resolution=64, in_channels=3, out_ch=3, ch=32,
-                        ch_mult=[1, 1, 2, 2, 4], num_res_blocks=2, attn_resolutions=[4], dropout=0.0)
+                        ch_mult=[1, 1, 2, 4], num_res_blocks=2, attn_resolutions=[8], dropout=0.0)  # 64x64 -> 8x8 latents
 
 _COMMON = dict(embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0, n_unmasked=0, plot=False, backend="hip", image_embed=True)
 
@@ -82,8 +82,8 @@ def config4() -> GPTConfig:
     return route_a(6)
 
 
-def tiny_route_m(num_cams: int = 3, legacy: bool = True) -> GPTConfig:
-    return route_m(num_cams, num_layers=2, dim=128, heads=2, vocab=64, cam_res=(64, 64), cam_latent_res=(4, 4),
+def tiny_route_m(num_cams: int = 3, legacy: bool = True, latent=(4, 4)) -> GPTConfig:
+    return route_m(num_cams, num_layers=2, dim=128, heads=2, vocab=64, cam_res=(64, 64), cam_latent_res=latent,
                    bev_latent_res=(4, 4), legacy_prob_matrix=legacy)
 
 

@@ -1,0 +1,296 @@
+"""Thin Python host over the C ABI: one ``Context`` per (device, model).
+
+PyTorch is used for device memory, streams and (later) ``torch.distributed`` only: every tensor handed to the library is a
+raw ``data_ptr()``; all arithmetic of the hot path happens inside libbevgen_hip's HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Mapping, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, tables
+from ._lib import bevgen_cfg
+from .weights import ff_inner_dim
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype, device, name: str) -> torch.Tensor:
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+def mask_schedule(timesteps: int, seq_len: int):
+    """Host logic of MaskGit.generate (muse_net:564-567), evaluated with torch fp32 exactly like the reference:
+    n_t = max(int(cos(t*pi/2) * T), 1) for t in linspace(0,1,timesteps)."""
+    out = []
+    for t in torch.linspace(0, 1, timesteps):
+        out.append(max(int((torch.cos(t * math.pi * 0.5) * seq_len).item()), 1))
+    return out
+
+
+def topk_count(thres: float, vocab: int) -> int:
+    """muse_net:454: k = ceil((1 - thres) * V)."""
+    return math.ceil((1 - thres) * vocab)
+
+
+class Context:
+    """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
+
+    def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
+                 device: Optional[int] = None, max_batch: int = 0, precision: str = "fp32"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("bevgen_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product")
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.cfg = cfg
+        c = bevgen_cfg()
+        c.abi_version = _lib.ABI_VERSION
+        c.route = _lib.ROUTE_MASKGIT if route == "maskgit" else _lib.ROUTE_AR
+        c.precision = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16}[precision]
+        c.max_batch = max_batch
+        if cfg is not None:
+            c.num_layers, c.num_heads, c.dim = cfg.num_layers, cfg.num_heads, cfg.num_embed
+            c.vocab_size, c.cond_vocab_size = cfg.vocab_size, cfg.cond_vocab_size
+            c.num_cams, c.cam_latent_h, c.cam_latent_w = cfg.num_cams, cfg.cam_latent_h, cfg.cam_latent_w
+            c.num_cond_tokens, c.seq_len, c.sparse_block_size = cfg.num_cond_tokens, cfg.gpt_block_size, cfg.sparse_block_size
+            c.image_embed, c.bev_embed, c.camera_bias = int(cfg.image_embed), int(cfg.bev_embed), int(cfg.camera_bias)
+            c.ff_inner = ff_inner_dim(cfg.num_embed) if route == "maskgit" else 0
+        self.vq_ddconfig = dict(vq_ddconfig) if vq_ddconfig is not None else None
+        if vq_ddconfig is not None:
+            dd = vq_ddconfig
+            mult = list(dd["ch_mult"])
+            c.vq_ch, c.vq_num_res_blocks, c.vq_z_channels = dd["ch"], dd["num_res_blocks"], dd["z_channels"]
+            c.vq_embed_dim, c.vq_n_embed, c.vq_resolution, c.vq_out_ch = vq_embed_dim, vq_n_embed, dd["resolution"], dd["out_ch"]
+            c.vq_num_levels = len(mult)
+            for i, m in enumerate(mult):
+                c.vq_ch_mult[i] = m
+            attn = list(dd["attn_resolutions"])
+            c.vq_attn_resolution = attn[0] if attn else 0
+        self._c = c
+        self.route = route
+        h = C.c_void_p()
+        code = self.lib.bevgen_create(C.byref(c), self.device_index, C.byref(h))
+        if code != 0:
+            raise _lib.BevgenError(code, (self.lib.bevgen_last_error(None) or b"").decode())
+        self._h = h
+        self._finalized = False
+
+    # ------------------------------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.bevgen_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, code):
+        _lib.check(self._h, code)
+
+    def load_tensor(self, name: str, t) -> None:
+        a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        if a.dtype == np.float32:
+            dt = _lib.DTYPE_F32
+        elif a.dtype == np.float64:
+            dt = _lib.DTYPE_F64
+        elif a.dtype == np.int64:
+            dt = _lib.DTYPE_I64
+        elif a.dtype == np.uint8:
+            dt = _lib.DTYPE_U8
+        else:
+            a = a.astype(np.float32)
+            dt = _lib.DTYPE_F32
+        a = np.ascontiguousarray(a)
+        shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        self._check(self.lib.bevgen_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), dt, a.ndim, shape))
+        self._finalized = False
+
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor], prefix: str = "") -> None:
+        """Upload every tensor of a reference-named state_dict under ``prefix`` (e.g. 'first_stage_model.')."""
+        for k, v in sd.items():
+            self.load_tensor(prefix + k, v)
+
+    def set_tables(self, cfg=None) -> None:
+        cfg = cfg or self.cfg
+        self.load_tensor("table.forward_shuffle_idx", cfg.forward_shuffle_idx.to(torch.int64))
+        self.load_tensor("table.attention_mask", cfg.attention_mask.to(torch.float32))
+        self.load_tensor("table.layout", cfg.layout.to(torch.int64))
+        if cfg.prob_matrix is not None:
+            self.load_tensor("table.prob_matrix", cfg.prob_matrix.to(torch.float32))  # the reference casts the (float64, legacy) prior to the activation dtype
+        if cfg.image_embed:
+            self.load_tensor("table.image_plane", tables.image_plane(cfg).reshape(3, -1))
+
+    def finalize(self) -> None:
+        self._check(self.lib.bevgen_finalize(self._h))
+        self._finalized = True
+
+    # ------------------------------------------------------------------------------------------ Route M
+    def muse_forward(self, ids, cond_ids, I_inv, E_inv, want_logits=True, want_embed=True):
+        cfg = self.cfg
+        d = self.device
+        ids = _req(ids, torch.int64, d, "ids")
+        cond_ids = _req(cond_ids, torch.int64, d, "cond_ids")
+        I_inv = _req(I_inv, torch.float32, d, "I_inv")
+        E_inv = _req(E_inv, torch.float32, d, "E_inv")
+        B = cond_ids.shape[0]
+        rows = B * cfg.num_cams
+        logits = torch.empty((rows, cfg.num_cam_tokens, cfg.vocab_size), dtype=torch.float32, device=d) if want_logits else None
+        embed = torch.empty((rows, cfg.num_cam_tokens, cfg.num_embed), dtype=torch.float32, device=d) if want_embed else None
+        self._check(self.lib.bevgen_muse_forward(self._h, _ptr(ids), _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, _ptr(logits), _ptr(embed), _stream()))
+        return logits, embed
+
+    def maskgit_generate(self, cond_ids, I_inv, E_inv, *, timesteps=18, temperature=1.0, topk_filter_thres=0.9, critic_noise_scale=1.0,
+                         gumbel_u=None, critic_u=None, init_ids=None):
+        cfg = self.cfg
+        d = self.device
+        cond_ids = _req(cond_ids, torch.int64, d, "cond_ids")
+        I_inv = _req(I_inv, torch.float32, d, "I_inv")
+        E_inv = _req(E_inv, torch.float32, d, "E_inv")
+        B = cond_ids.shape[0]
+        rows = B * cfg.num_cams
+        T = cfg.num_cam_tokens
+        sched = mask_schedule(timesteps, T)
+        sched_c = (C.c_int32 * timesteps)(*sched)
+        if gumbel_u is not None:
+            gumbel_u = _req(gumbel_u, torch.float32, d, "gumbel_u")
+            assert tuple(gumbel_u.shape) == (timesteps, rows, T, cfg.vocab_size), gumbel_u.shape
+        if critic_u is not None:
+            critic_u = _req(critic_u, torch.float32, d, "critic_u")
+            assert tuple(critic_u.shape) == (timesteps, rows, T), critic_u.shape
+        if init_ids is not None:
+            init_ids = _req(init_ids, torch.int64, d, "init_ids").reshape(rows, T)
+        out = torch.empty((rows, T), dtype=torch.int64, device=d)
+        self._check(self.lib.bevgen_maskgit_generate(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, timesteps, sched_c, float(temperature),
+                                                      topk_count(topk_filter_thres, cfg.vocab_size), float(critic_noise_scale), _ptr(gumbel_u), _ptr(critic_u),
+                                                      _ptr(init_ids), _ptr(out), _stream()))
+        return out.reshape(rows, cfg.cam_latent_h, cfg.cam_latent_w)
+
+    # ------------------------------------------------------------------------------------------ Route A
+    def sparse_self_attention(self, q, k, v, layout, attn_mask, add_mask, block):
+        d = self.device
+        q, k, v = (_req(t, torch.float32, d, "qkv") for t in (q, k, v))
+        B, H, L, dh = q.shape
+        assert dh == 64, "head dimension must be 64"
+        layout = _req(layout, torch.int64, d, "layout")
+        attn_mask = _req(attn_mask.reshape(L, L), torch.float32, d, "attn_mask")
+        add = None if add_mask is None else _req(add_mask.reshape(L, L), torch.float32, d, "add_mask")
+        out = torch.empty_like(q)
+        self._check(self.lib.bevgen_sparse_self_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(layout), _ptr(attn_mask), _ptr(add), B, H, L, int(block), _ptr(out), _stream()))
+        return out
+
+    def ar_prefill(self, cond_ids, I_inv, E_inv):
+        d = self.device
+        cond_ids = _req(cond_ids, torch.int64, d, "cond_ids")
+        I_inv = _req(I_inv, torch.float32, d, "I_inv")
+        E_inv = _req(E_inv, torch.float32, d, "E_inv")
+        self._ar_B = cond_ids.shape[0]
+        self._check(self.lib.bevgen_ar_prefill(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), self._ar_B, _stream()))
+
+    def ar_logits(self):
+        out = torch.empty((self._ar_B, self.cfg.vocab_size), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_ar_logits(self._h, _ptr(out), _stream()))
+        return out
+
+    def ar_decode_step(self, token):
+        token = _req(token, torch.int64, self.device, "token")
+        self._check(self.lib.bevgen_ar_decode_step(self._h, _ptr(token), _stream()))
+
+    def ar_sample(self, cond_ids, I_inv, E_inv, *, steps=None, top_k=None, temperature=1.0, greedy=True, noise_u=None, samples_per_layout=1, return_logits=False):
+        cfg = self.cfg
+        d = self.device
+        cond_ids = _req(cond_ids, torch.int64, d, "cond_ids")
+        I_inv = _req(I_inv, torch.float32, d, "I_inv")
+        E_inv = _req(E_inv, torch.float32, d, "E_inv")
+        B = cond_ids.shape[0]
+        steps = cfg.num_img_tokens if steps is None else int(steps)
+        if noise_u is not None:
+            noise_u = _req(noise_u, torch.float32, d, "noise_u")
+            assert tuple(noise_u.shape) == (steps, B)
+        out = torch.empty((B, cfg.num_cams, cfg.num_cam_tokens), dtype=torch.int64, device=d)
+        logits = torch.empty((steps, B, cfg.vocab_size), dtype=torch.float32, device=d) if return_logits else None
+        self._check(self.lib.bevgen_ar_sample(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, steps, int(top_k or 0), float(temperature), int(bool(greedy)),
+                                               _ptr(noise_u), int(samples_per_layout), _ptr(out), _ptr(logits), _stream()))
+        return (out, logits) if return_logits else out
+
+    # ------------------------------------------------------------------------------------------ stage 1
+    def vq_decode(self, ids, denormalize=True):
+        dd = self.vq_ddconfig
+        ids = _req(ids, torch.int64, self.device, "ids")
+        n = ids.shape[0]
+        R = dd["resolution"]
+        out = torch.empty((n, dd["out_ch"], R, R), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids.reshape(n, -1)), n, int(bool(denormalize)), _ptr(out), _stream()))
+        return out
+
+    # ------------------------------------------------------------------------------------------ operator level (tests / roofline)
+    def op_gemm(self, a, w, bias=None, residual=None, gelu=False, skinny=False):
+        M, K = a.shape
+        N = w.shape[0]
+        c = torch.empty((M, N), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_op_gemm(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(c), M, N, K, int(gelu), int(skinny), _stream()))
+        return c
+
+    def op_layernorm(self, x, gamma, beta=None, eps=1e-5):
+        y = torch.empty_like(x)
+        self._check(self.lib.bevgen_op_layernorm(self._h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), x.shape[0], x.shape[1], float(eps), _stream()))
+        return y
+
+    def op_geglu_layernorm(self, h, gamma, ldy=None):
+        rows, two_f = h.shape
+        F = two_f // 2
+        ldy = ldy or F
+        y = torch.empty((rows, ldy), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_op_geglu_layernorm(self._h, _ptr(h), _ptr(gamma), _ptr(y), rows, F, ldy, _stream()))
+        return y
+
+    def op_attention(self, q, k, v, bias, scale):
+        B, H, Nq, _ = q.shape
+        Nk_pad = k.shape[2]
+        out = torch.empty((B, Nq, H * 64), dtype=torch.float32, device=self.device)
+        ld = 0 if bias is None else bias.shape[-1]
+        self._check(self.lib.bevgen_op_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(bias), ld, B, H, Nq, Nk_pad, float(scale), _ptr(out), _stream()))
+        return out
+
+    def op_decode_attention(self, q, kcache, vcache, n, bias=None, keep=None, scale=0.125, kv_dtype=0):
+        B, HD = q.shape
+        H = HD // 64
+        Lmax = kcache.shape[2]
+        out = torch.empty((B, HD), dtype=torch.float32, device=self.device)
+        ldb = 0 if bias is None else bias.shape[-1]
+        ldk = 0 if keep is None else keep.shape[-1]
+        khs = 0 if keep is None or keep.dim() < 3 or keep.shape[0] == 1 else keep.shape[1] * keep.shape[2]
+        self._check(self.lib.bevgen_op_decode_attention(self._h, _ptr(q), _ptr(kcache), _ptr(vcache), int(kv_dtype), _ptr(bias), ldb, _ptr(keep), ldk, khs,
+                                                         B, H, int(n), Lmax, float(scale), _ptr(out), _stream()))
+        return out
+
+    def op_conv3x3(self, x_nhwc, w_ohwi, bias, residual=None, upsample=False):
+        n, H, W, Cin = x_nhwc.shape
+        Cout = w_ohwi.shape[0]
+        oh, ow = (2 * H, 2 * W) if upsample else (H, W)
+        y = torch.empty((n, oh, ow, Cout), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_op_conv3x3(self._h, _ptr(x_nhwc), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(y), n, H, W, Cin, Cout, int(upsample), _stream()))
+        return y
+
+    def op_groupnorm(self, x_nhwc, gamma, beta, swish=True):
+        n, H, W, Cc = x_nhwc.shape
+        y = torch.empty_like(x_nhwc)
+        self._check(self.lib.bevgen_op_groupnorm(self._h, _ptr(x_nhwc), _ptr(gamma), _ptr(beta), _ptr(y), n, H * W, Cc, int(swish), _stream()))
+        return y

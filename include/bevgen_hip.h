@@ -1,0 +1,179 @@
+/* libbevgen_hip - C ABI of the MI355X-native BEVGen stage-2 sampling path (gfx950 / ROCm).
+ *
+ * The reference (alexanderswerdlow/BEVGen) is pure Python: it has NO FFI for this path; its "plugin" mechanism is
+ * Hydra `_target_` instantiation of Python classes (configs/experiment/muse_stage_two_multi_view.yaml:17,26,31,41;
+ * configs/model/stage_2.yaml:1,7,9,36,59).  The drop-in is therefore two layers:
+ *   - Python classes with the reference's constructor/forward signatures (package bevgen_amd), and
+ *   - this C ABI underneath them, which is what a maintainer binds (ctypes stub in INTEGRATION.md).
+ * Each entry point below names the reference function whose arithmetic it replaces (paths under
+ * multi_view_generation/, line numbers as in the surveyed tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on failure; bevgen_last_error(ctx) gives the message
+ *   - the CALLER owns every buffer passed in; `const T* d_*` / `T* d_*` are DEVICE pointers (e.g. torch tensor
+ *     data_ptr()), `h_*` are HOST pointers; the library owns weights, KV cache and workspace inside the context
+ *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous on it unless stated otherwise,
+ *     the library performs no hidden host synchronisation on the sampling path
+ *   - one context per (device, model); a context is not thread-safe
+ *   - int64 token ids, fp32 everything else (the arithmetic type is a context property: BEVGEN_PRECISION_*)
+ */
+#ifndef BEVGEN_HIP_H
+#define BEVGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEVGEN_ABI_VERSION 1
+
+enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
+enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 };
+enum { BEVGEN_DTYPE_F32 = 0, BEVGEN_DTYPE_I64 = 1, BEVGEN_DTYPE_U8 = 2, BEVGEN_DTYPE_F64 = 3 };
+
+enum {
+    BEVGEN_OK = 0,
+    BEVGEN_ERR_INVALID = -1,   /* bad argument / missing tensor / unsupported size */
+    BEVGEN_ERR_HIP = -2,       /* a HIP runtime call failed */
+    BEVGEN_ERR_STATE = -3,     /* call order violated (e.g. generate before finalize) */
+    BEVGEN_ERR_INTERNAL = -4
+};
+
+/* Sizes of the stage-2 transformer (mirror of GPTConfig, modules/transformer/mingpt_sparse.py:26-102) and of the
+ * stage-1 VQGAN decoder (ddconfig, configs/model/stage_2.yaml:45-55).  Zero-initialise, then fill. */
+typedef struct bevgen_cfg {
+    int32_t abi_version;     /* = BEVGEN_ABI_VERSION */
+    int32_t route;           /* BEVGEN_ROUTE_* */
+    int32_t precision;       /* BEVGEN_PRECISION_* (arithmetic of projections / KV-cache storage) */
+    int32_t num_layers, num_heads, dim, vocab_size, cond_vocab_size;
+    int32_t num_cams, cam_latent_h, cam_latent_w;      /* T = h*w tokens per camera, N = C*T */
+    int32_t num_cond_tokens;                           /* K (BEV latent cells) */
+    int32_t seq_len;                                   /* L = gpt_block_size */
+    int32_t sparse_block_size;                         /* blk; L % blk == 0 */
+    int32_t image_embed, bev_embed, camera_bias;       /* feature flags */
+    int32_t ff_inner;                                  /* Route M: int(dim*4*2/3); 0 for Route A */
+    int32_t max_batch;                                 /* upper bound on scenes (Route M) / sequences (Route A) per call */
+    /* stage-1 decoder; vq_ch == 0 -> no VQGAN in this context */
+    int32_t vq_ch, vq_num_res_blocks, vq_z_channels, vq_embed_dim, vq_n_embed, vq_resolution, vq_out_ch;
+    int32_t vq_num_levels;
+    int32_t vq_ch_mult[8];
+    int32_t vq_attn_resolution;                        /* spatial size at which AttnBlocks are inserted (16) */
+    int32_t reserved[16];
+} bevgen_cfg;
+
+typedef struct bevgen_ctx bevgen_ctx;
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * lifecycle                                                                                                       */
+int bevgen_create(const bevgen_cfg* cfg, int device, bevgen_ctx** out);
+void bevgen_destroy(bevgen_ctx* ctx);
+const char* bevgen_last_error(const bevgen_ctx* ctx);   /* ctx may be NULL: error of the last failed bevgen_create */
+int bevgen_abi_version(void);
+
+/* Upload one tensor (synchronous H2D copy).  `name` is the reference state_dict key
+ * (utils/general.py:119-160 loader semantics: names listed in bevgen_amd/weights.py), with the prefixes
+ *   "transformer." / "token_critic."  Route M MaskGit keys   (stage2/muse_maskgit_pytorch.py:204-261, 388-392)
+ *   ""                                Route A GPT keys        (transformer/mingpt_sparse.py:267-308)
+ *   "first_stage_model."              stage-1 VQModel keys    (stage1/vqgan.py:31-80)
+ * or one of the static tables (built on the host exactly as in the reference, bevgen_amd/tables.py):
+ *   "table.forward_shuffle_idx" i64[N]   CustomPermuter          transformer/permuter.py:33-88
+ *   "table.attention_mask"      f32[L,L] allowed_pattern[0]      transformer/mask_generator.py:202-206
+ *   "table.layout"              i64[H,L/blk,L/blk]               transformer/mask_generator.py:217-228
+ *   "table.prob_matrix"         f32[L,L] camera-bias prior       transformer/mask_generator.py:172-190
+ *   "table.image_plane"         f32[3,T] pixel plane             transformer/mingpt_sparse.py:288-294
+ * Unknown names are stored and ignored (strict=False). */
+int bevgen_load_tensor(bevgen_ctx* ctx, const char* name, const void* h_data, int dtype, int ndim, const int64_t* shape);
+
+/* Convenience wrapper: the four tables at once (any pointer may be NULL to skip it). */
+int bevgen_set_tables(bevgen_ctx* ctx, const int64_t* h_forward_shuffle_idx, const float* h_attention_mask,
+                      const int64_t* h_layout, const float* h_prob_matrix, const float* h_image_plane);
+
+/* Validate that every tensor the route needs is present and build the derived device data (fused QKV weights,
+ * attention-bias matrices = tril-scatter(camera_bias_emb) + prob_matrix as in mingpt_sparse.py:375-380 /
+ * muse_maskgit_pytorch.py:343-348, visibility masks, re-laid-out conv kernels).  Must precede any compute call. */
+int bevgen_finalize(bevgen_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Route M - MaskGit                                                                                               */
+
+/* TransformerMultiView.forward in eval mode (stage2/muse_maskgit_pytorch.py:283-371):
+ *   d_ids [B*C, T] (mask id = vocab_size), d_cond_ids [B, K], d_I_inv [B,C,3,3], d_E_inv [B,C,4,4]
+ *   -> d_logits [B*C, T, V] and/or d_embed [B*C, T, D] (either may be NULL). */
+int bevgen_muse_forward(bevgen_ctx* ctx, const int64_t* d_ids, const int64_t* d_cond_ids, const float* d_I_inv, const float* d_E_inv,
+                        int B, float* d_logits, float* d_embed, void* stream);
+
+/* MaskGit.generate with the self token critic (stage2/muse_maskgit_pytorch.py:511-627).
+ *   h_mask_schedule[timesteps]  tokens re-masked at each iteration, max(int(cos(pi/2 t) T), 1) (:566-567) - host-computed
+ *   topk_k                      ceil((1 - topk_filter_thres) * V) (:453-454)
+ *   d_gumbel_u [timesteps, B*C, T, V], d_critic_u [timesteps, B*C, T]  explicit U[0,1) noise replacing :430-431/:446-448,
+ *                               NULL = deterministic setting (gumbel noise 0, critic uniform 0.5)
+ *   d_init_ids [B*C, T] or NULL (partial decoding, :543-544, 573-574)
+ *   -> d_out_ids [B*C, T]
+ * The classifier-free-guidance "null" forwards of the reference (:272-276, 394-396) are bit-identical to the conditional
+ * ones in eval mode and are not executed; the critic forward after the last iteration (result unused) is skipped. */
+int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_I_inv, const float* d_E_inv, int B,
+                            int timesteps, const int32_t* h_mask_schedule, float temperature, int topk_k, float critic_noise_scale,
+                            const float* d_gumbel_u, const float* d_critic_u, const int64_t* d_init_ids, int64_t* d_out_ids, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Route A - autoregressive sparse-causal transformer with camera bias (prefill + KV-cache decode)                 */
+
+/* Operator seam: SparseSelfAttention.forward(query, key, value, attn_mask, add_mask)
+ * (transformer/sparse_self_attention.py:103-177): q,k,v,out [B,H,L,64] fp32, layout i64 [H,L/blk,L/blk],
+ * attn_mask f32 [L,L] ('mul' mode: 0 = masked), add_mask f32 [L,L] or NULL.  Dense restatement of the DeepSpeed
+ * sdd/softmax/dsd pipeline: out = softmax(dh^-0.5 (q k^T + add_mask) + M) v.  Stateless (ctx only carries errors/workspace). */
+int bevgen_sparse_self_attention(bevgen_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, const int64_t* d_layout,
+                                 const float* d_attn_mask, const float* d_add_mask, int B, int H, int L, int block, float* d_out, void* stream);
+
+/* GPT.forward over the K condition rows (transformer/mingpt_sparse.py:319-391 restricted to rows 0..K-1): fills the KV cache
+ * of all layers for B sequences and leaves the hidden state of row K-1 ready for bevgen_ar_logits. */
+int bevgen_ar_prefill(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_I_inv, const float* d_E_inv, int B, void* stream);
+
+/* ln_f + head on the newest row (mingpt_sparse.py:386-387): d_logits [B, V] = logits of decode step `n_decoded`. */
+int bevgen_ar_logits(bevgen_ctx* ctx, float* d_logits, void* stream);
+
+/* Feed the token chosen at the current step (stage2/cond_transformer_multi_view.py:219) and advance one position:
+ * embedding of the token at its (camera, latent cell) + one pass over all layers against the KV cache. */
+int bevgen_ar_decode_step(bevgen_ctx* ctx, const int64_t* d_token, void* stream);
+
+/* Net2NetTransformer.sample (stage2/cond_transformer_multi_view.py:154-227) with prefill + KV cache:
+ *   top_k <= 0 disables the filter; greedy != 0 -> arg-max (sample=False), else inverse-CDF draw with d_noise_u [steps, B];
+ *   samples_per_layout: consecutive groups of sequences share cond ids/cameras (B = layouts * samples_per_layout rows are
+ *   passed explicitly; the flag only enables prefix reuse);  -> d_out_ids [B, C, T] (camera-major, like the reference's x) */
+int bevgen_ar_sample(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_I_inv, const float* d_E_inv, int B, int steps,
+                     int top_k, float temperature, int greedy, const float* d_noise_u, int samples_per_layout,
+                     int64_t* d_out_ids, float* d_step_logits /* [steps,B,V] or NULL */, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * stage-1 VQGAN decode                                                                                            */
+
+/* decode_to_img (stage2/cond_transformer_multi_view_muse.py:157-164): get_codebook_entry (stage1/quantize.py:314-329) ->
+ * post_quant_conv + Decoder (stage1/vqgan.py:118-121, stage1/model.py:506-537) [-> util.denormalize_tensor,
+ * bev_utils/util.py:97-118 when denormalize != 0].   d_ids [n, h*w] -> d_out [n, out_ch, H, W] fp32. */
+int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* d_ids, int n, int denormalize, float* d_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Operator-level entry points (parity tests and roofline measurements call the kernels through these)             */
+int bevgen_op_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, const float* d_residual, float* d_c,
+                   int M, int N, int K, int act_gelu, int skinny, void* stream);            /* C = A W^T (+bias)(gelu)(+res) */
+int bevgen_op_layernorm(bevgen_ctx* ctx, const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int rows, int D, float eps, void* stream);
+int bevgen_op_geglu_layernorm(bevgen_ctx* ctx, const float* d_h, const float* d_gamma, float* d_y, int rows, int F, int ldy, void* stream);
+int bevgen_op_attention(bevgen_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, const float* d_bias, int ldbias,
+                        int B, int H, int Nq, int Nk_pad, float scale, float* d_out, void* stream);   /* q [B,H,Nq,64], k/v [B,H,Nk_pad,64] */
+int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* d_q, const void* d_kcache, const void* d_vcache, int kv_dtype,
+                               const float* d_bias, int ldbias, const uint8_t* d_keep, int ldkeep, long keep_head_stride,
+                               int B, int H, int n, int Lmax, float scale, float* d_out, void* stream);
+int bevgen_op_conv3x3(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_w_ohwi, const float* d_bias, const float* d_residual,
+                      float* d_y_nhwc, int n, int H, int W, int Cin, int Cout, int upsample2x, void* stream);
+int bevgen_op_groupnorm(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_gamma, const float* d_beta, float* d_y, int n, int hw, int C,
+                        int swish, void* stream);
+
+/* Per-kernel timing support for bench.py's roofline leg: number of workgroup splits the decode-attention kernel uses. */
+int bevgen_decode_attention_splits(int B, int H, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVGEN_HIP_H */

@@ -1,0 +1,207 @@
+"""Generate tests/golden/*.npz by RUNNING THE IMPORTED REFERENCE (build container only).
+
+TEST INFRASTRUCTURE.  Usage:  python -m oracle.ref_import.make_golden [--only NAME ...] [--skip-full]
+
+Every fixture is data: seeded inputs + the outputs the reference modules (imported from /root/reference through
+oracle/ref_import/stubs.py) produce for them, with this repo's deterministic weights loaded into the reference modules.
+While generating, the CPU restatement (oracle/restate.py) is run on the same inputs and must agree (tolerances below), which
+is what pins the oracle.  Weights are not stored (regenerated from seed + parameter name).
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from bevgen_amd import presets, synthetic  # noqa: E402
+from oracle import cases, restate as R  # noqa: E402
+from oracle.ref_import import refmodels as RM, stubs  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def top2_margin(logits: torch.Tensor) -> float:
+    v = logits.topk(2, dim=-1).values
+    return float((v[..., 0] - v[..., 1]).min())
+
+
+def save(name, **arrays):
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------------------ tables
+TABLE_CASES = {
+    "cfg1": presets.config1,
+    "nusc6_224x400": presets.config4,
+    "argo3_rays": lambda: presets.config2(3),
+    "nusc6_rays": lambda: presets.config2(6),
+    "nusc3_ablation": lambda: presets.route_a(3, num_layers=2),
+    "tiny_a_blk4": lambda: presets.tiny_route_a(3, block=4),
+}
+
+
+def golden_tables():
+    for name, mk in TABLE_CASES.items():
+        cfg = mk()
+        ref = RM.ref_gpt_config(cfg)
+        layouts, allowed = ref.get_mask()
+        L = ref.gpt_block_size
+        K = ref.num_cond_tokens
+        rows = sorted({0, K - 1, K, K + 1, min(L - 1, K + 37), L - 13 if L > 13 else 0, L - 1})
+        prob32 = ref.prob_matrix.to(torch.float32)
+        save("tables_" + name,
+             sizes=np.array([ref.num_cond_tokens, ref.num_cam_tokens, ref.num_img_tokens, ref.num_pad_tokens, ref.gpt_block_size]),
+             forward_shuffle_idx=ref.forward_shuffle_idx.to(torch.int32), layout_bits=np.packbits(layouts.numpy().astype(np.uint8)),
+             layout_shape=np.array(layouts.shape), mask_bits=np.packbits(ref.attention_mask.numpy().astype(np.uint8)),
+             prob_rows_idx=np.array(rows), prob_rows=prob32[rows], prob_sha256=np.array(sha(prob32)), prob_is_f64=np.array(ref.prob_matrix.dtype == torch.float64),
+             image_plane=stubs.import_reference().gpt.generate_grid(ref.cam_latent_h, ref.cam_latent_w).reshape(3, -1) * torch.tensor([ref.cam_res[0], ref.cam_res[1], 1.0])[:, None],
+             bev_grid=stubs.import_reference().gpt.get_bev_grid(ref))
+
+
+# ------------------------------------------------------------------------------------------------ Route M
+def golden_route_m(case: cases.Case, full: bool):
+    cfg = case.make_cfg()
+    sd = cases.maskgit_state_dict(cfg, case.weight_seed)
+    mg, _ = RM.build_ref_maskgit(cfg, sd)
+    bt = cases.inputs(case, cfg)
+    batch = {"intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
+    rows, T = case.batch * cfg.num_cams, cfg.num_cam_tokens
+    g = torch.Generator().manual_seed(case.input_seed)
+    ids = torch.randint(0, cfg.vocab_size + 1, (rows, T), generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        lr, er = mg.transformer(ids, return_embed=True, conditioning_token_ids=bt["cond_ids"], batch=batch)
+    t_fwd = time.time() - t0
+    lo, eo = R.muse_forward(sd, cfg, ids, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], depth=cfg.num_layers, heads=cfg.num_heads)
+    assert rel(lo, lr) < 2e-5 and rel(eo, er) < 2e-5, (rel(lo, lr), rel(eo, er))
+    # deterministic generate
+    with RM.deterministic_maskgit_noise(None), torch.no_grad():
+        gen_ref = mg.generate(cond_images=bt["cond_ids"], fmap_size=cfg.cam_latent_res, batch=batch, timesteps=case.timesteps)
+    trace = []
+    gen_or = R.maskgit_generate(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], depth=cfg.num_layers, heads=cfg.num_heads,
+                                timesteps=case.timesteps, trace=trace)
+    assert torch.equal(gen_ref, gen_or), "oracle generate != reference generate (greedy)"
+    out = dict(ids_in=ids.to(torch.int16), cond_ids=bt["cond_ids"].to(torch.int16), I_inv=bt["intrinsics_inv"], E_inv=bt["extrinsics_inv"],
+               gen_greedy=gen_ref.to(torch.int16), trace_ids=torch.stack([t["ids"] for t in trace]).to(torch.int16),
+               min_margin_greedy=np.array(min(top2_margin(t["logits"]) for t in trace)), ref_forward_seconds=np.array(t_fwd))
+    if not full:
+        noise = cases.maskgit_noise(case, cfg)
+        with RM.deterministic_maskgit_noise(noise), torch.no_grad():
+            gen_ref_n = mg.generate(cond_images=bt["cond_ids"], fmap_size=cfg.cam_latent_res, batch=batch, timesteps=case.timesteps)
+        gen_or_n = R.maskgit_generate(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], depth=cfg.num_layers, heads=cfg.num_heads,
+                                      timesteps=case.timesteps, noise=noise)
+        assert torch.equal(gen_ref_n, gen_or_n), "oracle generate != reference generate (explicit noise)"
+        out.update(logits=lr, embed=er, gen_noisy=gen_ref_n.to(torch.int16), trace_scores=torch.stack([t["scores"] for t in trace]))
+    else:
+        out.update(logits_rows=lr[:, :4].clone(), logits_sha256=np.array(sha(lr)), embed_rows=er[:, :2].clone())
+    save("route_m_" + case.name, **out)
+
+
+# ------------------------------------------------------------------------------------------------ Route A
+def golden_route_a(case: cases.Case, full: bool):
+    cfg = case.make_cfg()
+    sd = cases.gpt_state_dict(cfg, case.weight_seed)
+    gpt, _ = RM.build_ref_gpt(cfg, sd)
+    bt = cases.inputs(case, cfg)
+    batch = {"intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
+    B, C, T, N = case.batch, cfg.num_cams, cfg.num_cam_tokens, cfg.num_img_tokens
+    g = torch.Generator().manual_seed(case.input_seed)
+    ids = torch.randint(0, cfg.vocab_size, (B, C, T), generator=g)
+    with torch.no_grad():
+        lr = gpt(ids.clone(), bt["cond_ids"], batch, sampling=True)
+    lo = R.gpt_forward(sd, cfg, ids, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"])
+    assert rel(lo, lr) < 2e-5, rel(lo, lr)
+    # greedy sampling with the reference's own loop structure (one full forward per token), driven through the reference GPT
+    x = torch.full((B, C, T), cfg.vocab_size, dtype=torch.long)
+    step_logits = []
+    t0 = time.time()
+    with torch.no_grad():
+        for s in range(N):
+            j = int(cfg.forward_shuffle_idx[s])
+            logits = gpt(x, bt["cond_ids"], batch, sampling=True)[:, j]
+            step_logits.append(logits.clone())
+            x[:, j // T, j % T] = logits.softmax(-1).topk(1).indices[:, 0]
+    t_ref = time.time() - t0
+    lc = []
+    xc = R.ar_sample_cached(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], logits_out=lc)
+    assert torch.equal(x, xc), "KV-cache oracle != reference full-recompute sampling (greedy)"
+    err = max(rel(a, b) for a, b in zip(lc, step_logits))
+    assert err < 5e-5, err
+    sl = torch.stack(step_logits)  # [N,B,V]
+    out = dict(ids_in=ids.to(torch.int16), cond_ids=bt["cond_ids"].to(torch.int16), I_inv=bt["intrinsics_inv"], E_inv=bt["extrinsics_inv"],
+               sample_greedy=x.to(torch.int16), min_margin_greedy=np.array(top2_margin(sl)), ref_sample_seconds=np.array(t_ref))
+    if not full:
+        noise_u = synthetic.uniform_noise((N, B), 11, 2)
+        xs = R.ar_sample_full_recompute(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], temperature=0.9, top_k=8, noise_u=noise_u)
+        xs2 = R.ar_sample_cached(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], temperature=0.9, top_k=8, noise_u=noise_u)
+        assert torch.equal(xs, xs2)
+        out.update(logits_full=lr, step_logits=sl, sample_topk8=xs.to(torch.int16))
+    else:
+        keep = sorted({0, 1, 17, N // 2, N - 1})
+        out.update(step_logits_idx=np.array(keep), step_logits=sl[keep])
+    save("route_a_" + case.name, **out)
+
+
+# ------------------------------------------------------------------------------------------------ VQGAN decode
+def golden_vq():
+    v = cases.VQ_TINY
+    dd = v["dd"]
+    sd = cases.vq_state_dict(dd, v["n_embed"], v["embed_dim"], v["seed"], with_encoder=True)
+    lat = dd["resolution"] // 2 ** (len(dd["ch_mult"]) - 1)
+    vq = RM.build_ref_vqmodel(dd, v["n_embed"], v["embed_dim"], sd, (dd["resolution"],) * 2, (lat, lat))
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, v["n_embed"], (v["n_images"], lat * lat), generator=g)
+    with torch.no_grad():
+        zq = vq.quantize.get_codebook_entry(ids.reshape(-1), shape=(v["n_images"], lat, lat, v["embed_dim"]))
+        xr = vq.decode(zq)
+        xd = stubs.import_reference().util.denormalize_tensor(xr, keep_tensor=True)
+    xo = R.vq_decode_ids(sd, dd, ids, (lat, lat), denorm=False)
+    assert rel(xo, xr) < 1e-5, rel(xo, xr)
+    assert (R.denormalize(xo) - xd).abs().max() < 1e-5
+    save("vq_tiny", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--skip-full", action="store_true")
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    want = lambda n: args.only is None or n in args.only
+    if want("tables"):
+        print("tables")
+        golden_tables()
+    if want("vq"):
+        print("vq")
+        golden_vq()
+    for name, case in cases.CASES.items():
+        full = name in ("a_config1", "m_full_3cam")
+        if not want(name) or (full and args.skip_full):
+            continue
+        print(name)
+        t0 = time.time()
+        (golden_route_m if case.route == "m" else golden_route_a)(case, full)
+        print(f"  {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main()

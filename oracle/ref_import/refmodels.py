@@ -49,25 +49,13 @@ def ref_gpt_config(cfg):
         return ns.gpt.GPTConfig(**kw)
 
 
-def muse_kwargs(cfg) -> Dict:
-    return dict(depth=cfg.num_layers, heads=cfg.num_heads, dim_head=64, ff_mult=4, num_tokens=cfg.vocab_size)
+from oracle.cases import muse_kwargs, maskgit_state_dict, gpt_state_dict  # noqa: E402,F401
 
 
-def maskgit_state_dict(cfg, seed: int) -> Dict[str, torch.Tensor]:
-    from bevgen_amd import tables
+def vq_state_dict(dd: Mapping, n_embed: int, embed_dim: int, seed: int, with_encoder: bool = True):
+    from oracle.cases import vq_state_dict as _v
 
-    shapes = W.maskgit_shapes(cfg, **muse_kwargs(cfg))
-    return W.generate_state_dict(shapes, seed, tables={"bev_grid": tables.get_bev_grid(cfg)}, alias=W.maskgit_alias)
-
-
-def gpt_state_dict(cfg, seed: int) -> Dict[str, torch.Tensor]:
-    from bevgen_amd import tables
-
-    return W.generate_state_dict(W.gpt_shapes(cfg), seed, tables={"bev_grid": tables.get_bev_grid(cfg), "master_layout": cfg.layout})
-
-
-def vq_state_dict(dd: Mapping, n_embed: int, embed_dim: int, seed: int, with_encoder: bool = True) -> Dict[str, torch.Tensor]:
-    return W.generate_state_dict(W.vqmodel_shapes(dd, n_embed, embed_dim, with_encoder=with_encoder), seed)
+    return _v(dd, n_embed, embed_dim, seed, with_encoder=with_encoder)
 
 
 def build_ref_maskgit(cfg, sd):

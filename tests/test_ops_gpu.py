@@ -1,0 +1,164 @@
+"""Operator-level parity: each HIP kernel (called through the C ABI) vs a plain PyTorch-CPU fp32 computation of the same op."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 136, 64), (1, 7, 32), (777, 1024, 1024), (300, 5460, 1024), (260, 1024, 2752)])
+@pytest.mark.parametrize("epi", ["none", "bias_gelu_res"])
+def test_gemm(gpu_ctx, M, N, K, epi):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    # asymmetric operands (a transposed output or swapped operand cannot pass)
+    if epi == "none":
+        ref = a.double() @ w.double().t()
+        out = gpu_ctx.op_gemm(dev(a), dev(w))
+    else:
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
+        out = gpu_ctx.op_gemm(dev(a), dev(w), dev(b), dev(r), gelu=True)
+    assert rel(out.cpu().double(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (16, 3072, 1024), (33, 1024, 4096), (64, 1000, 1024), (48, 4096, 1024)])
+def test_gemm_skinny(gpu_ctx, M, N, K):
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
+    out = gpu_ctx.op_gemm(dev(a), dev(w), dev(b), dev(r), gelu=True, skinny=True)
+    assert rel(out.cpu().double(), ref) < 2e-6
+    out2 = gpu_ctx.op_gemm(dev(a), dev(w), skinny=True)
+    assert rel(out2.cpu().double(), a.double() @ w.double().t()) < 2e-6
+
+
+@pytest.mark.parametrize("rows,D,beta", [(5, 128, True), (1000, 1024, False), (37, 1024, True)])
+def test_layernorm(gpu_ctx, rows, D, beta):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, D, generator=g) * 3 + 1
+    gamma = torch.randn(D, generator=g)
+    b = torch.randn(D, generator=g) if beta else None
+    ref = F.layer_norm(x, (D,), gamma, b, 1e-5)
+    out = gpu_ctx.op_layernorm(dev(x), dev(gamma), dev(b) if beta else None)
+    assert rel(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("rows,Fi", [(9, 341), (130, 2730)])
+def test_geglu_layernorm(gpu_ctx, rows, Fi):
+    g = torch.Generator().manual_seed(Fi)
+    h = torch.randn(rows, 2 * Fi, generator=g)
+    gamma = torch.randn(Fi, generator=g)
+    a, gate = h.chunk(2, dim=-1)
+    ref = F.layer_norm(gate * F.gelu(a), (Fi,), gamma, None, 1e-5)
+    ldy = (Fi + 31) // 32 * 32
+    out = gpu_ctx.op_geglu_layernorm(dev(h), dev(gamma), ldy=ldy).cpu()
+    assert rel(out[:, :Fi], ref) < 1e-5
+    assert out[:, Fi:].abs().max() == 0  # zero padding consumed by the following GEMM
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 48, 49), (2, 3, 200, 257), (1, 16, 300, 17), (2, 2, 128, 128)])
+@pytest.mark.parametrize("use_bias", [True, False])
+def test_attention(gpu_ctx, B, H, Nq, Nk, use_bias):
+    if not use_bias and Nk % 32:
+        pytest.skip("bias-less form needs Nk % 32 == 0")
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q = torch.randn(B, H, Nq, 64, generator=g)
+    k = torch.randn(B, H, Nk, 64, generator=g)
+    v = torch.randn(B, H, Nk, 64, generator=g)
+    Nk_pad = (Nk + 31) // 32 * 32
+    kp = torch.zeros(B, H, Nk_pad, 64); kp[:, :, :Nk] = k
+    vp = torch.zeros(B, H, Nk_pad, 64); vp[:, :, :Nk] = v
+    scale = 0.31
+    sim = torch.einsum("bhid,bhjd->bhij", q.double(), k.double()) * scale
+    bias = None
+    if use_bias:
+        bias_real = torch.randn(Nq, Nk, generator=g) * 2
+        bias_real[::3, 1::2] = -1e30  # masked entries
+        bias_real[:, 0] = 0.5         # never a fully masked row
+        sim = sim + bias_real.double()
+        bias = torch.full((Nq, Nk_pad), -1e30)
+        bias[:, :Nk] = bias_real
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v.double()).permute(0, 2, 1, 3).reshape(B, Nq, H * 64)
+    out = gpu_ctx.op_attention(dev(q), dev(kp), dev(vp), dev(bias) if use_bias else None, scale)
+    assert rel(out.cpu().double(), ref) < 5e-6
+
+
+def test_attention_online_softmax_rescale_branch(gpu_ctx):
+    """A key far above the running maximum appears in a LATE tile: every accumulator must be rescaled exactly once."""
+    B, H, Nq, Nk = 1, 1, 64, 256
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, H, Nq, 64, generator=g)
+    k = torch.randn(B, H, Nk, 64, generator=g) * 0.1
+    v = torch.randn(B, H, Nk, 64, generator=g)
+    k[0, 0, 200] = q[0, 0, 7] * 3.0   # spike for query 7 in tile 6
+    k[0, 0, 40] = q[0, 0, 9] * 2.0    # and an early one for query 9
+    sim = torch.einsum("bhid,bhjd->bhij", q.double(), k.double())
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v.double()).permute(0, 2, 1, 3).reshape(B, Nq, 64)
+    out = gpu_ctx.op_attention(dev(q), dev(k), dev(v), None, 1.0)
+    assert rel(out.cpu().double(), ref) < 5e-6
+
+
+@pytest.mark.parametrize("B,H,n,Lmax", [(1, 2, 1, 64), (2, 4, 77, 128), (3, 16, 600, 640), (16, 16, 2368, 2368)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_decode_attention(gpu_ctx, B, H, n, Lmax, masked):
+    g = torch.Generator().manual_seed(n)
+    q = torch.randn(B, H * 64, generator=g)
+    kc = torch.randn(B, H, Lmax, 64, generator=g)
+    vc = torch.randn(B, H, Lmax, 64, generator=g)
+    L = Lmax
+    bias = torch.randn(L, L, generator=g)
+    keep = None
+    scale = 0.125
+    qh = q.reshape(B, H, 64).double()
+    s = (torch.einsum("bhd,bhjd->bhj", qh, kc[:, :, :n].double()) + bias[n - 1, :n].double()) * scale
+    if masked:
+        keep = (torch.rand(H, L, L, generator=g) > 0.3).to(torch.uint8)
+        keep[:, :, 0] = 1
+        s = s.masked_fill(keep[:, n - 1, :n][None] == 0, float("-inf"))
+    ref = torch.einsum("bhj,bhjd->bhd", s.softmax(-1), vc[:, :, :n].double()).reshape(B, H * 64)
+    out = gpu_ctx.op_decode_attention(dev(q), dev(kc), dev(vc), n, bias=dev(bias), keep=dev(keep) if masked else None, scale=scale)
+    assert rel(out.cpu().double(), ref) < 5e-6
+
+
+@pytest.mark.parametrize("n,H,W,Cin,Cout,up", [(2, 8, 8, 64, 128, False), (1, 16, 16, 32, 32, True), (3, 5, 7, 32, 3, False), (1, 32, 32, 128, 64, False)])
+def test_conv3x3(gpu_ctx, n, H, W, Cin, Cout, up):
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    res = torch.randn_like(ref, dtype=torch.float32)
+    ref = ref + res.double()
+    out = gpu_ctx.op_conv3x3(dev(x.permute(0, 2, 3, 1)), dev(w.permute(0, 2, 3, 1)), dev(b), residual=dev(res.permute(0, 2, 3, 1)), upsample=up)
+    assert rel(out.cpu().permute(0, 3, 1, 2).double(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("n,hw,C,swish", [(2, 64, 32, True), (1, 4096, 128, True), (3, 256, 512, False), (2, 100, 64, True)])
+def test_groupnorm(gpu_ctx, n, hw, C, swish):
+    g = torch.Generator().manual_seed(C)
+    h = int(math.isqrt(hw))
+    x = torch.randn(n, C, h, hw // h, generator=g) * 2 + 0.7
+    gamma = torch.randn(C, generator=g)
+    beta = torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, 1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    out = gpu_ctx.op_groupnorm(dev(x.permute(0, 2, 3, 1)), dev(gamma), dev(beta), swish=swish)
+    assert rel(out.cpu().permute(0, 3, 1, 2), ref) < 1e-5

@@ -1,0 +1,70 @@
+"""Static tables: bevgen_amd.tables vs golden vectors produced by the imported reference."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from bevgen_amd import presets, tables
+from conftest import golden
+
+CASES = {
+    "cfg1": presets.config1,
+    "nusc6_224x400": presets.config4,
+    "argo3_rays": lambda: presets.config2(3),
+    "nusc6_rays": lambda: presets.config2(6),
+    "nusc3_ablation": lambda: presets.route_a(3, num_layers=2),
+    "tiny_a_blk4": lambda: presets.tiny_route_a(3, block=4),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_tables_match_reference(name):
+    g = golden("tables_" + name)
+    cfg = CASES[name]()
+    K, T, N, P, L = (int(v) for v in g["sizes"])
+    assert (cfg.num_cond_tokens, cfg.num_cam_tokens, cfg.num_img_tokens, cfg.num_pad_tokens, cfg.gpt_block_size) == (K, T, N, P, L)
+    assert np.array_equal(cfg.forward_shuffle_idx.numpy(), g["forward_shuffle_idx"].astype(np.int64))
+    assert np.array_equal(cfg.backward_shuffle_idx.numpy(), np.argsort(g["forward_shuffle_idx"]))
+    shape = tuple(g["layout_shape"])
+    layout = np.unpackbits(g["layout_bits"])[: int(np.prod(shape))].reshape(shape)
+    assert np.array_equal(cfg.layout.numpy(), layout.astype(np.int64))
+    mask = np.unpackbits(g["mask_bits"])[: L * L].reshape(L, L)
+    assert np.array_equal(cfg.attention_mask.numpy(), mask.astype(np.float32))
+    prob32 = cfg.prob_matrix.to(torch.float32)
+    assert hashlib.sha256(prob32.contiguous().numpy().tobytes()).hexdigest() == str(g["prob_sha256"])  # bit-exact camera-bias prior
+    assert np.array_equal(prob32[g["prob_rows_idx"]].numpy(), g["prob_rows"])
+    assert np.array_equal(tables.image_plane(cfg).reshape(3, -1).numpy(), g["image_plane"])
+    assert np.array_equal(tables.get_bev_grid(cfg).numpy(), g["bev_grid"])
+
+
+def test_identity_order_when_not_causal():
+    cfg = presets.route_a(3, num_layers=1)
+    from bevgen_amd.config import GPTConfig
+    import dataclasses
+
+    kw = {f.name: getattr(cfg, f.name) for f in dataclasses.fields(cfg) if f.init}
+    kw.update(causal_order=False, cam_names=cfg.cam_names.name, dataset=cfg.dataset.name, layouts=None)
+    c2 = GPTConfig(**kw)
+    assert torch.equal(c2.forward_shuffle_idx, torch.arange(c2.num_img_tokens))
+
+
+def test_nuscenes_order_is_a_permutation_center_out():
+    cfg = presets.config4()
+    f = cfg.forward_shuffle_idx
+    assert sorted(f.tolist()) == list(range(cfg.num_img_tokens))
+    # first decoded token: centre column (w odd -> 12) of CAM_FRONT row 0, then CAM_BACK's centre
+    w = cfg.cam_latent_w
+    assert f[0].item() == 0 * cfg.num_cam_tokens + w // 2
+    assert f[1].item() == 1 * cfg.num_cam_tokens + w // 2
+
+
+def test_density_below_one_needs_rng_and_is_seed_reproducible():
+    torch.manual_seed(3)
+    a = presets.route_a(3, num_layers=1, density=0.35).layout
+    torch.manual_seed(3)
+    b = presets.route_a(3, num_layers=1, density=0.35).layout
+    assert torch.equal(a, b)
+    assert not torch.equal(a[0], a[1])  # per-head random layouts
+    full = presets.route_a(3, num_layers=1, density=1.0).layout
+    assert a.sum() < full.sum()
