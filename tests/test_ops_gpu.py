@@ -31,7 +31,7 @@ def test_gemm(gpu_ctx, M, N, K, epi):
         r = torch.randn(M, N, generator=g)
         ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
         out = gpu_ctx.op_gemm(dev(a), dev(w), dev(b), dev(r), gelu=True)
-    assert rel(out.cpu().double(), ref) < 2e-6
+    assert rel(out.cpu().double(), ref) < 6e-6  # fp32 accumulate: ~sqrt(K) eps
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 128), (16, 3072, 1024), (33, 1024, 4096), (64, 1000, 1024), (48, 4096, 1024)])
@@ -43,9 +43,9 @@ def test_gemm_skinny(gpu_ctx, M, N, K):
     r = torch.randn(M, N, generator=g)
     ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
     out = gpu_ctx.op_gemm(dev(a), dev(w), dev(b), dev(r), gelu=True, skinny=True)
-    assert rel(out.cpu().double(), ref) < 2e-6
+    assert rel(out.cpu().double(), ref) < 6e-6  # fp32 accumulate: ~sqrt(K) eps
     out2 = gpu_ctx.op_gemm(dev(a), dev(w), skinny=True)
-    assert rel(out2.cpu().double(), a.double() @ w.double().t()) < 2e-6
+    assert rel(out2.cpu().double(), a.double() @ w.double().t()) < 6e-6
 
 
 @pytest.mark.parametrize("rows,D,beta", [(5, 128, True), (1000, 1024, False), (37, 1024, True)])
