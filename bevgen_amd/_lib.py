@@ -69,6 +69,8 @@ SIGNATURES = {
     "bevgen_op_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "bevgen_op_groupnorm": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "bevgen_decode_attention_splits": (_i, [_i, _i, _i]),
+    "bevgen_profile_begin": (_i, [_p]),
+    "bevgen_profile_end": (_i, [_p, C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None

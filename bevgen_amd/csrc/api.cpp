@@ -1,6 +1,7 @@
 // extern "C" surface of libbevgen_hip (declared in include/bevgen_hip.h): argument validation, exception -> error-code
 // translation.  No torch types cross this boundary: raw pointers, sizes and a hipStream_t.
 #include "model.h"
+#include "profiler.h"
 
 using namespace bevgen;
 
@@ -233,5 +234,16 @@ int bevgen_op_groupnorm(bevgen_ctx* ctx, const float* x, const float* gamma, con
 }
 
 int bevgen_decode_attention_splits(int B, int H, int n) { return decode_attention_splits(B, H, n); }
+
+int bevgen_profile_begin(bevgen_ctx* ctx) {
+    return guarded(ctx, [&] { prof_begin(); });
+}
+
+int bevgen_profile_end(bevgen_ctx* ctx, double* out) {
+    return guarded(ctx, [&] {
+        BG_REQUIRE(out, "profile_end: null output");
+        prof_end(out);
+    });
+}
 
 }  // extern "C"

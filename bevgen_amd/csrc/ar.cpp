@@ -210,7 +210,7 @@ static void decode_step_launch(Ctx& c, StepWs& w, const int64_t* tok, hipStream_
         a.bias = c.attn_bias; a.ldbias = L;
         a.keep = c.keep; a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
         a.R = w.xn; a.ldr = D; a.O = w.x2; a.ldo = D;
-        a.B = B; a.H = H; a.n = c.K + 1; a.d_n = st.d_step; a.Lmax = L;
+        a.B = B; a.H = H; a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step; a.Lmax = L;
         a.scale = 0.125f; a.kv_dtype = cache_dtype(c);
         launch_decode_attention_ws(a, w.dec_ws, w.splits, s);
         launch_layernorm(w.x2, D, l.ln2_w, l.ln2_b, w.h, D, B, D, 1e-5f, s);

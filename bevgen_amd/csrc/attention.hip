@@ -18,6 +18,7 @@
 //    (LPK lanes x 16 B cover one key row; 64/LPK keys per instruction); split-K over the context for occupancy.
 #include "common.h"
 #include "kernels.h"
+#include "profiler.h"
 #include <hip/hip_bf16.h>
 
 namespace bevgen {
@@ -168,6 +169,7 @@ void launch_attention(const AttnArgs& a, hipStream_t s) {
     BG_REQUIRE(a.Nk_pad % KT == 0 && a.Nk_pad > 0, "attention: Nk_pad=%d must be a positive multiple of %d", a.Nk_pad, KT);
     BG_REQUIRE(a.bias == nullptr || a.ldbias % 4 == 0, "attention: bias row stride must be a multiple of 4");
     dim3 grid(cdiv(a.Nq, 128), a.H, a.B);
+    ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk_pad * 64, s);
     hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, s, a);
     LAUNCH_CHECK();
 }
@@ -334,6 +336,9 @@ void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipSt
     BG_REQUIRE(a.d_n || (a.n > 0 && a.n <= a.Lmax), "decode attention: n=%d out of range (Lmax=%d)", a.n, a.Lmax);
     BG_REQUIRE(a.group <= 1, "decode attention: shared-prefix groups not implemented in this kernel");
     dim3 grid(S, a.H, a.B);
+    // algorithmic bytes of one launch: K and V rows of the visible context, once each (2 * n * 64 * elem per (sequence, head))
+    const double n_host = a.d_n ? a.n + a.n_hint : a.n;
+    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.B * a.H * n_host * 64 * (a.kv_dtype == 0 ? 4 : 2), s);
     if (a.kv_dtype == 0)
         hipLaunchKernelGGL(decode_attention_kernel<0>, grid, dim3(256), 0, s, a, ws, S);
     else

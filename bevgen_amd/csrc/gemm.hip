@@ -16,6 +16,7 @@
 // inside one tap.
 #include "common.h"
 #include "kernels.h"
+#include "profiler.h"
 
 namespace bevgen {
 
@@ -188,6 +189,7 @@ void launch_gemm(const GemmArgs& g, hipStream_t stream) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<MODE_CONV3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : PROF_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, stream);
     if (g.mode == MODE_CONV3)
         hipLaunchKernelGGL(gemm_f32_kernel<MODE_CONV3>, grid, dim3(256), lds, stream, g);
     else

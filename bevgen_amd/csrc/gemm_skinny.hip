@@ -12,6 +12,7 @@
 //     in a fixed order and applies the epilogue) so that narrow layers still occupy all 256 CUs.
 #include "common.h"
 #include "kernels.h"
+#include "profiler.h"
 
 namespace bevgen {
 
@@ -125,6 +126,7 @@ void launch_gemm_skinny_ws(const GemmArgs& g, float* ws, hipStream_t stream) {
     BG_REQUIRE(g.batch == 1 && g.bias_m == nullptr, "gemm_skinny: batch/bias_m unsupported");
     const int ks = gemm_skinny_ksplit(g.M, g.N, g.K);
     dim3 grid(cdiv(g.N, 32), ks);
+    ProfScope prof(PROF_GEMM_SKINNY, ((double)g.N * g.K + (double)g.M * g.K + (double)g.M * g.N) * sizeof(float), stream);  // work = algorithmic bytes (W once + x + y)
     if (g.M <= 32)
         hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 0, stream, g, ws, ks);
     else

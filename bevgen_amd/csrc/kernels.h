@@ -79,6 +79,7 @@ struct DecodeAttnArgs {
     int B = 0, H = 0;
     int n = 0;                       // context length (keys 0..n-1); if d_n != null the length is *d_n + n
     const int* d_n = nullptr;        // device-side step counter (hipGraph replay)
+    int n_hint = 0;                  // host's copy of *d_n (profiling only)
     int Lmax = 0;
     float scale = 1.f;               // dh^-0.5, applied to (q.k + bias)
     int kv_dtype = 0;                // 0 = fp32, 1 = bf16

@@ -240,6 +240,18 @@ class Context:
         self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids.reshape(n, -1)), n, int(bool(denormalize)), _ptr(out), _stream()))
         return out
 
+    # ------------------------------------------------------------------------------------------ per-kernel HIP-event timing
+    PROFILE_KINDS = ("gemm", "conv3x3", "attention", "decode_attention", "gemm_skinny")
+
+    def profile_begin(self):
+        self._check(self.lib.bevgen_profile_begin(self._h))
+
+    def profile_end(self) -> Dict[str, Dict[str, float]]:
+        """{kind: {'launches', 'ms', 'work'}}; work = FLOP (gemm/conv/attention) or bytes (decode_attention/gemm_skinny)."""
+        buf = (C.c_double * (3 * len(self.PROFILE_KINDS)))()
+        self._check(self.lib.bevgen_profile_end(self._h, buf))
+        return {k: {"launches": buf[3 * i], "ms": buf[3 * i + 1], "work": buf[3 * i + 2]} for i, k in enumerate(self.PROFILE_KINDS)}
+
     # ------------------------------------------------------------------------------------------ operator level (tests / roofline)
     def op_gemm(self, a, w, bias=None, residual=None, gelu=False, skinny=False):
         M, K = a.shape

@@ -341,3 +341,23 @@ def strip_prefixes(sd: Mapping[str, torch.Tensor], ignore_keys: Sequence[str] = 
             continue
         out[k] = v
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# whole-model synthetic state dicts (benchmarks, smoke, parity cases)
+# --------------------------------------------------------------------------------------------
+def maskgit_state_dict(cfg, seed: int, dim_head: int = 64, ff_mult: float = 4) -> "OrderedDict[str, torch.Tensor]":
+    from . import tables
+
+    shapes = maskgit_shapes(cfg, depth=cfg.num_layers, heads=cfg.num_heads, dim_head=dim_head, ff_mult=ff_mult, num_tokens=cfg.vocab_size)
+    return generate_state_dict(shapes, seed, tables={"bev_grid": tables.get_bev_grid(cfg)}, alias=maskgit_alias)
+
+
+def gpt_state_dict(cfg, seed: int) -> "OrderedDict[str, torch.Tensor]":
+    from . import tables
+
+    return generate_state_dict(gpt_shapes(cfg), seed, tables={"bev_grid": tables.get_bev_grid(cfg), "master_layout": cfg.layout})
+
+
+def vq_state_dict(dd: Mapping, n_embed: int, embed_dim: int, seed: int, with_encoder: bool = False) -> "OrderedDict[str, torch.Tensor]":
+    return generate_state_dict(vqmodel_shapes(dd, n_embed, embed_dim, with_encoder=with_encoder), seed)

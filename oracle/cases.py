@@ -44,16 +44,9 @@ def muse_kwargs(cfg):
     return dict(depth=cfg.num_layers, heads=cfg.num_heads, dim_head=64, ff_mult=4, num_tokens=cfg.vocab_size)
 
 
-def maskgit_state_dict(cfg, seed: int):
-    return W.generate_state_dict(W.maskgit_shapes(cfg, **muse_kwargs(cfg)), seed, tables={"bev_grid": tables.get_bev_grid(cfg)}, alias=W.maskgit_alias)
-
-
-def gpt_state_dict(cfg, seed: int):
-    return W.generate_state_dict(W.gpt_shapes(cfg), seed, tables={"bev_grid": tables.get_bev_grid(cfg), "master_layout": cfg.layout})
-
-
-def vq_state_dict(dd, n_embed: int, embed_dim: int, seed: int, with_encoder: bool = False):
-    return W.generate_state_dict(W.vqmodel_shapes(dd, n_embed, embed_dim, with_encoder=with_encoder), seed)
+maskgit_state_dict = W.maskgit_state_dict
+gpt_state_dict = W.gpt_state_dict
+vq_state_dict = W.vq_state_dict
 
 
 def inputs(case: Case, cfg):
