@@ -159,7 +159,15 @@ int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* ids, int n, int denormalize
     return guarded(ctx, [&] {
         need_final(ctx);
         BG_REQUIRE(ids && out && n >= 1, "vq_decode: bad arguments");
-        vq_decode(*ctx, ids, n, denormalize, out, (hipStream_t)stream);
+        vq_decode(*ctx, ids, nullptr, n, denormalize, out, (hipStream_t)stream);
+    });
+}
+
+int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* zq, int n, int denormalize, float* out, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(zq && out && n >= 1, "vq_decode_latents: bad arguments");
+        vq_decode(*ctx, nullptr, zq, n, denormalize, out, (hipStream_t)stream);
     });
 }
 

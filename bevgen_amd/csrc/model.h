@@ -122,7 +122,7 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
                const float* noise_u, int samples_per_layout, int64_t* out, float* step_logits, hipStream_t s);
 // vqdec.cpp
 void vq_finalize(Ctx& c);
-void vq_decode(Ctx& c, const int64_t* ids, int n, int denorm, float* out, hipStream_t s);
+void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n, int denorm, float* out, hipStream_t s);
 // tables.hip
 void launch_build_attn_bias(const float* tril_emb /*or null*/, const float* prob /*or null*/, float* out, int L, hipStream_t s);
 void launch_build_muse_bias(const float* attn_bias, int L, int K, int N, float* bias_self, int ldS, float* bias_cross, int ldC, hipStream_t s);

@@ -44,4 +44,21 @@ void launch_nhwc_to_nchw(const float* x, float* y, int n, int hw, int C, int ldc
     LAUNCH_CHECK();
 }
 
+// x [n, C, hw] -> y [n, hw, C]
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int hw, int C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long np = i / C;
+        const int p = (int)(np % hw);
+        const long n = np / hw;
+        y[i] = x[(n * C + c) * hw + p];
+    }
+}
+
+void launch_nchw_to_nhwc(const float* x, float* y, int n, int hw, int C, hipStream_t s) {
+    const long total = (long)n * C * hw;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, y, total, hw, C);
+    LAUNCH_CHECK();
+}
+
 }  // namespace bevgen

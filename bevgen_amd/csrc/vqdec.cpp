@@ -175,7 +175,7 @@ void vq_finalize(Ctx& c) {
     c.has_vq = true;
 }
 
-void vq_decode(Ctx& c, const int64_t* ids, int n_total, int denorm, float* out, hipStream_t s) {
+void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_total, int denorm, float* out, hipStream_t s) {
     BG_REQUIRE(c.has_vq, "this context was created without a VQGAN decoder (vq_ch == 0)");
     const auto& g = c.cfg;
     const int lat = g.vq_resolution >> (g.vq_num_levels - 1);
@@ -220,7 +220,8 @@ void vq_decode(Ctx& c, const int64_t* ids, int n_total, int denorm, float* out, 
         float* img = c.arena.get<float>((size_t)n * R * R * 4);
 
         const long lrows = (long)n * lat * lat;
-        launch_codebook_gather(ids + (long)i0 * lat * lat, c.codebook, zq, (int)lrows, g.vq_embed_dim, g.vq_n_embed, s);
+        if (ids) launch_codebook_gather(ids + (long)i0 * lat * lat, c.codebook, zq, (int)lrows, g.vq_embed_dim, g.vq_n_embed, s);
+        else launch_nchw_to_nhwc(latents_nchw + (long)i0 * g.vq_embed_dim * lat * lat, zq, n, lat * lat, g.vq_embed_dim, s);
         conv1(zq, lrows, c.post_quant, ws.t, nullptr, s);                       // post_quant_conv
         Act x{ws.t, n, lat, lat, g.vq_z_channels};
         conv3(x, c.conv_in, ws.a, nullptr, 0, s);                               // conv_in

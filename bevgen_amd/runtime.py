@@ -240,6 +240,15 @@ class Context:
         self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids.reshape(n, -1)), n, int(bool(denormalize)), _ptr(out), _stream()))
         return out
 
+    def vq_decode_latents(self, zq, denormalize=False):
+        """VQModel.decode(quant): zq [n, embed_dim, h, w] fp32."""
+        dd = self.vq_ddconfig
+        zq = _req(zq, torch.float32, self.device, "zq")
+        n, R = zq.shape[0], dd["resolution"]
+        out = torch.empty((n, dd["out_ch"], R, R), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_vq_decode_latents(self._h, _ptr(zq), n, int(bool(denormalize)), _ptr(out), _stream()))
+        return out
+
     # ------------------------------------------------------------------------------------------ per-kernel HIP-event timing
     PROFILE_KINDS = ("gemm", "conv3x3", "attention", "decode_attention", "gemm_skinny")
 

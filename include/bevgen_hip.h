@@ -154,6 +154,9 @@ int bevgen_ar_sample(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_
  * bev_utils/util.py:97-118 when denormalize != 0].   d_ids [n, h*w] -> d_out [n, out_ch, H, W] fp32. */
 int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* d_ids, int n, int denormalize, float* d_out, void* stream);
 
+/* VQModel.decode(quant) (stage1/vqgan.py:118-121) for already looked-up latents: d_zq [n, embed_dim, h, w] (NCHW, like the reference). */
+int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* d_zq, int n, int denormalize, float* d_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Operator-level entry points (parity tests and roofline measurements call the kernels through these)             */
 int bevgen_op_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, const float* d_residual, float* d_c,

@@ -180,6 +180,26 @@ def golden_vq():
     save("vq_tiny", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd)
 
 
+def golden_keys():
+    """state_dict key -> shape of the reference modules (tiny sizes), as instantiated by the reference's own constructors."""
+    import json
+
+    out = {}
+    cfg = presets.tiny_route_m(3, legacy=False)
+    mg, _ = RM.build_ref_maskgit(cfg, cases.maskgit_state_dict(cfg, 1))
+    out["maskgit_tiny_route_m_3cam"] = {k: list(v.shape) for k, v in mg.state_dict().items()}
+    ca = presets.tiny_route_a(3)
+    gpt, _ = RM.build_ref_gpt(ca, cases.gpt_state_dict(ca, 1))
+    out["gpt_tiny_route_a_3cam"] = {k: list(v.shape) for k, v in gpt.state_dict().items()}
+    dd = presets.VQ_DDCONFIG_TINY
+    vq = RM.build_ref_vqmodel(dd, 64, 64, cases.vq_state_dict(dd, 64, 64, 1, with_encoder=True), (64, 64), (8, 8))
+    out["vqmodel_tiny"] = {k: list(v.shape) for k, v in vq.state_dict().items()}
+    path = os.path.join(GOLDEN, "state_dict_keys.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print(f"  wrote {path}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -193,6 +213,9 @@ def main():
     if want("vq"):
         print("vq")
         golden_vq()
+    if want("keys"):
+        print("keys")
+        golden_keys()
     for name, case in cases.CASES.items():
         full = name in ("a_config1", "m_full_3cam")
         if not want(name) or (full and args.skip_full):
