@@ -63,8 +63,8 @@ int bevgen_create(const bevgen_cfg* cfg, int device, bevgen_ctx** out) {
 
 void bevgen_destroy(bevgen_ctx* ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
     delete ctx;
 }
 

@@ -9,6 +9,7 @@
 // rows <= K-1+s: we compute the K condition rows once (prefill), keep K/V of every layer, and per step push exactly one new
 // row through the stack (validity verified against the reference).
 #include "model.h"
+#include "profiler.h"
 
 namespace bevgen {
 
@@ -242,17 +243,59 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     c.arena.reset();
     StepWs w = step_ws(c, B);
     launch_fill_i64(out, (long)B * c.N, c.cfg.vocab_size, s);  // x = vocab_size everywhere (ar_lm:157)
-    for (int step = 0; step < steps; ++step) {
-        launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, B, c.D, 1e-5f, s);
-        float* lg = step_logits ? step_logits + (size_t)step * B * c.V : w.logits;
-        small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, lg, c.V, B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, s);
-        launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u + (size_t)step * B, w.tok, B, c.V, top_k, temperature, s);
-        launch_store_tokens(w.tok, c.fwd_idx, st.d_step, out, B, c.N, s);
-        if (step + 1 < steps) {
-            decode_step_launch(c, w, w.tok, s);
-            st.step += 1;
+
+    // one decode iteration: logits of the newest row -> token -> (optionally) push the token through the stack.
+    // Every position-dependent quantity (decode-order index, cache slot, bias row, context length, noise row) is read from the device-side
+    // step counter, so the launch sequence is identical for every step and can be captured once and replayed as a hipGraph.
+    auto head_and_pick = [&](float* lg, hipStream_t q) {
+        launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, B, c.D, 1e-5f, q);
+        small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, lg, c.V, B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, q);
+        launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u, st.d_step, w.tok, B, c.V, top_k, temperature, q);
+        launch_store_tokens(w.tok, c.fwd_idx, st.d_step, out, B, c.N, q);
+    };
+
+    const bool use_graph = steps > 2 && !step_logits && !prof_enabled() && !c.disable_graphs;
+    if (!use_graph) {
+        for (int step = 0; step < steps; ++step) {
+            head_and_pick(step_logits ? step_logits + (size_t)step * B * c.V : w.logits, s);
+            if (step + 1 < steps) {
+                decode_step_launch(c, w, w.tok, s);
+                st.step += 1;
+            }
         }
+        return;
     }
+
+    // graph path: capture {head, pick, store, one full decode step} on a library-owned stream (the caller's stream may be the legacy
+    // default stream, which cannot be captured), replay it steps-1 times, finish with one eager head+pick.
+    if (!c.graph_stream) {
+        HIP_CHECK(hipStreamCreateWithFlags(&c.graph_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&c.graph_ev_in, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c.graph_ev_out, hipEventDisableTiming));
+    }
+    hipStream_t q = c.graph_stream;
+    HIP_CHECK(hipEventRecord(c.graph_ev_in, s));
+    HIP_CHECK(hipStreamWaitEvent(q, c.graph_ev_in, 0));
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_CHECK(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
+    try {
+        head_and_pick(w.logits, q);
+        decode_step_launch(c, w, w.tok, q);
+    } catch (...) {
+        (void)hipStreamEndCapture(q, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    HIP_CHECK(hipStreamEndCapture(q, &graph));
+    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int step = 0; step + 1 < steps; ++step) HIP_CHECK(hipGraphLaunch(exec, q));
+    st.step += steps - 1;
+    head_and_pick(w.logits, q);
+    HIP_CHECK(hipEventRecord(c.graph_ev_out, q));
+    HIP_CHECK(hipStreamWaitEvent(s, c.graph_ev_out, 0));
+    // the exec object must outlive its in-flight launches: destroy it once the work has drained (deferred to the next call / destroy)
+    c.retire_graph(exec, graph);
 }
 
 }  // namespace bevgen

@@ -201,11 +201,13 @@ template <> struct KvTraits<1> {  // bf16 rows: 128 B = 8 lanes x 16 B
 constexpr int DEC_UNROLL = 4;
 
 // partial results: ws[((b*H + h)*S + split)*66 + {0: m, 1: l, 2..65: o[64]}]
-template <int DT>
-__global__ __launch_bounds__(256) void decode_attention_kernel(DecodeAttnArgs a, float* __restrict__ ws, int S) {
+// NW = waves per workgroup.  S == 1 (one workgroup sees the whole context): the epilogue normalises, adds the residual and writes O
+// directly - no workspace round trip, no second kernel.  S > 1: partials go to `ws` and decode_attention_combine_kernel merges them.
+template <int DT, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArgs a, float* __restrict__ ws, int S) {
     using T = KvTraits<DT>;
     constexpr int LPK = T::LPK, DPL = T::DPL, KPI = 64 / LPK;
-    __shared__ float red[4][66];
+    __shared__ float red[NW][66];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane % LPK, kslot = lane / LPK;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecodeAttnArgs a,
 #pragma unroll
     for (int i = 0; i < DPL; ++i) acc[i] = 0.f;
 
-    constexpr int stride = 4 * KPI;  // keys consumed per unroll slot by the 4 waves
+    constexpr int stride = NW * KPI;  // keys consumed per unroll slot by the workgroup's waves
     const int iters = k_end > k_begin ? (k_end - k_begin + stride * DEC_UNROLL - 1) / (stride * DEC_UNROLL) : 0;
     for (int it = 0; it < iters; ++it) {
         float kx[DEC_UNROLL][DPL], vx[DEC_UNROLL][DPL], sc[DEC_UNROLL];
@@ -291,19 +293,25 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(DecodeAttnArgs a,
     }
     __syncthreads();
     if (tid < 64) {
-        float mw[4], mm = kNegBig;
+        float mm = kNegBig;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { mw[w] = red[w][0]; mm = fmaxf(mm, mw[w]); }
+        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, red[w][0]);
         float l = 0.f, o = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float fw = expf(mw[w] - mm);
+        for (int w = 0; w < NW; ++w) {
+            const float fw = expf(red[w][0] - mm);
             l += red[w][1] * fw;
             o += red[w][2 + tid] * fw;
         }
-        float* out = ws + (((long)b * a.H + head) * S + split) * 66;
-        if (tid == 0) { out[0] = mm; out[1] = l; }
-        out[2 + tid] = o;
+        if (S == 1) {
+            float v = o / l;
+            if (a.R) v += a.R[(long)b * a.ldr + head * 64 + tid];
+            a.O[(long)b * a.ldo + head * 64 + tid] = v;
+        } else {
+            float* out = ws + (((long)b * a.H + head) * S + split) * 66;
+            if (tid == 0) { out[0] = mm; out[1] = l; }
+            out[2 + tid] = o;
+        }
     }
 }
 
@@ -324,7 +332,9 @@ __global__ __launch_bounds__(64) void decode_attention_combine_kernel(DecodeAttn
 }
 
 int decode_attention_splits(int B, int H, int n_max) {
-    // enough workgroups to cover the 256 CUs a few times over, but at least 256 keys per split
+    // B*H >= 192 workgroups already cover the chip: one 16-wave workgroup per (sequence, head), direct epilogue.
+    // Fewer than that: split the context over workgroups (at least 256 keys per split) and merge in a second kernel.
+    if ((long)B * H >= 192) return 1;
     int S = 1;
     while ((long)B * H * S < 1024 && n_max / (S * 2) >= 256) S *= 2;
     return S;
@@ -339,10 +349,18 @@ void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipSt
     // algorithmic bytes of one launch: K and V rows of the visible context, once each (2 * n * 64 * elem per (sequence, head))
     const double n_host = a.d_n ? a.n + a.n_hint : a.n;
     ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.B * a.H * n_host * 64 * (a.kv_dtype == 0 ? 4 : 2), s);
+    if (S == 1) {
+        if (a.kv_dtype == 0)
+            hipLaunchKernelGGL((decode_attention_kernel<0, 16>), grid, dim3(1024), 0, s, a, ws, S);
+        else
+            hipLaunchKernelGGL((decode_attention_kernel<1, 16>), grid, dim3(1024), 0, s, a, ws, S);
+        LAUNCH_CHECK();
+        return;
+    }
     if (a.kv_dtype == 0)
-        hipLaunchKernelGGL(decode_attention_kernel<0>, grid, dim3(256), 0, s, a, ws, S);
+        hipLaunchKernelGGL((decode_attention_kernel<0, 4>), grid, dim3(256), 0, s, a, ws, S);
     else
-        hipLaunchKernelGGL(decode_attention_kernel<1>, grid, dim3(256), 0, s, a, ws, S);
+        hipLaunchKernelGGL((decode_attention_kernel<1, 4>), grid, dim3(256), 0, s, a, ws, S);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(decode_attention_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, a, ws, S);
     LAUNCH_CHECK();

@@ -23,16 +23,37 @@ void* Arena::alloc(size_t bytes) {
     return base + a;
 }
 void Arena::release() {
-    if (base) hipFree(base);
+    if (base) (void)hipFree(base);
     base = nullptr;
     cap = off = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ ctx
+void Ctx::retire_graph(hipGraphExec_t e, hipGraph_t g) {
+    // graphs retired by earlier calls have certainly been enqueued before this point; drain and free them
+    if (!retired_graphs.empty() && graph_stream) {
+        (void)hipStreamSynchronize(graph_stream);
+        for (auto& p : retired_graphs) {
+            (void)hipGraphExecDestroy(p.first);
+            (void)hipGraphDestroy(p.second);
+        }
+        retired_graphs.clear();
+    }
+    retired_graphs.emplace_back(e, g);
+}
+
 Ctx::~Ctx() {
+    if (graph_stream) (void)hipStreamSynchronize(graph_stream);
+    for (auto& p : retired_graphs) {
+        (void)hipGraphExecDestroy(p.first);
+        (void)hipGraphDestroy(p.second);
+    }
+    if (graph_ev_in) (void)hipEventDestroy(graph_ev_in);
+    if (graph_ev_out) (void)hipEventDestroy(graph_ev_out);
+    if (graph_stream) (void)hipStreamDestroy(graph_stream);
     for (auto& kv : params)
-        if (kv.second.ptr) hipFree(kv.second.ptr);
-    for (void* p : owned) hipFree(p);
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (void* p : owned) (void)hipFree(p);
     arena.release();
     persist.release();
 }
@@ -82,7 +103,7 @@ void ctx_load_tensor(Ctx& c, const char* name, const void* h, int dtype, int ndi
     t.bytes = (size_t)n * dtype_size(t.dtype);
     auto it = c.params.find(name);
     if (it != c.params.end()) {
-        hipFree(it->second.ptr);
+        (void)hipFree(it->second.ptr);
         c.params.erase(it);
     }
     HIP_CHECK(hipMalloc(&t.ptr, t.bytes));
@@ -205,7 +226,7 @@ void ctx_finalize(Ctx& c) {
     HIP_CHECK(hipSetDevice(c.device));
     const auto& g = c.cfg;
     // free previously derived buffers (re-finalize after reloading weights)
-    for (void* p : c.owned) hipFree(p);
+    for (void* p : c.owned) (void)hipFree(p);
     c.owned.clear();
     c.T = g.cam_latent_h * g.cam_latent_w;
     c.N = c.T * g.num_cams;

@@ -98,6 +98,13 @@ struct Ctx {
     const float *norm_out_w = nullptr, *norm_out_b = nullptr;
     float *denorm_mean = nullptr, *denorm_std = nullptr;
 
+    // ---- hipGraph replay of the Route A decode step
+    hipStream_t graph_stream = nullptr;
+    hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
+    std::vector<std::pair<hipGraphExec_t, hipGraph_t>> retired_graphs;
+    bool disable_graphs = false;
+    void retire_graph(hipGraphExec_t e, hipGraph_t g);  // destroyed once the stream has drained (next call or destroy)
+
     ~Ctx();
     const DevTensor& need(const std::string& name) const;
     const DevTensor* find(const std::string& name) const;
