@@ -200,13 +200,9 @@ static void decode_step_launch(Ctx& c, StepWs& w, const int64_t* tok, hipStream_
         char* vc = reinterpret_cast<char*>(st.vcache) + i * layer_bytes;
         launch_layernorm(xin, D, l.ln1_w, l.ln1_b, w.xn, D, B, D, 1e-5f, s);
         small_gemm(w.xn, D, l.wqkv, D, l.bqkv, w.qkv, 3 * D, B, 3 * D, D, ACT_NONE, nullptr, 0, w.gemm_ws, s);
-        // cache slot = K + step
-        {
-            // d_step counts fed image tokens; the new row sits at sequence position K + step
-            launch_ar_kv_append(w.qkv, kc, vc, cache_dtype(c), B, H, c.K, st.d_step, L, s);
-        }
         DecodeAttnArgs a;
         a.q = w.qkv; a.ldq = 3 * D;
+        a.append_k = w.qkv + D; a.append_v = w.qkv + 2 * D;  // the new row (sequence position K + step) is appended inside the attention kernel
         a.kcache = kc; a.vcache = vc;
         a.bias = c.attn_bias; a.ldbias = L;
         a.keep = c.keep; a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;

@@ -229,6 +229,25 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
     const uint8_t* keep = a.keep ? a.keep + (long)head * a.keep_head_stride + (long)row * a.ldkeep : nullptr;
     const float* bias_row = a.bias ? a.bias + (long)row * a.ldbias : nullptr;
 
+    // fused KV append: the workgroup that owns the newest key writes this step's k/v row into the cache, then everybody reads it back
+    // through the normal path (same-workgroup visibility is guaranteed by the barrier)
+    if (a.append_k && k_end == n) {
+        if (tid < 128) {
+            const bool is_v = tid >= 64;
+            const int d = tid & 63;
+            const float val = (is_v ? a.append_v : a.append_k)[(long)b * a.ldq + head * 64 + d];
+            void* cache = const_cast<void*>(is_v ? a.vcache : a.kcache);
+            const long idx = (cache_row0 + row) * 64 + d;
+            if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
+            else {
+                uint32_t u = __float_as_uint(val);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                reinterpret_cast<uint16_t*>(cache)[idx] = (uint16_t)(u >> 16);
+            }
+        }
+        __syncthreads();
+    }
+
     float m_run = kNegBig, l_run = 0.f, acc[DPL];
 #pragma unroll
     for (int i = 0; i < DPL; ++i) acc[i] = 0.f;

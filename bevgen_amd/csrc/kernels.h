@@ -73,6 +73,8 @@ struct DecodeAttnArgs {
     const uint8_t* keep = nullptr;   // [H or 1][L][ldkeep] 1 = visible (allowed AND layout block present); null = all visible
     long keep_head_stride = 0;
     int ldkeep = 0;
+    const float* append_k = nullptr; // this step's key / value rows [B, H*64] (row stride ldq): written into cache row n-1 by the kernel itself
+    const float* append_v = nullptr; //   (fused KV append, saves one launch per layer); null = the cache already holds row n-1
     const float* R = nullptr;        // residual [B, H*64] (row stride ldr) or null
     float* O = nullptr;              // [B, H*64] (row stride ldo)
     int ldr = 0, ldo = 0;
