@@ -45,10 +45,11 @@ def parse():
     ap.add_argument("--no-decode-leg", action="store_true")
     ap.add_argument("--decode-batch", type=int, default=16)
     ap.add_argument("--decode-steps", type=int, default=0, help="0 = a full decode (N image tokens)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"], help="fp32 = exact fp32 MFMA (bit-exact parity mode); f16x3 = split-precision GEMMs")
     return ap.parse_args()
 
 
-def build_route_m(cams, batch, device):
+def build_route_m(cams, batch, device, precision="fp32"):
     from bevgen_amd import presets
     from bevgen_amd.runtime import Context
     from bevgen_amd.weights import maskgit_state_dict, vq_state_dict
@@ -56,7 +57,7 @@ def build_route_m(cams, batch, device):
     cfg = presets.config2(cams)
     sd = maskgit_state_dict(cfg, 1234)
     dd = presets.VQ_DDCONFIG_F16
-    ctx = Context(cfg, route="maskgit", vq_ddconfig=dd, vq_n_embed=1024, vq_embed_dim=256, device=device, max_batch=batch)
+    ctx = Context(cfg, route="maskgit", vq_ddconfig=dd, vq_n_embed=1024, vq_embed_dim=256, device=device, max_batch=batch, precision=precision)
     ctx.load_state_dict(sd)
     ctx.load_state_dict(vq_state_dict(dd, 1024, 256, 99), prefix="first_stage_model.")
     ctx.set_tables()
@@ -167,7 +168,7 @@ def main():
     from bevgen_amd import synthetic
     from bevgen_amd.parallel import gather_scenes
 
-    cfg, ctx, _ = build_route_m(args.cams, args.batch, local_rank)
+    cfg, ctx, _ = build_route_m(args.cams, args.batch, local_rank, args.precision)
     bt = synthetic.make_batch(cfg, args.batch, seed=1000 + rank)  # each rank: its own shard of scenes
     bt = {k: v.to(ctx.device) for k, v in bt.items()}
 

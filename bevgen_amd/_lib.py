@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevgen_hip.h")
 
 ABI_VERSION = 1
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
-PRECISION_FP32, PRECISION_BF16 = 0, 1
+PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_F64 = 0, 1, 2, 3
 
 

@@ -14,6 +14,7 @@ static int guarded(bevgen_ctx* ctx, F&& f) {
     try {
         if (!ctx) return BEVGEN_ERR_INVALID;
         HIP_CHECK(hipSetDevice(ctx->device));
+        split_registry_set(ctx->cfg.precision == BEVGEN_PRECISION_F16X3 ? &ctx->split : nullptr);
         f();
         return BEVGEN_OK;
     } catch (const Error& e) {
@@ -38,7 +39,7 @@ int bevgen_create(const bevgen_cfg* cfg, int device, bevgen_ctx** out) {
         BG_REQUIRE(cfg && out, "bevgen_create: null argument");
         BG_REQUIRE(cfg->abi_version == BEVGEN_ABI_VERSION, "bevgen_create: ABI version %d, library is %d", cfg->abi_version, BEVGEN_ABI_VERSION);
         BG_REQUIRE(cfg->route == BEVGEN_ROUTE_MASKGIT || cfg->route == BEVGEN_ROUTE_AR, "bevgen_create: unknown route %d", cfg->route);
-        BG_REQUIRE(cfg->precision == BEVGEN_PRECISION_FP32, "bevgen_create: only BEVGEN_PRECISION_FP32 is available in this build");
+        BG_REQUIRE(cfg->precision == BEVGEN_PRECISION_FP32 || cfg->precision == BEVGEN_PRECISION_F16X3, "bevgen_create: precision must be BEVGEN_PRECISION_FP32 or BEVGEN_PRECISION_F16X3");
         int ndev = 0;
         HIP_CHECK(hipGetDeviceCount(&ndev));
         BG_REQUIRE(device >= 0 && device < ndev, "bevgen_create: device %d not present (%d visible)", device, ndev);
@@ -179,7 +180,16 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float*
         g.A = a; g.B = w; g.C = c; g.R = residual; g.bias_n = bias;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
         g.act = act_gelu ? ACT_GELU : ACT_NONE;
-        if (skinny) launch_gemm_skinny(g, (hipStream_t)stream);
+        if (skinny == 2) {  // split-precision path with an on-the-fly split of W (tests / roofline probes)
+            ctx->arena.reserve((size_t)N * K * 4 + 1024);
+            ctx->arena.reset();
+            void* hi = ctx->arena.alloc((size_t)N * K * 2);
+            void* lo = ctx->arena.alloc((size_t)N * K * 2);
+            launch_split_weight(w, hi, lo, (long)N * K, (hipStream_t)stream);
+            g.B_hi = reinterpret_cast<const uint16_t*>(hi);
+            g.B_lo = reinterpret_cast<const uint16_t*>(lo);
+            launch_gemm_split(g, (hipStream_t)stream);
+        } else if (skinny) launch_gemm_skinny(g, (hipStream_t)stream);
         else launch_gemm(g, (hipStream_t)stream);
     });
 }

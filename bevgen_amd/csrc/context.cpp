@@ -29,6 +29,14 @@ void Arena::release() {
 }
 
 // ------------------------------------------------------------------------------------------------ ctx
+void Ctx::split_weight(const float* w, long n) {
+    if (cfg.precision != BEVGEN_PRECISION_F16X3 || split.count(w)) return;
+    void* hi = own((size_t)n * 2);
+    void* lo = own((size_t)n * 2);
+    launch_split_weight(w, hi, lo, n, 0);
+    split[w] = SplitPlanes{reinterpret_cast<const uint16_t*>(hi), reinterpret_cast<const uint16_t*>(lo)};
+}
+
 void Ctx::retire_graph(hipGraphExec_t e, hipGraph_t g) {
     // graphs retired by earlier calls have certainly been enqueued before this point; drain and free them
     if (!retired_graphs.empty() && graph_stream) {
@@ -168,7 +176,15 @@ static void finalize_muse(Ctx& c) {
         l.ff_g3 = c.pf(q + "3.gamma");
         l.ff_w4_padded = reinterpret_cast<float*>(c.own((size_t)D * c.Fpad * sizeof(float)));
         launch_pad_rows(c.pf(q + "4.weight"), F, l.ff_w4_padded, c.Fpad, D, F, 0);
+        for (int j = 0; j < 2; ++j) {
+            c.split_weight(l.to_q[j], (long)inner * D);
+            c.split_weight(l.to_kv[j], 2L * inner * D);
+            c.split_weight(l.to_out[j], (long)D * inner);
+        }
+        c.split_weight(l.ff_w1, 2L * F * D);
+        c.split_weight(l.ff_w4_padded, (long)D * c.Fpad);
     }
+    c.split_weight(c.pf(p + "to_logits.weight"), (long)g.vocab_size * D);
     // attention bias matrices with the null-key column
     c.NkS_pad = (int)round_up(c.N + 1, 32);
     c.NkC_pad = (int)round_up(c.K + 1, 32);
@@ -203,6 +219,9 @@ static void finalize_ar(Ctx& c) {
         l.bqkv = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
         launch_fuse_qkv(c.pf(q + "attention.query.weight"), c.pf(q + "attention.key.weight"), c.pf(q + "attention.value.weight"),
                         c.pf(q + "attention.query.bias"), c.pf(q + "attention.key.bias"), c.pf(q + "attention.value.bias"), l.wqkv, l.bqkv, D, 0);
+        c.split_weight(l.wqkv, 3L * D * D);      // used by the prefill GEMMs (the per-token decode GEMMs stream the fp32 weights)
+        c.split_weight(l.mlp0_w, 4L * D * D);
+        c.split_weight(l.mlp2_w, 4L * D * D);
     }
     // visibility mask: allowed AND layout block present.  Heads with identical layouts share one plane.
     const int blk = g.sparse_block_size, nb = c.L / blk;
@@ -228,6 +247,7 @@ void ctx_finalize(Ctx& c) {
     // free previously derived buffers (re-finalize after reloading weights)
     for (void* p : c.owned) (void)hipFree(p);
     c.owned.clear();
+    c.split.clear();
     c.T = g.cam_latent_h * g.cam_latent_w;
     c.N = c.T * g.num_cams;
     c.K = g.num_cond_tokens;

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "profiler.h"
+#include <unordered_map>
 
 namespace bevgen {
 
@@ -176,7 +177,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+static const std::unordered_map<const float*, SplitPlanes>* g_split_table = nullptr;
+void split_registry_set(const void* table) { g_split_table = reinterpret_cast<const std::unordered_map<const float*, SplitPlanes>*>(table); }
+
 void launch_gemm(const GemmArgs& g, hipStream_t stream) {
+    if (g.B_hi) return launch_gemm_split(g, stream);
+    if (g_split_table && g.strideB == 0) {  // the executing context runs in split-precision mode and B is one of its (pre-split) weights
+        auto it = g_split_table->find(g.B);
+        if (it != g_split_table->end()) {
+            GemmArgs s = g;
+            s.B_hi = it->second.hi;
+            s.B_lo = it->second.lo;
+            return launch_gemm_split(s, stream);
+        }
+    }
     BG_REQUIRE(g.K % BK == 0, "gemm: K=%d must be a multiple of %d (pad the operands)", g.K, BK);
     BG_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 floats");
     BG_REQUIRE(g.M > 0 && g.N > 0 && g.batch > 0, "gemm: empty problem");

@@ -25,8 +25,18 @@ struct GemmArgs {
     int mode = MODE_PLAIN;
     // MODE_CONV3: output spatial size (conv_h x conv_w), input channels, fused nearest-2x upsample of the input
     int conv_h = 0, conv_w = 0, conv_cin = 0, conv_up = 0;
+    // split-precision path (gemm_split.hip): the (hi, lo) f16 planes of B, same [N, ldb] layout; null = exact fp32 MFMA path
+    const uint16_t* B_hi = nullptr;
+    const uint16_t* B_lo = nullptr;
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
+
+// Split-precision (3x f16 MFMA, fp32-class accuracy) variant and its weight preparation
+struct SplitPlanes { const uint16_t* hi; const uint16_t* lo; };
+void launch_gemm_split(const GemmArgs& g, hipStream_t stream);
+void launch_split_weight(const float* w, void* hi, void* lo, long n, hipStream_t s);
+// Table of pre-split weights of the context whose call is executing (null = exact fp32 everywhere): launch_gemm consults it by B pointer.
+void split_registry_set(const void* table /* const std::unordered_map<const float*, SplitPlanes>* */);
 
 // Skinny GEMM for decode steps (M <= 64 rows, weight-streaming bound): C[M,N] = A[M,K] B[N,K]^T + bias, act, residual
 void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream);               // library-owned split-K workspace (op tests)

@@ -98,6 +98,10 @@ struct Ctx {
     const float *norm_out_w = nullptr, *norm_out_b = nullptr;
     float *denorm_mean = nullptr, *denorm_std = nullptr;
 
+    // ---- split-precision mode (BEVGEN_PRECISION_F16X3): (hi, lo) f16 planes of every GEMM / conv weight, keyed by its fp32 device pointer
+    std::unordered_map<const float*, SplitPlanes> split;
+    void split_weight(const float* w, long n);
+
     // ---- hipGraph replay of the Route A decode step
     hipStream_t graph_stream = nullptr;
     hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;

@@ -27,6 +27,7 @@ ConvW load_conv(Ctx& c, const std::string& name, int k) {
     cw.b = c.pf(kPrefix + name + ".bias");
     cw.w = reinterpret_cast<float*>(c.own(w.bytes));
     launch_relayout_conv_weight(w.f(), cw.w, cw.cout, cw.cin, k, k, 0);
+    c.split_weight(cw.w, (long)cw.cout * cw.cin * k * k);
     return cw;
 }
 

@@ -61,7 +61,7 @@ class Context:
         c = bevgen_cfg()
         c.abi_version = _lib.ABI_VERSION
         c.route = _lib.ROUTE_MASKGIT if route == "maskgit" else _lib.ROUTE_AR
-        c.precision = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16}[precision]
+        c.precision = {"fp32": _lib.PRECISION_FP32, "f16x3": _lib.PRECISION_F16X3}[precision]
         c.max_batch = max_batch
         if cfg is not None:
             c.num_layers, c.num_heads, c.dim = cfg.num_layers, cfg.num_heads, cfg.num_embed

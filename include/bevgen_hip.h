@@ -30,7 +30,10 @@ extern "C" {
 #define BEVGEN_ABI_VERSION 1
 
 enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
-enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 };
+/* FP32  : every product and accumulation in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32) - bit-exact greedy tokens vs the CPU reference.
+ * F16X3 : large GEMMs / convolutions as 3 f16 MFMAs per k-step on (hi, lo*2^-11) splits of the fp32 operands: ~2^-22 relative error per product,
+ *         fp32 accumulation, up to 5x the fp32 MFMA rate.  Everything else (attention, norms, samplers, decode-step GEMMs) stays fp32. */
+enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 /* reserved */, BEVGEN_PRECISION_F16X3 = 2 };
 enum { BEVGEN_DTYPE_F32 = 0, BEVGEN_DTYPE_I64 = 1, BEVGEN_DTYPE_U8 = 2, BEVGEN_DTYPE_F64 = 3 };
 
 enum {

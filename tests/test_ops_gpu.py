@@ -162,3 +162,33 @@ def test_groupnorm(gpu_ctx, n, hw, C, swish):
         ref = ref * torch.sigmoid(ref)
     out = gpu_ctx.op_groupnorm(dev(x.permute(0, 2, 3, 1)), dev(gamma), dev(beta), swish=swish)
     assert rel(out.cpu().permute(0, 3, 1, 2), ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 136, 64), (777, 1024, 1024), (300, 5460, 1024), (260, 1024, 2752)])
+def test_gemm_split_precision(gpu_ctx, M, N, K):
+    """3x f16 MFMA on (hi, lo*2^-11) splits: fp32-class accuracy (a handful of fp32 ulps beyond the exact fp32 path)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 3.0          # LayerNorm-like magnitudes
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
+    out = torch.empty(M, N, device="cuda")
+    from bevgen_amd.runtime import _ptr, _stream
+    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(dev(a)), _ptr(dev(w)), _ptr(dev(b)), _ptr(dev(r)), _ptr(out), M, N, K, 1, 2, _stream()))
+    err = rel(out.cpu().double(), ref)
+    exact = rel(gpu_ctx.op_gemm(dev(a), dev(w), dev(b), dev(r), gelu=True).cpu().double(), ref)
+    assert err < 2e-6, (err, exact)
+
+
+def test_gemm_split_precision_small_and_large_magnitudes(gpu_ctx):
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(256, 256, generator=g)
+    a[:, ::7] *= 1e-5     # tiny entries (f16-subnormal hi parts) must not lose the result
+    a[:, 3::11] *= 3e3    # large but in-range
+    w = torch.randn(128, 256, generator=g) * 0.05
+    ref = a.double() @ w.double().t()
+    out = torch.empty(256, 128, device="cuda")
+    from bevgen_amd.runtime import _ptr, _stream
+    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(dev(a)), _ptr(dev(w)), None, None, _ptr(out), 256, 128, 256, 0, 2, _stream()))
+    assert rel(out.cpu().double(), ref) < 2e-6
