@@ -72,6 +72,21 @@ struct AttnArgs {
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
+// Split-precision flash attention (attention_split.hip): operands pre-split into (hi, lo) f16 planes by the preparation kernels.
+//   Qh/Ql [B,H,Nq,64], Kh/Kl [B,H,Nk_pad,64], VTh/VTl [B,H,64,Nk_pad] (V transposed); bias / output conventions as AttnArgs.
+struct AttnSplitArgs {
+    const _Float16 *Qh, *Ql, *Kh, *Kl, *VTh, *VTl;
+    const float* bias; float* O;
+    int B, H, Nq, Nk_pad;
+    int ldbias; long bias_head_stride;
+    float scale;
+    long o_bstride, o_qstride, o_hstride;
+};
+void launch_attention_split(const AttnSplitArgs& a, hipStream_t s);
+void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, hipStream_t s);
+void launch_muse_kv_prep_split(const float* kvraw, const float* null_kv, const float* k_scale, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nk,
+                               int Nk_pad, hipStream_t s);
+
 // Decode attention (Route A, one new query row per sequence): see attention.hip
 struct DecodeAttnArgs {
     const float* q = nullptr;        // [B, H*64] this step's query rows (row stride ldq)

@@ -91,7 +91,13 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
         HIP_CHECK(hipMemsetAsync(w.crossV[i], 0, kvC * sizeof(float), s));
         const MuseLayer& l = c.muse[i];
         gemm(w.context, D, l.to_kv[1], D, w.kvraw, 2 * D, B * c.K, 2 * D, D, nullptr, 0, s);
-        launch_muse_kv_prep(w.kvraw, l.null_kv[1], l.k_scale[1], w.crossK[i], w.crossV[i], B, H, c.K, c.NkC_pad, s);
+        if (c.cfg.precision == BEVGEN_PRECISION_F16X3) {  // each fp32-sized buffer holds the (hi, lo) f16 planes back to back
+            _Float16* kh = reinterpret_cast<_Float16*>(w.crossK[i]);
+            _Float16* vh = reinterpret_cast<_Float16*>(w.crossV[i]);
+            launch_muse_kv_prep_split(w.kvraw, l.null_kv[1], l.k_scale[1], kh, kh + kvC, vh, vh + kvC, B, H, c.K, c.NkC_pad, s);
+        } else {
+            launch_muse_kv_prep(w.kvraw, l.null_kv[1], l.k_scale[1], w.crossK[i], w.crossV[i], B, H, c.K, c.NkC_pad, s);
+        }
     }
 }
 
@@ -108,8 +114,22 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         launch_layernorm(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
         gemm(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
         gemm(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
-        launch_muse_q_prep(w.qraw, l.q_scale[0], w.Q, B, H, N, s);
-        launch_muse_kv_prep(w.kvraw, l.null_kv[0], l.k_scale[0], w.Ks, w.Vs, B, H, N, c.NkS_pad, s);
+        const bool split = g.precision == BEVGEN_PRECISION_F16X3;
+        const size_t qN = (size_t)rows * D, kvS = (size_t)B * H * c.NkS_pad * 64, kvC = (size_t)B * H * c.NkC_pad * 64;
+        _Float16 *Qh = reinterpret_cast<_Float16*>(w.Q), *Ksh = reinterpret_cast<_Float16*>(w.Ks), *VTsh = reinterpret_cast<_Float16*>(w.Vs);
+        AttnSplitArgs sa{};
+        if (split) {
+            launch_muse_q_prep_split(w.qraw, l.q_scale[0], Qh, Qh + qN, B, H, N, s);
+            launch_muse_kv_prep_split(w.kvraw, l.null_kv[0], l.k_scale[0], Ksh, Ksh + kvS, VTsh, VTsh + kvS, B, H, N, c.NkS_pad, s);
+            sa.Qh = Qh; sa.Ql = Qh + qN; sa.Kh = Ksh; sa.Kl = Ksh + kvS; sa.VTh = VTsh; sa.VTl = VTsh + kvS;
+            sa.bias = c.bias_self; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
+            sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f;
+            sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
+            launch_attention_split(sa, s);
+        } else {
+            launch_muse_q_prep(w.qraw, l.q_scale[0], w.Q, B, H, N, s);
+            launch_muse_kv_prep(w.kvraw, l.null_kv[0], l.k_scale[0], w.Ks, w.Vs, B, H, N, c.NkS_pad, s);
+        }
         AttnArgs a{};
         a.Q = w.Q; a.K = w.Ks; a.V = w.Vs; a.bias = c.bias_self; a.R = nullptr; a.O = w.att;
         a.B = B; a.H = H; a.Nq = N; a.Nk_pad = c.NkS_pad;
@@ -117,16 +137,24 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         a.kv_bstride = (long)H * c.NkS_pad * 64; a.kv_hstride = (long)c.NkS_pad * 64;
         a.ldbias = c.ldS; a.bias_head_stride = 0; a.scale = 8.0f;
         a.o_bstride = (long)N * D; a.o_qstride = D; a.o_hstride = 64;
-        launch_attention(a, s);
+        if (!split) launch_attention(a, s);
         gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);  // x = to_out(att) + x
         // ---- cross attention
         launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
         gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
-        launch_muse_q_prep(w.qraw, l.q_scale[1], w.Q, B, H, N, s);
-        a.K = w.crossK[i]; a.V = w.crossV[i]; a.bias = c.bias_cross; a.Nk_pad = c.NkC_pad;
-        a.kv_bstride = (long)H * c.NkC_pad * 64; a.kv_hstride = (long)c.NkC_pad * 64;
-        a.ldbias = c.ldC;
-        launch_attention(a, s);
+        if (split) {
+            launch_muse_q_prep_split(w.qraw, l.q_scale[1], Qh, Qh + qN, B, H, N, s);
+            _Float16 *ckh = reinterpret_cast<_Float16*>(w.crossK[i]), *cvh = reinterpret_cast<_Float16*>(w.crossV[i]);
+            sa.Kh = ckh; sa.Kl = ckh + kvC; sa.VTh = cvh; sa.VTl = cvh + kvC;
+            sa.bias = c.bias_cross; sa.Nk_pad = c.NkC_pad; sa.ldbias = c.ldC;
+            launch_attention_split(sa, s);
+        } else {
+            launch_muse_q_prep(w.qraw, l.q_scale[1], w.Q, B, H, N, s);
+            a.K = w.crossK[i]; a.V = w.crossV[i]; a.bias = c.bias_cross; a.Nk_pad = c.NkC_pad;
+            a.kv_bstride = (long)H * c.NkC_pad * 64; a.kv_hstride = (long)c.NkC_pad * 64;
+            a.ldbias = c.ldC;
+            launch_attention(a, s);
+        }
         gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
         // ---- feed forward
         launch_layernorm(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);

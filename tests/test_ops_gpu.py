@@ -175,7 +175,8 @@ def test_gemm_split_precision(gpu_ctx, M, N, K):
     ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
     out = torch.empty(M, N, device="cuda")
     from bevgen_amd.runtime import _ptr, _stream
-    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(dev(a)), _ptr(dev(w)), _ptr(dev(b)), _ptr(dev(r)), _ptr(out), M, N, K, 1, 2, _stream()))
+    da, dw, db, dr = dev(a), dev(w), dev(b), dev(r)  # keep the device tensors alive across the raw-pointer call
+    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), _ptr(db), _ptr(dr), _ptr(out), M, N, K, 1, 2, _stream()))
     err = rel(out.cpu().double(), ref)
     exact = rel(gpu_ctx.op_gemm(dev(a), dev(w), dev(b), dev(r), gelu=True).cpu().double(), ref)
     assert err < 2e-6, (err, exact)
@@ -190,5 +191,6 @@ def test_gemm_split_precision_small_and_large_magnitudes(gpu_ctx):
     ref = a.double() @ w.double().t()
     out = torch.empty(256, 128, device="cuda")
     from bevgen_amd.runtime import _ptr, _stream
-    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(dev(a)), _ptr(dev(w)), None, None, _ptr(out), 256, 128, 256, 0, 2, _stream()))
+    da, dw = dev(a), dev(w)
+    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), None, None, _ptr(out), 256, 128, 256, 0, 2, _stream()))
     assert rel(out.cpu().double(), ref) < 2e-6
