@@ -31,6 +31,22 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_FP32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32: exact fp32 at the vector rate (dense)
+MFMA_F16_PEAK_TF = 2500.0   # dense f16/bf16 MFMA peak
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
+    gfx950 correction applied), at the probe shape recorded there; None if no PMC summary covers the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.split("<")[0] in kernel:
+                return {"bytes_per_launch": v["traffic_bytes"], "algorithmic_bytes": v["algorithmic_bytes"], "shape": v["shape"], "source": os.path.basename(path)}
+    return None
 
 
 def parse():
@@ -45,7 +61,8 @@ def parse():
     ap.add_argument("--no-decode-leg", action="store_true")
     ap.add_argument("--decode-batch", type=int, default=16)
     ap.add_argument("--decode-steps", type=int, default=0, help="0 = a full decode (N image tokens)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "f16x3"], help="fp32 = exact fp32 MFMA (bit-exact parity mode); f16x3 = split-precision GEMMs")
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"], help="fp32 = exact fp32 MFMA; f16x3 = split-precision products (both bit-exact on the parity fixtures)")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the additional one-step run in exact-fp32 mode")
     return ap.parse_args()
 
 
@@ -140,7 +157,7 @@ def decode_leg(device, batch, steps):
     ach = da["work"] / (da["ms"] * 1e-3) / 1e9 if da["ms"] > 0 else 0.0
     out = {
         "ms_per_decode_step": wall * 1e3 / steps,
-        "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("decode_attention_kernel"),
                                       "launches": int(da["launches"]), "avg_us": da["ms"] * 1e3 / max(da["launches"], 1),
                                       "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of a full decode, fp32 KV cache, L=2368"},
         "decode_scenes_per_s": batch / wall,
@@ -168,53 +185,73 @@ def main():
     from bevgen_amd import synthetic
     from bevgen_amd.parallel import gather_scenes
 
-    cfg, ctx, _ = build_route_m(args.cams, args.batch, local_rank, args.precision)
-    bt = synthetic.make_batch(cfg, args.batch, seed=1000 + rank)  # each rank: its own shard of scenes
-    bt = {k: v.to(ctx.device) for k, v in bt.items()}
+    def run_route_m(precision, steps, warmup):
+        cfg, ctx, _ = build_route_m(args.cams, args.batch, local_rank, precision)
+        bt = synthetic.make_batch(cfg, args.batch, seed=1000 + rank)  # each rank: its own shard of scenes
+        bt = {k: v.to(ctx.device) for k, v in bt.items()}
 
-    def one_step():
-        ids = ctx.maskgit_generate(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], timesteps=args.timesteps)
-        px = ctx.vq_decode(ids.reshape(args.batch * args.cams, -1), denormalize=True)      # [B*C,3,256,256] in [0,1]
-        return gather_scenes(px.reshape(args.batch, args.cams, 3, px.shape[-2], px.shape[-1]), dist)
+        def one_step():
+            ids = ctx.maskgit_generate(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], timesteps=args.timesteps)
+            px = ctx.vq_decode(ids.reshape(args.batch * args.cams, -1), denormalize=True)      # [B*C,3,256,256] in [0,1]
+            return gather_scenes(px.reshape(args.batch, args.cams, 3, px.shape[-2], px.shape[-1]), dist)
 
-    for _ in range(args.warmup):
-        one_step()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ctx.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_end()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    ctx.close()
+        for _ in range(warmup):
+            one_step()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        prof = ctx.profile_end()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ctx.close()
+        return float(t.item()), prof
+
+    elapsed, prof = run_route_m(args.precision, args.steps, args.warmup)
+    exact = None
+    if world == 1 and args.precision != "fp32" and not args.no_exact_leg:
+        e2, p2 = run_route_m("fp32", 1, 1)   # the exact-fp32 parity mode on the same workload (one step)
+        exact = (e2, p2)
 
     if rank != 0:
         if dist:
             dist.destroy_process_group()
         return
 
+    def roof(prof, elapsed_s, precision):
+        g = prof["gemm"]
+        ach = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        if precision == "fp32":
+            peak, kern, note = MFMA_FP32_PEAK_TF, "gemm_f32_kernel<MODE_PLAIN>", "v_mfma_f32_32x32x2_f32, exact fp32"
+        else:
+            peak, kern, note = MFMA_F16_PEAK_TF / 3.0, "gemm_split_kernel<MODE_PLAIN>", "3 v_mfma_f32_32x32x16_f16 per fp32 product (hi/lo split): ceiling = f16 dense peak / 3"
+        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(kern), "kernel": kern, "note": note,
+                "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1)}
+
     scenes = world * args.batch * args.steps
-    g = prof["gemm"]
-    ach_tf = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     line = {
         "metric": "multi-view scenes/sec (6x256x256)", "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM/conv/attention products as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; everything else fp32)",
+        "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: Route M MaskGit (14 layers, D=1024, 18 iterations, self-critic) {args.cams}x256x256, batch {args.batch} scenes/GPU, + VQGAN f16 decode",
-                   "global_batch": world * args.batch, "parallelism": f"scene-parallel x{world} (RCCL gather of uint8 pixels)"},
-        "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": MFMA_FP32_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / MFMA_FP32_PEAK_TF, "traffic": None,
-                     "kernel": "gemm_f32_kernel<MODE_PLAIN>", "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1)},
+                   "global_batch": world * args.batch, "parallelism": f"scene-parallel x{world} (RCCL gather of uint8 pixels)", "precision_mode": args.precision},
+        "roofline": roof(prof, elapsed, args.precision),
         "kernel_time_share": {k: v["ms"] / (elapsed * 1e3) for k, v in prof.items() if v["launches"]},
         "kernel_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12) for k, v in prof.items() if v["launches"] and k in ("gemm", "conv3x3", "attention")},
     }
+    if exact is not None:
+        e2, p2 = exact
+        line["exact_fp32_mode"] = {"value": world * args.batch / e2, "unit": "scenes/s", "ms_per_step": e2 * 1e3, "roofline": roof(p2, e2, "fp32"),
+                                   "note": "bit-exact-parity mode (every product in fp32 on the matrix cores), same workload, 1 step"}
     if world == 1 and not args.no_decode_leg:
         line.update(decode_leg(local_rank, args.decode_batch, args.decode_steps))
     if world == 1 and not args.no_cpu_baseline:

@@ -60,21 +60,19 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs a) {
 
     // tile loader: 32 rows x 16 float4 = 512 float4 per matrix -> 2 per thread
     const int lrow0 = tid >> 4, lc4 = tid & 15;  // rows lrow0 and lrow0+16
-    float4 rk[2], rv[2];
+    float4 rk0, rk1, rv0, rv1;  // named registers (arrays captured by the lambdas below would be demoted to scratch)
     auto gload = [&](int tile) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const long off = (long)(tile * KT + lrow0 + 16 * i) * 64 + lc4 * 4;
-            rk[i] = *reinterpret_cast<const float4*>(Kp + off);
-            rv[i] = *reinterpret_cast<const float4*>(Vp + off);
-        }
+        const long off0 = (long)(tile * KT + lrow0) * 64 + lc4 * 4, off1 = off0 + 16 * 64;
+        rk0 = *reinterpret_cast<const float4*>(Kp + off0);
+        rv0 = *reinterpret_cast<const float4*>(Vp + off0);
+        rk1 = *reinterpret_cast<const float4*>(Kp + off1);
+        rv1 = *reinterpret_cast<const float4*>(Vp + off1);
     };
     auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<float4*>(&Ks[buf][(lrow0 + 16 * i) * KLD + lc4 * 4]) = rk[i];
-            *reinterpret_cast<float4*>(&Vs[buf][(lrow0 + 16 * i) * VLD + lc4 * 4]) = rv[i];
-        }
+        *reinterpret_cast<float4*>(&Ks[buf][lrow0 * KLD + lc4 * 4]) = rk0;
+        *reinterpret_cast<float4*>(&Vs[buf][lrow0 * VLD + lc4 * 4]) = rv0;
+        *reinterpret_cast<float4*>(&Ks[buf][(lrow0 + 16) * KLD + lc4 * 4]) = rk1;
+        *reinterpret_cast<float4*>(&Vs[buf][(lrow0 + 16) * VLD + lc4 * 4]) = rv1;
     };
 
     const int ntiles = a.Nk_pad / KT;

@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         if (more) gload(tile + 1);
 
         // ---- S^T = K Q^T
-        f32x16 sM, sC;
+        f32x16 sM, sC, sD;  // main, and two correction accumulators so that no MFMA depends on its predecessor
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sM[r] = 0.f; sC[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { sM[r] = 0.f; sC[r] = 0.f; sD[r] = 0.f; }
         const _Float16* kh = &Kh[cur][qi * SKLD + 8 * h];
         const _Float16* kl = &Kl[cur][qi * SKLD + 8 * h];
 #pragma unroll
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
             const half8 al = *reinterpret_cast<const half8*>(kl + 16 * s);
             sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], sM, 0, 0, 0);
             sC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], sC, 0, 0, 0);
-            sC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], sC, 0, 0, 0);
+            sD = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], sD, 0, 0, 0);
         }
 
         // ---- scale + bias, online softmax
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
             const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                sv[4 * g + j] = (sM[4 * g + j] + sC[4 * g + j] * kLoI) * a.scale + bb[j];
+                sv[4 * g + j] = (sM[4 * g + j] + (sC[4 * g + j] + sD[4 * g + j]) * kLoI) * a.scale + bb[j];
                 mx = fmaxf(mx, sv[4 * g + j]);
             }
         }
@@ -134,19 +134,24 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
 
         // ---- O^T += V^T P^T.  k-step s covers keys [16s, 16s+16); lane half h owns keys 16s + {0..3} + 4h and 16s + 8 + {0..3} + 4h
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const _Float16* vh = &Vh[cur][(32 * t + qi) * SVLD + 4 * h];
-            const _Float16* vl = &Vl[cur][(32 * t + qi) * SVLD + 4 * h];
+        for (int s = 0; s < 2; ++s) {
+            half8 avh[2], avl[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const half4 h0 = *reinterpret_cast<const half4*>(vh + 16 * s), h1 = *reinterpret_cast<const half4*>(vh + 16 * s + 8);
-                const half4 l0 = *reinterpret_cast<const half4*>(vl + 16 * s), l1 = *reinterpret_cast<const half4*>(vl + 16 * s + 8);
-                const half8 avh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                const half8 avl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                oM[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, ph[s], oM[t], 0, 0, 0);
-                oC[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, pl[s], oC[t], 0, 0, 0);
-                oC[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, ph[s], oC[t], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                const _Float16* vh = &Vh[cur][(32 * t + qi) * SVLD + 4 * h + 16 * s];
+                const _Float16* vl = &Vl[cur][(32 * t + qi) * SVLD + 4 * h + 16 * s];
+                const half4 h0 = *reinterpret_cast<const half4*>(vh), h1 = *reinterpret_cast<const half4*>(vh + 8);
+                const half4 l0 = *reinterpret_cast<const half4*>(vl), l1 = *reinterpret_cast<const half4*>(vl + 8);
+                avh[t] = half8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                avl[t] = half8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             }
+            // interleave the two head-dim halves so that consecutive MFMAs never share an accumulator
+            oM[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[0], ph[s], oM[0], 0, 0, 0);
+            oM[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[1], ph[s], oM[1], 0, 0, 0);
+            oC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[0], pl[s], oC[0], 0, 0, 0);
+            oC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[1], pl[s], oC[1], 0, 0, 0);
+            oC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[0], ph[s], oC[0], 0, 0, 0);
+            oC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[1], ph[s], oC[1], 0, 0, 0);
         }
 
         if (more) lstore(cur ^ 1);

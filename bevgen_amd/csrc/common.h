@@ -40,6 +40,21 @@ struct Error : std::runtime_error {
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 
+// XCD-aware tile order for 2-D tiled GEMMs.  Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, used
+// for speed only), each with a private L2.  With the natural order the gx column tiles that share one A row-panel land on 8 different L2s
+// and the panel is fetched from HBM 8 times (measured: 4.5x the algorithmic traffic).  Re-labelling so that every XCD walks a CONTIGUOUS
+// range of tile ids keeps a panel's column tiles on one XCD, back to back.  Bijective for any grid size (MI355X guide, T1).
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+    const int total = gx * gy;
+    const int lin = blockIdx.y * gx + blockIdx.x;
+    const int xcd = lin & 7, k = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int logical = base + k;
+    ty = logical / gx;
+    tx = logical - ty * gx;
+}
+
 constexpr float kNegBig = -1.0e30f;  // "minus infinity" that never produces inf-inf NaNs in online softmax
 
 // -------- wave-level helpers (wave = 64 lanes) --------

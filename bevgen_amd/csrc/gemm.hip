@@ -85,8 +85,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    // blockIdx.x walks N-tiles fastest so that concurrently resident blocks share the same A panel (L2 reuse)
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // N-tiles fastest within an XCD-contiguous id range: the column tiles of one A row-panel run back to back on ONE XCD (shared L2)
+    int tx, ty;
+    xcd_tile(gridDim.x, gridDim.y, tx, ty);
+    const int n0 = tx * BN, m0 = ty * BM;
     const int bz = blockIdx.z;
     const float* A = g.A + (long)bz * g.strideA;
     const float* B = g.B + (long)bz * g.strideB;

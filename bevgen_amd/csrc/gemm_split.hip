@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * SBN, m0 = blockIdx.y * SBM;
+    int tx, ty;
+    xcd_tile(gridDim.x, gridDim.y, tx, ty);
+    const int n0 = tx * SBN, m0 = ty * SBM;
     const int bz = blockIdx.z;
     const float* A = g.A + (long)bz * g.strideA;
 
@@ -180,14 +182,20 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs g) {
                 bh[i] = *reinterpret_cast<const half8*>(b_hi + i * 32 * SLD + ks * 16);
                 bl[i] = *reinterpret_cast<const half8*>(b_lo + i * 32 * SLD + ks * 16);
             }
+            // issue order: no accumulator is reused by the next MFMA (a dependent back-to-back pair stalls the matrix pipe for the
+            // full result latency) - every accumulator is touched again only 4 instructions later
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accM[i][j], 0, 0, 0);
-                    accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accC[i][j], 0, 0, 0);
-                    accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accM[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accC[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
         }
         if (more) {
             _Float16* nx = cur ? stage0 : stage1;
