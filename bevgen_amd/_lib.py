@@ -35,7 +35,7 @@ class bevgen_cfg(C.Structure):
         ("ff_inner", C.c_int32), ("max_batch", C.c_int32),
         ("vq_ch", C.c_int32), ("vq_num_res_blocks", C.c_int32), ("vq_z_channels", C.c_int32), ("vq_embed_dim", C.c_int32),
         ("vq_n_embed", C.c_int32), ("vq_resolution", C.c_int32), ("vq_out_ch", C.c_int32), ("vq_num_levels", C.c_int32),
-        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("reserved", C.c_int32 * 16),
+        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("vq_in_channels", C.c_int32), ("reserved", C.c_int32 * 15),
     ]
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "bevgen_ar_sample": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _p, _p]),
     "bevgen_vq_decode": (_i, [_p, _p, _i, _i, _p, _p]),
     "bevgen_vq_decode_latents": (_i, [_p, _p, _i, _i, _p, _p]),
+    "bevgen_vq_encode": (_i, [_p, _p, _i, _p, _p]),
     "bevgen_op_gemm": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "bevgen_op_layernorm": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "bevgen_op_geglu_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),

@@ -164,6 +164,14 @@ int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* ids, int n, int denormalize
     });
 }
 
+int bevgen_vq_encode(bevgen_ctx* ctx, const float* x, int n, int64_t* ids, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(x && ids && n >= 1, "vq_encode: bad arguments");
+        vq_encode(*ctx, x, n, ids, (hipStream_t)stream);
+    });
+}
+
 int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* zq, int n, int denormalize, float* out, void* stream) {
     return guarded(ctx, [&] {
         need_final(ctx);

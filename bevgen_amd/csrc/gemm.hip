@@ -41,12 +41,13 @@ __device__ __forceinline__ void load_a_tile(const GemmArgs& g, const float* __re
                 const int tap = k0 / g.conv_cin;
                 const int c0 = k0 - tap * g.conv_cin;
                 const int kh = tap / 3, kw = tap - kh * 3;
-                int yy = rowinfo[i][1] + kh - 1, xx = rowinfo[i][2] + kw - 1;
-                if (yy >= 0 && yy < g.conv_h && xx >= 0 && xx < g.conv_w) {
+                // input coordinate of this tap: stride 1|2, zero padding `conv_pad` on the top/left (the bottom/right padding is implied by
+                // the bounds test), optional nearest-2x upsample of the stored input
+                int yy = rowinfo[i][1] * g.conv_stride + kh - g.conv_pad, xx = rowinfo[i][2] * g.conv_stride + kw - g.conv_pad;
+                const int lim_h = g.conv_up ? 2 * g.conv_hin : g.conv_hin, lim_w = g.conv_up ? 2 * g.conv_win : g.conv_win;
+                if (yy >= 0 && yy < lim_h && xx >= 0 && xx < lim_w) {
                     if (g.conv_up) { yy >>= 1; xx >>= 1; }
-                    const int hin = g.conv_up ? (g.conv_h >> 1) : g.conv_h;
-                    const int win = g.conv_up ? (g.conv_w >> 1) : g.conv_w;
-                    v = *reinterpret_cast<const float4*>(A + (((long)rowinfo[i][0] * hin + yy) * win + xx) * g.conv_cin + c0 + c4 * 4);
+                    v = *reinterpret_cast<const float4*>(A + (((long)rowinfo[i][0] * g.conv_hin + yy) * g.conv_win + xx) * g.conv_cin + c0 + c4 * 4);
                 }
             }
         }
@@ -179,10 +180,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+static GemmArgs conv_defaults(const GemmArgs& g0) {
+    GemmArgs g = g0;
+    if (g.mode == MODE_CONV3) {
+        if (g.conv_stride == 0) g.conv_stride = 1;
+        if (g.conv_pad < 0) g.conv_pad = 1;
+        if (g.conv_hin == 0) g.conv_hin = g.conv_up ? g.conv_h / 2 : g.conv_h;
+        if (g.conv_win == 0) g.conv_win = g.conv_up ? g.conv_w / 2 : g.conv_w;
+    }
+    return g;
+}
+
 static const std::unordered_map<const float*, SplitPlanes>* g_split_table = nullptr;
 void split_registry_set(const void* table) { g_split_table = reinterpret_cast<const std::unordered_map<const float*, SplitPlanes>*>(table); }
 
-void launch_gemm(const GemmArgs& g, hipStream_t stream) {
+void launch_gemm(const GemmArgs& g_in, hipStream_t stream) {
+    const GemmArgs g = conv_defaults(g_in);
     if (g.B_hi) return launch_gemm_split(g, stream);
     if (g_split_table && g.strideB == 0) {  // the executing context runs in split-precision mode and B is one of its (pre-split) weights
         auto it = g_split_table->find(g.B);

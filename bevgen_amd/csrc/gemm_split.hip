@@ -55,12 +55,11 @@ __device__ __forceinline__ void load_a(const GemmArgs& g, const float* __restric
                 const int tap = k0 / g.conv_cin;
                 const int c0 = k0 - tap * g.conv_cin;
                 const int kh = tap / 3, kw = tap - kh * 3;
-                int yy = rowinfo[i][1] + kh - 1, xx = rowinfo[i][2] + kw - 1;
-                if (yy >= 0 && yy < g.conv_h && xx >= 0 && xx < g.conv_w) {
+                int yy = rowinfo[i][1] * g.conv_stride + kh - g.conv_pad, xx = rowinfo[i][2] * g.conv_stride + kw - g.conv_pad;
+                const int lim_h = g.conv_up ? 2 * g.conv_hin : g.conv_hin, lim_w = g.conv_up ? 2 * g.conv_win : g.conv_win;
+                if (yy >= 0 && yy < lim_h && xx >= 0 && xx < lim_w) {
                     if (g.conv_up) { yy >>= 1; xx >>= 1; }
-                    const int hin = g.conv_up ? (g.conv_h >> 1) : g.conv_h;
-                    const int win = g.conv_up ? (g.conv_w >> 1) : g.conv_w;
-                    src = A + (((long)rowinfo[i][0] * hin + yy) * win + xx) * g.conv_cin + c0 + c8 * 8;
+                    src = A + (((long)rowinfo[i][0] * g.conv_hin + yy) * g.conv_win + xx) * g.conv_cin + c0 + c8 * 8;
                 }
             }
         }
@@ -228,7 +227,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs g) {
         }
 }
 
-void launch_gemm_split(const GemmArgs& g, hipStream_t stream) {
+void launch_gemm_split(const GemmArgs& g_in, hipStream_t stream) {
+    GemmArgs g = g_in;
+    if (g.mode == MODE_CONV3) {
+        if (g.conv_stride == 0) g.conv_stride = 1;
+        if (g.conv_pad < 0) g.conv_pad = 1;
+        if (g.conv_hin == 0) g.conv_hin = g.conv_up ? g.conv_h / 2 : g.conv_h;
+        if (g.conv_win == 0) g.conv_win = g.conv_up ? g.conv_w / 2 : g.conv_w;
+    }
     BG_REQUIRE(g.B_hi && g.B_lo, "gemm_split: the B operand has not been split");
     BG_REQUIRE(g.K % SBK == 0 && g.lda % 4 == 0 && g.ldb % 8 == 0, "gemm_split: K %% 32, lda %% 4, ldb %% 8 required (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
     BG_REQUIRE(g.batch == 1 || g.strideB == 0, "gemm_split: batched B operands are not split");

@@ -25,6 +25,9 @@ struct GemmArgs {
     int mode = MODE_PLAIN;
     // MODE_CONV3: output spatial size (conv_h x conv_w), input channels, fused nearest-2x upsample of the input
     int conv_h = 0, conv_w = 0, conv_cin = 0, conv_up = 0;
+    // general form: stored input is conv_hin x conv_win, tap coordinate = out * conv_stride + k - conv_pad (0 = derive the 'same' defaults:
+    // stride 1, pad 1, hin/win = output size or half of it with conv_up).  Downsample (stage1/model.py:56-75): stride 2, pad 0, hin = 2*conv_h.
+    int conv_hin = 0, conv_win = 0, conv_stride = 0, conv_pad = -1;
     // split-precision path (gemm_split.hip): the (hi, lo) f16 planes of B, same [N, ldb] layout; null = exact fp32 MFMA path
     const uint16_t* B_hi = nullptr;
     const uint16_t* B_lo = nullptr;

@@ -49,6 +49,7 @@ struct ConvW { float* w = nullptr; const float* b = nullptr; int cin = 0, cout =
 struct ResBlockW { const float *n1w, *n1b, *n2w, *n2b; ConvW c1, c2, nin; bool has_nin = false; int cin = 0, cout = 0; };
 struct AttnBlockW { const float *nw, *nb; ConvW q, k, v, proj; int c = 0; };
 struct UpLevelW { std::vector<ResBlockW> blocks; std::vector<AttnBlockW> attns; bool has_up = false; ConvW up; };
+struct DownLevelW { std::vector<ResBlockW> blocks; std::vector<AttnBlockW> attns; bool has_down = false; ConvW down; };
 
 struct Ctx {
     bevgen_cfg cfg{};
@@ -97,6 +98,15 @@ struct Ctx {
     std::vector<UpLevelW> up;  // index = level (0 = full resolution)
     const float *norm_out_w = nullptr, *norm_out_b = nullptr;
     float *denorm_mean = nullptr, *denorm_std = nullptr;
+    // ---- VQGAN encoder + quantizer (stage1/model.py:342-433, vqgan.py:84-116, quantize.py:271-312)
+    bool has_vq_enc = false;
+    int enc_cin_pad = 0;
+    ConvW enc_conv_in, enc_conv_out, quant_conv;
+    std::vector<DownLevelW> down;
+    ResBlockW enc_mid1, enc_mid2;
+    AttnBlockW enc_mid_attn;
+    const float *enc_norm_out_w = nullptr, *enc_norm_out_b = nullptr;
+    float* codebook_sqnorm = nullptr;
 
     // ---- split-precision mode (BEVGEN_PRECISION_F16X3): (hi, lo) f16 planes of every GEMM / conv weight, keyed by its fp32 device pointer
     std::unordered_map<const float*, SplitPlanes> split;
@@ -134,6 +144,12 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
 // vqdec.cpp
 void vq_finalize(Ctx& c);
 void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n, int denorm, float* out, hipStream_t s);
+void vq_encode(Ctx& c, const float* x_nchw, int n, int64_t* ids, hipStream_t s);
+// vqenc_kernels.hip
+void launch_nchw_to_nhwc_pad(const float* x, float* y, int n, int hw, int C, int Cpad, hipStream_t s);
+void launch_relayout_conv_weight_pad(const float* w, float* o, int cout, int cin, int cin_pad, int kh, int kw, hipStream_t s);
+void launch_row_sqnorm(const float* x, float* out, long rows, int D, hipStream_t s);
+void launch_vq_argmin(const float* dots, const float* zz, const float* ee, int64_t* ids, long rows, int n_e, hipStream_t s);
 // tables.hip
 void launch_build_attn_bias(const float* tril_emb /*or null*/, const float* prob /*or null*/, float* out, int L, hipStream_t s);
 void launch_build_muse_bias(const float* attn_bias, int L, int K, int N, float* bias_self, int ldS, float* bias_cross, int ldC, hipStream_t s);

@@ -138,12 +138,19 @@ void attnblock(const AttnBlockW& a, Act& x, float* y, DecWs& ws, hipStream_t s) 
 
 }  // namespace
 
+static void vq_enc_finalize(Ctx& c);
+
 void vq_finalize(Ctx& c) {
     const auto& g = c.cfg;
     BG_REQUIRE(g.vq_num_levels >= 1 && g.vq_num_levels <= 8, "vq_num_levels out of range");
     const DevTensor& cb = c.need(kPrefix + "quantize.embedding.weight");
     BG_REQUIRE(cb.shape.size() == 2 && cb.shape[0] == g.vq_n_embed && cb.shape[1] == g.vq_embed_dim, "codebook must be [n_embed, embed_dim]");
     c.codebook = cb.f();
+    c.has_vq = c.find(kPrefix + "decoder.conv_in.weight") != nullptr;
+    c.has_vq_enc = c.find(kPrefix + "encoder.conv_in.weight") != nullptr;
+    BG_REQUIRE(c.has_vq || c.has_vq_enc, "VQGAN context: neither decoder.* nor encoder.* tensors were loaded");
+    if (c.has_vq_enc) vq_enc_finalize(c);
+    if (!c.has_vq) return;
     c.post_quant = load_conv(c, "post_quant_conv", 1);
     c.conv_in = load_conv(c, "decoder.conv_in", 3);
     c.mid1 = load_res(c, "decoder.mid.block_1.");
@@ -173,11 +180,10 @@ void vq_finalize(Ctx& c) {
     c.denorm_std = reinterpret_cast<float*>(c.own(sizeof stdv));
     HIP_CHECK(hipMemcpy(c.denorm_mean, mean, sizeof mean, hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(c.denorm_std, stdv, sizeof stdv, hipMemcpyHostToDevice));
-    c.has_vq = true;
 }
 
 void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_total, int denorm, float* out, hipStream_t s) {
-    BG_REQUIRE(c.has_vq, "this context was created without a VQGAN decoder (vq_ch == 0)");
+    BG_REQUIRE(c.has_vq, "this context holds no VQGAN decoder weights (decoder.* tensors were not loaded)");
     const auto& g = c.cfg;
     const int lat = g.vq_resolution >> (g.vq_num_levels - 1);
     const int R = g.vq_resolution;
@@ -264,6 +270,148 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
         conv3(t, c.conv_out, img, nullptr, 0, s);  // [n, R*R, out_ch]
         launch_nhwc_to_nchw(img, out + (long)i0 * g.vq_out_ch * R * R, n, R * R, g.vq_out_ch, g.vq_out_ch, denorm ? c.denorm_mean : nullptr,
                             denorm ? c.denorm_std : nullptr, denorm ? 1 : 0, s);
+    }
+}
+
+// =====================================================================================================
+// Encoder + quantizer: the step BEFORE the sampling path (encode_to_c / encode_to_z, muse_lm:142-155)
+//   Encoder.forward        stage1/model.py:405-433   (Downsample :56-75: zero pad (0,1,0,1) then 3x3 stride-2 conv)
+//   VQModel.encode         stage1/vqgan.py:84-116    (geometric_embedding=False in the released configs)
+//   VectorQuantizer2.forward  stage1/quantize.py:271-312
+// =====================================================================================================
+static ConvW load_conv_in_padded(Ctx& c, const std::string& name, int cin_pad) {
+    const DevTensor& w = c.need(kPrefix + name + ".weight");
+    BG_REQUIRE(w.shape.size() == 4 && w.shape[2] == 3 && w.shape[3] == 3, "conv '%s' is not a 3x3 kernel", name.c_str());
+    ConvW cw;
+    cw.cout = (int)w.shape[0];
+    cw.cin = cin_pad;
+    cw.k = 3;
+    cw.b = c.pf(kPrefix + name + ".bias");
+    cw.w = reinterpret_cast<float*>(c.own((size_t)cw.cout * 9 * cin_pad * sizeof(float)));
+    launch_relayout_conv_weight_pad(w.f(), cw.w, cw.cout, (int)w.shape[1], cin_pad, 3, 3, 0);
+    c.split_weight(cw.w, (long)cw.cout * 9 * cin_pad);
+    return cw;
+}
+
+static void vq_enc_finalize(Ctx& c) {
+    const auto& g = c.cfg;
+    BG_REQUIRE(g.vq_in_channels >= 1, "vq_in_channels must be set for the encoder");
+    c.enc_cin_pad = (int)round_up(g.vq_in_channels, 32);
+    c.enc_conv_in = load_conv_in_padded(c, "encoder.conv_in", c.enc_cin_pad);
+    c.down.clear();
+    c.down.resize(g.vq_num_levels);
+    int res = g.vq_resolution;
+    for (int lvl = 0; lvl < g.vq_num_levels; ++lvl) {
+        DownLevelW& d = c.down[lvl];
+        const std::string p = "encoder.down." + std::to_string(lvl) + ".";
+        for (int b = 0; b < g.vq_num_res_blocks; ++b) {
+            d.blocks.push_back(load_res(c, p + "block." + std::to_string(b) + "."));
+            if (res == g.vq_attn_resolution) d.attns.push_back(load_attn(c, p + "attn." + std::to_string(b) + "."));
+        }
+        d.has_down = lvl != g.vq_num_levels - 1;
+        if (d.has_down) {
+            d.down = load_conv(c, p + "downsample.conv", 3);
+            res /= 2;
+        }
+    }
+    c.enc_mid1 = load_res(c, "encoder.mid.block_1.");
+    c.enc_mid_attn = load_attn(c, "encoder.mid.attn_1.");
+    c.enc_mid2 = load_res(c, "encoder.mid.block_2.");
+    c.enc_norm_out_w = c.pf(kPrefix + "encoder.norm_out.weight");
+    c.enc_norm_out_b = c.pf(kPrefix + "encoder.norm_out.bias");
+    c.enc_conv_out = load_conv(c, "encoder.conv_out", 3);
+    c.quant_conv = load_conv(c, "quant_conv", 1);
+    BG_REQUIRE(c.enc_conv_out.cout == g.vq_z_channels && c.quant_conv.cout == g.vq_embed_dim, "encoder output channels do not match z_channels / embed_dim (double_z must be False)");
+    c.codebook_sqnorm = reinterpret_cast<float*>(c.own((size_t)g.vq_n_embed * sizeof(float)));
+    launch_row_sqnorm(c.codebook, c.codebook_sqnorm, g.vq_n_embed, g.vq_embed_dim, 0);
+}
+
+void vq_encode(Ctx& c, const float* x_nchw, int n_total, int64_t* ids, hipStream_t s) {
+    BG_REQUIRE(c.has_vq_enc, "this context holds no VQGAN encoder weights (encoder.* tensors were not loaded)");
+    const auto& g = c.cfg;
+    const int R = g.vq_resolution;
+    const int lat = R >> (g.vq_num_levels - 1);
+    long per_img = (long)R * R * std::max(c.enc_cin_pad, g.vq_ch);
+    int max_c = g.vq_ch;
+    {
+        int res = R;
+        for (int lvl = 0; lvl < g.vq_num_levels; ++lvl) {
+            const int ch = g.vq_ch * g.vq_ch_mult[lvl];
+            per_img = std::max<long>(per_img, (long)res * res * ch);
+            max_c = std::max(max_c, ch);
+            if (lvl != g.vq_num_levels - 1) res /= 2;
+        }
+    }
+    const int chunk = std::min(n_total, 16);
+    const long attn_hw = std::max<long>((long)g.vq_attn_resolution * g.vq_attn_resolution, (long)lat * lat);
+    const size_t act_b = (size_t)per_img * chunk * sizeof(float);
+    const size_t need = 4 * act_b + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, R * R) +
+                        (size_t)chunk * attn_hw * (3 * max_c + attn_hw) * sizeof(float) + (size_t)chunk * lat * lat * (g.vq_n_embed + g.vq_embed_dim + 1) * sizeof(float) + 32 * 256;
+    c.arena.reserve(need);
+    for (int i0 = 0; i0 < n_total; i0 += chunk) {
+        const int n = std::min(chunk, n_total - i0);
+        c.arena.reset();
+        DecWs ws;
+        ws.a = c.arena.get<float>((size_t)per_img * n);
+        ws.b = c.arena.get<float>((size_t)per_img * n);
+        ws.t = c.arena.get<float>((size_t)per_img * n);
+        float* o = c.arena.get<float>((size_t)per_img * n);
+        ws.stats = c.arena.get<float>((size_t)n * 64);
+        ws.gn_ws = c.arena.alloc(groupnorm_ws_bytes(n, R * R));
+        ws.q = c.arena.get<float>((size_t)n * attn_hw * max_c);
+        ws.k = c.arena.get<float>((size_t)n * attn_hw * max_c);
+        ws.vT = c.arena.get<float>((size_t)n * attn_hw * max_c);
+        ws.S = c.arena.get<float>((size_t)n * attn_hw * attn_hw);
+        const long lrows = (long)n * lat * lat;
+        float* dots = c.arena.get<float>((size_t)lrows * g.vq_n_embed);
+        float* zq = c.arena.get<float>((size_t)lrows * g.vq_embed_dim);
+        float* zz = c.arena.get<float>((size_t)lrows);
+
+        launch_nchw_to_nhwc_pad(x_nchw + (long)i0 * g.vq_in_channels * R * R, ws.t, n, R * R, g.vq_in_channels, c.enc_cin_pad, s);
+        Act x{ws.t, n, R, R, c.enc_cin_pad};
+        conv3(x, c.enc_conv_in, ws.a, nullptr, 0, s);
+        x = Act{ws.a, n, R, R, c.enc_conv_in.cout};
+        auto pick2 = [&](float*& scratch, float*& y) {
+            float* bufs[3] = {ws.a, ws.b, o};
+            scratch = nullptr; y = nullptr;
+            for (float* b : bufs) { if (b != x.p) { if (!scratch) scratch = b; else y = b; } }
+        };
+        auto res_step = [&](const ResBlockW& r) { float *sc, *y; pick2(sc, y); resblock(r, x, y, sc, ws, s); };
+        auto attn_step = [&](const AttnBlockW& ab) { float *sc, *y; pick2(sc, y); attnblock(ab, x, y, ws, s); };
+        for (int lvl = 0; lvl < g.vq_num_levels; ++lvl) {
+            const DownLevelW& d = c.down[lvl];
+            for (size_t b = 0; b < d.blocks.size(); ++b) {
+                res_step(d.blocks[b]);
+                if (!d.attns.empty()) attn_step(d.attns[b]);
+            }
+            if (d.has_down) {  // F.pad(x, (0,1,0,1)) + conv 3x3 stride 2 padding 0
+                float *sc, *y; pick2(sc, y);
+                GemmArgs ga;
+                ga.mode = MODE_CONV3;
+                ga.A = x.p; ga.B = d.down.w; ga.C = y; ga.bias_n = d.down.b;
+                ga.M = x.n * (x.h / 2) * (x.w / 2); ga.N = d.down.cout; ga.K = 9 * d.down.cin;
+                ga.lda = d.down.cin; ga.ldb = 9 * d.down.cin; ga.ldc = d.down.cout;
+                ga.conv_h = x.h / 2; ga.conv_w = x.w / 2; ga.conv_cin = d.down.cin; ga.conv_up = 0;
+                ga.conv_hin = x.h; ga.conv_win = x.w; ga.conv_stride = 2; ga.conv_pad = 0;
+                launch_gemm(ga, s);
+                x = Act{y, x.n, x.h / 2, x.w / 2, d.down.cout};
+            }
+        }
+        res_step(c.enc_mid1);
+        attn_step(c.enc_mid_attn);
+        res_step(c.enc_mid2);
+        gn(x, c.enc_norm_out_w, c.enc_norm_out_b, ws.t, 1, ws, s);
+        Act t{ws.t, x.n, x.h, x.w, x.c};
+        float *sc, *y; pick2(sc, y);
+        conv3(t, c.enc_conv_out, y, nullptr, 0, s);                     // [n, lat*lat, z_channels]
+        conv1(y, lrows, c.quant_conv, zq, nullptr, s);                  // quant_conv (1x1)
+        // distances to the codebook: (|z|^2 + |e|^2) - 2 z.e, arg-min (exact fp32 products: the codebook is never split)
+        launch_row_sqnorm(zq, zz, lrows, g.vq_embed_dim, s);
+        GemmArgs gd;
+        gd.A = zq; gd.B = c.codebook; gd.C = dots;
+        gd.M = (int)lrows; gd.N = g.vq_n_embed; gd.K = g.vq_embed_dim; gd.lda = g.vq_embed_dim; gd.ldb = g.vq_embed_dim; gd.ldc = g.vq_n_embed;
+        launch_gemm(gd, s);
+        launch_vq_argmin(dots, zz, c.codebook_sqnorm, ids + (long)i0 * lat * lat, lrows, g.vq_n_embed, s);
     }
 }
 

@@ -5,8 +5,8 @@
   VectorQuantizer2        stage1/quantize.py:213-329 (``quantize`` attribute; ``get_codebook_entry`` is the decode-side entry)
 
 Parameters carry the reference's ``state_dict`` names (encoder.*, decoder.*, quantize.embedding.weight, quant_conv.*, post_quant_conv.*).
-``decode`` runs the hand-written HIP decoder (bevgen_vq_decode / bevgen_vq_decode_latents).  ``encode`` (the step BEFORE the path,
-SURVEY.md section 8f-1) is not part of this library yet and raises.
+``decode`` runs the hand-written HIP decoder (bevgen_vq_decode / bevgen_vq_decode_latents); ``encode`` (the step BEFORE the path)
+runs the HIP encoder + arg-min quantizer (bevgen_vq_encode).
 """
 from __future__ import annotations
 
@@ -82,7 +82,7 @@ class VQModel(nn.Module):
                 raise RuntimeError("VQModel must live on a ROCm device before decode(); libbevgen_hip has no CPU path")
             ctx = Context(None, vq_ddconfig=self.ddconfig, vq_n_embed=self.n_embed, vq_embed_dim=self.embed_dim,
                           device=dev.index if dev.index is not None else torch.cuda.current_device())
-            sd = {k: v for k, v in self.state_dict().items() if not k.startswith("encoder.") and not k.startswith("quant_conv.")}
+            sd = {k: v for k, v in self.state_dict().items() if k != "colorize"}
             ctx.load_state_dict(sd, prefix="first_stage_model.")
             ctx.finalize()
             self._ctx = ctx
@@ -102,9 +102,18 @@ class VQModel(nn.Module):
     def decode_code(self, code_b):
         return self.decode_ids(code_b.reshape(code_b.shape[0], -1))
 
+    @torch.no_grad()
+    def encode_ids(self, x):
+        """Encoder -> quant_conv -> arg-min over the codebook: x [n, in_channels, R, R] -> ids [n, h*w]."""
+        return self.context().vq_encode(x)
+
+    @torch.no_grad()
     def encode(self, x, batch=None):
-        raise NotImplementedError("the VQGAN encoder / VectorQuantizer2.forward (the step before the sampling path, SURVEY.md 8f-1) is not in libbevgen_hip yet; "
-                                  "pass precomputed BEV token ids (batch['cond_ids'])")
+        """vqgan:84-116 (geometric_embedding=False) -> (quant [n, e, h, w], emb_loss=None, (None, None, indices [n*h*w]))."""
+        ids = self.encode_ids(x)
+        lat = self.ddconfig["resolution"] // 2 ** (len(self.ddconfig["ch_mult"]) - 1)
+        quant = self.quantize.get_codebook_entry(ids.reshape(-1), (x.shape[0], lat, lat, self.embed_dim))
+        return quant, None, (None, None, ids.reshape(-1))
 
     def forward(self, input, batch=None):
         raise NotImplementedError("stage-1 training/reconstruction forward is outside the stage-2 sampling path")

@@ -7,8 +7,8 @@ What runs where:
   * sample()          -> MaskGit.generate inside libbevgen_hip (HIP kernels)
   * decode_to_img()   -> fused codebook lookup + VQGAN decoder + denormalise inside libbevgen_hip
   * 'gt'              -> util.denormalize_tensor of the input images (one fused elementwise expression; no model arithmetic)
-  * encode_to_c / encode_to_z (VQGAN *encoders*, the step before the path - SURVEY.md 8f-1) are not in the library yet:
-    ``batch['cond_ids']`` [B, K] (BEV token ids) must be supplied, and 'rec' is returned as None unless ``batch['z_ids']`` is given.
+  * encode_to_c / encode_to_z -> HIP VQGAN encoder + arg-min quantizer (bevgen_vq_encode); precomputed ``batch['cond_ids']`` /
+    ``batch['z_ids']`` short-circuit them.
 """
 from __future__ import annotations
 
@@ -86,9 +86,11 @@ class Net2NetTransformer(_Base):
         """muse_lm:120-140 -> ids [(B*C), h, w]."""
         init_ids = None
         if partial_decoding_idx is not None:
-            if "z_ids" not in batch:
-                raise NotImplementedError("partial decoding needs the ground-truth image tokens; supply batch['z_ids'] [B, C, T] (the VQGAN encoder is not in libbevgen_hip yet)")
-            z = batch["z_ids"].to(cond.device)
+            if "z_ids" in batch:
+                z = batch["z_ids"].to(cond.device)
+            else:
+                _, z = self.encode_to_z(self.get_input(self.first_stage_key, batch).to(cond.device), batch)
+                z = z.reshape(cond.shape[0], self.cfg.num_cams, -1)
             init_ids = torch.full_like(z, self.maskgit.mask_id)
             init_ids[:, partial_decoding_idx, :] = z[:, partial_decoding_idx]
             init_ids = init_ids.reshape(-1, z.shape[-1])
@@ -101,10 +103,19 @@ class Net2NetTransformer(_Base):
         """muse_lm:157-164 (+ denormalize_tensor when asked): ids [(B*C), T or h,w] -> [(B*C), 3, H, W]."""
         return self.first_stage_model.decode_ids(index.reshape(index.shape[0], -1), denormalize=denormalize)
 
+    @torch.no_grad()
     def encode_to_c(self, c, batch):
+        """muse_lm:149-155: BEV segmentation [B, S, 256, 256] -> condition token ids [B, K] (precomputed batch['cond_ids'] short-circuits)."""
         if "cond_ids" in batch:
             return None, batch["cond_ids"]
-        return self.cond_stage_model.encode(c, batch)
+        quant_c, _, info = self.cond_stage_model.encode(c, batch)
+        return quant_c, info[2].view(c.shape[0], -1)
+
+    @torch.no_grad()
+    def encode_to_z(self, x, batch):
+        """muse_lm:142-147: images [(B*C), 3, H, W] -> z ids [(B*C), T]."""
+        quant_z, _, info = self.first_stage_model.encode(x, batch)
+        return quant_z, info[2].view(x.shape[0], -1)
 
     def get_input(self, key, batch):
         x = batch[key]
@@ -139,13 +150,18 @@ class Net2NetTransformer(_Base):
         index_sample = self.sample(c_indices, batch, partial_decoding_idx=partial_idx, noise=noise)
         assert index_sample.max() < self.cfg.vocab_size
         gen = self.expand_all_images(self.decode_to_img(index_sample, denormalize=True))
-        rec = None
+        rec, gt = None, None
+        x_img = self.get_input(self.first_stage_key, batch).to(dev) if self.first_stage_key in batch else None
         if "z_ids" in batch:
             z = batch["z_ids"].to(dev).reshape(B * self.cfg.num_cams, -1)
+        elif x_img is not None:
+            _, z = self.encode_to_z(x_img, batch)           # reconstruction path of the reference (muse_lm:240-250)
+        else:
+            z = None
+        if z is not None:
             rec = self.expand_all_images(self.decode_to_img(z, denormalize=True))
-        gt = None
-        if self.first_stage_key in batch:
-            gt = self.expand_all_images(denormalize_tensor(self.get_input(self.first_stage_key, batch).to(dev)))
+        if x_img is not None:
+            gt = self.expand_all_images(denormalize_tensor(x_img))
         log.info("Generating images took %.3f s", time.time() - start)
         return {"gen": gen, "rec": rec, "gt": gt}
 

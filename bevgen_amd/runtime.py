@@ -81,6 +81,7 @@ class Context:
                 c.vq_ch_mult[i] = m
             attn = list(dd["attn_resolutions"])
             c.vq_attn_resolution = attn[0] if attn else 0
+            c.vq_in_channels = dd.get("in_channels", 0)
         self._c = c
         self.route = route
         h = C.c_void_p()
@@ -239,6 +240,17 @@ class Context:
         out = torch.empty((n, dd["out_ch"], R, R), dtype=torch.float32, device=self.device)
         self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids.reshape(n, -1)), n, int(bool(denormalize)), _ptr(out), _stream()))
         return out
+
+    def vq_encode(self, x):
+        """VQModel.encode -> token ids: x [n, in_channels, R, R] fp32 (NCHW) -> ids [n, h*w] int64."""
+        dd = self.vq_ddconfig
+        x = _req(x, torch.float32, self.device, "x")
+        n = x.shape[0]
+        lat = dd["resolution"] // 2 ** (len(dd["ch_mult"]) - 1)
+        assert tuple(x.shape[1:]) == (dd["in_channels"], dd["resolution"], dd["resolution"]), x.shape
+        ids = torch.empty((n, lat * lat), dtype=torch.int64, device=self.device)
+        self._check(self.lib.bevgen_vq_encode(self._h, _ptr(x), n, _ptr(ids), _stream()))
+        return ids
 
     def vq_decode_latents(self, zq, denormalize=False):
         """VQModel.decode(quant): zq [n, embed_dim, h, w] fp32."""

@@ -63,7 +63,8 @@ typedef struct bevgen_cfg {
     int32_t vq_num_levels;
     int32_t vq_ch_mult[8];
     int32_t vq_attn_resolution;                        /* spatial size at which AttnBlocks are inserted (16) */
-    int32_t reserved[16];
+    int32_t vq_in_channels;                            /* encoder input channels (3 images / 7 Argoverse BEV classes); 0 = decoder only */
+    int32_t reserved[15];
 } bevgen_cfg;
 
 typedef struct bevgen_ctx bevgen_ctx;
@@ -156,6 +157,11 @@ int bevgen_ar_sample(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_
  * post_quant_conv + Decoder (stage1/vqgan.py:118-121, stage1/model.py:506-537) [-> util.denormalize_tensor,
  * bev_utils/util.py:97-118 when denormalize != 0].   d_ids [n, h*w] -> d_out [n, out_ch, H, W] fp32. */
 int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* d_ids, int n, int denormalize, float* d_out, void* stream);
+
+/* VQModel.encode (stage1/vqgan.py:84-116 with geometric_embedding=False): Encoder (stage1/model.py:405-433) -> quant_conv ->
+ * VectorQuantizer2.forward arg-min (stage1/quantize.py:271-312).  d_x [n, in_channels, R, R] fp32 (NCHW, as get_input produces it,
+ * muse_lm:166-179) -> d_ids [n, h*w] int64.  This is encode_to_c (BEV segmentation -> condition tokens) and encode_to_z (muse_lm:142-155). */
+int bevgen_vq_encode(bevgen_ctx* ctx, const float* d_x, int n, int64_t* d_ids, void* stream);
 
 /* VQModel.decode(quant) (stage1/vqgan.py:118-121) for already looked-up latents: d_zq [n, embed_dim, h, w] (NCHW, like the reference). */
 int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* d_zq, int n, int denormalize, float* d_out, void* stream);

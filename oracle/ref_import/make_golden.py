@@ -177,7 +177,30 @@ def golden_vq():
     xo = R.vq_decode_ids(sd, dd, ids, (lat, lat), denorm=False)
     assert rel(xo, xr) < 1e-5, rel(xo, xr)
     assert (R.denormalize(xo) - xd).abs().max() < 1e-5
-    save("vq_tiny", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd)
+    # encode side (VQModel.encode -> VectorQuantizer2.forward arg-min), image model and the 7-channel BEV segmentation model
+    enc = {}
+    for tag, vv, model in (("img", v, vq), ("seg", cases.VQ_TINY_SEG, None)):
+        ddv = vv["dd"]
+        sdv = cases.vq_state_dict(ddv, vv["n_embed"], vv["embed_dim"], vv["seed"], with_encoder=True)
+        if model is None:
+            ns = stubs.import_reference()
+            from multi_view_generation.modules.losses.vqperceptual import DummyLoss
+            model = ns.vqgan.VQSegmentationModel(n_labels=ddv["in_channels"], ddconfig=dict(ddv), lossconfig=DummyLoss(), n_embed=vv["n_embed"], embed_dim=vv["embed_dim"],
+                                                 cam_res=(ddv["resolution"],) * 2, cam_latent_res=(lat, lat), cam_emd_dim=vv["embed_dim"])
+            sdl = dict(sdv); sdl["colorize"] = model.state_dict()["colorize"]
+            model.load_state_dict(sdl, strict=True)
+            model.eval()
+        gx = torch.Generator().manual_seed(17)
+        xin = torch.randn(vv["n_images"], ddv["in_channels"], ddv["resolution"], ddv["resolution"], generator=gx)
+        with torch.no_grad():
+            _, _, info = model.encode(xin, None)
+        ids_ref = info[2].view(vv["n_images"], -1)
+        ids_or, dist = R.vq_encode_ids(sdv, ddv, xin, return_distances=True)
+        assert torch.equal(ids_ref, ids_or), "oracle encode ids != reference"
+        top2 = dist.topk(2, dim=1, largest=False).values
+        enc.update({f"enc_{tag}_x": xin, f"enc_{tag}_ids": ids_ref.to(torch.int16), f"enc_{tag}_min_margin": np.array(float((top2[:, 1] - top2[:, 0]).min())),
+                    f"enc_{tag}_dist_scale": np.array(float(dist.abs().mean()))})
+    save("vq_tiny", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd, **enc)
 
 
 def golden_keys():

@@ -518,3 +518,37 @@ def vq_decode_ids(sd, dd: Mapping, ids: Tensor, latent_hw: Tuple[int, int], pref
     q = F.conv2d(zq, sd[prefix + "post_quant_conv.weight"], sd[prefix + "post_quant_conv.bias"])
     x = vq_decoder(sd, dd, q, prefix + "decoder.")
     return denormalize(x) if denorm else x
+
+
+# ================================================================================================
+# stage-1 VQGAN encode (the step before the path) - modules/stage1/{model,vqgan,quantize}.py
+# ================================================================================================
+def vq_encoder(sd, dd: Mapping, x: Tensor, prefix: str = "encoder.") -> Tensor:
+    """Encoder.forward (s1model:405-433); Downsample = F.pad(x,(0,1,0,1)) + conv3x3 stride 2 (s1model:68-72)."""
+    nres = len(dd["ch_mult"])
+    h = F.conv2d(x, sd[prefix + "conv_in.weight"], sd[prefix + "conv_in.bias"], padding=1)
+    for lvl in range(nres):
+        for b in range(dd["num_res_blocks"]):
+            h = _resnet(sd, f"{prefix}down.{lvl}.block.{b}.", h)
+            if f"{prefix}down.{lvl}.attn.{b}.norm.weight" in sd:
+                h = _attn_block(sd, f"{prefix}down.{lvl}.attn.{b}.", h)
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[f"{prefix}down.{lvl}.downsample.conv.weight"], sd[f"{prefix}down.{lvl}.downsample.conv.bias"], stride=2)
+    h = _resnet(sd, prefix + "mid.block_1.", h)
+    h = _attn_block(sd, prefix + "mid.attn_1.", h)
+    h = _resnet(sd, prefix + "mid.block_2.", h)
+    h = _gn_swish(h, sd[prefix + "norm_out.weight"], sd[prefix + "norm_out.bias"])
+    return F.conv2d(h, sd[prefix + "conv_out.weight"], sd[prefix + "conv_out.bias"], padding=1)
+
+
+def vq_encode_ids(sd, dd: Mapping, x: Tensor, prefix: str = "", return_distances: bool = False):
+    """VQModel.encode (vqgan:84-116, geometric_embedding=False) -> VectorQuantizer2.forward arg-min (quant:271-285): ids [n, h*w]."""
+    h = vq_encoder(sd, dd, x, prefix + "encoder.")
+    h = F.conv2d(h, sd[prefix + "quant_conv.weight"], sd[prefix + "quant_conv.bias"])
+    z = h.permute(0, 2, 3, 1).contiguous()
+    zf = z.view(-1, z.shape[-1])
+    E = sd[prefix + "quantize.embedding.weight"]
+    d = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(E ** 2, dim=1) - 2 * torch.einsum("bd,dn->bn", zf, E.t())
+    ids = torch.argmin(d, dim=1).view(x.shape[0], -1)
+    return (ids, d) if return_distances else ids
