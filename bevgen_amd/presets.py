@@ -82,9 +82,9 @@ def config4() -> GPTConfig:
     return route_a(6)
 
 
-def tiny_route_m(num_cams: int = 3, legacy: bool = True, latent=(4, 4)) -> GPTConfig:
+def tiny_route_m(num_cams: int = 3, legacy: bool = True, latent=(4, 4), bev=(4, 4)) -> GPTConfig:
     return route_m(num_cams, num_layers=2, dim=128, heads=2, vocab=64, cam_res=(64, 64), cam_latent_res=latent,
-                   bev_latent_res=(4, 4), legacy_prob_matrix=legacy)
+                   bev_latent_res=bev, legacy_prob_matrix=legacy)
 
 
 def tiny_route_a(num_cams: int = 3, block: int = 16) -> GPTConfig:

@@ -86,3 +86,47 @@ def test_sparse_self_attention_module_fp16_like_deepspeed():
     assert (out.float().cpu() - ref).abs().max() < 2e-3  # fp16 output rounding
     with pytest.raises(ValueError, match="dividable"):
         attn.get_layout(L + 1)
+
+
+def test_net2net_fully_native_forward_from_raw_batch():
+    """forward(batch) with the reference's raw batch keys only (image, segmentation, camera matrices): BEV segmentation -> HIP encoder -> cond ids ->
+    MaskGit -> HIP decoder, plus 'rec' through encode_to_z/decode and 'gt' - every stage checked against the oracle."""
+    from bevgen_amd.modules.stage1.vqgan import VQModel, VQSegmentationModel
+    from bevgen_amd.modules.stage2.cond_transformer_multi_view_muse import Net2NetTransformer
+    from bevgen_amd.modules.stage2.muse_maskgit_pytorch import MaskGit, MaskGitTransformerMultiView
+    from oracle import cases
+
+    cfg = presets.tiny_route_m(3, legacy=False, latent=(8, 8), bev=(8, 8))
+    dd, dds = cases.VQ_TINY["dd"], cases.VQ_TINY_SEG["dd"]
+    tr = MaskGitTransformerMultiView(num_tokens=cfg.vocab_size, dim=cfg.num_embed, seq_len=cfg.cam_latent_res, depth=cfg.num_layers, dim_head=64,
+                                     heads=cfg.num_heads, ff_mult=4, cfg=cfg)
+    mg = MaskGit(image_size=cfg.cam_latent_res, transformer=tr, self_token_critic=True, cond_drop_prob=0.1)
+    vq = VQModel(ddconfig=dd, n_embed=64, embed_dim=64, cam_res=(64, 64), cam_latent_res=(8, 8), cam_emd_dim=64)
+    vqc = VQSegmentationModel(n_labels=7, ddconfig=dds, n_embed=64, embed_dim=64, cam_res=(64, 64), cam_latent_res=(8, 8), cam_emd_dim=64, image_key="segmentation")
+    model = Net2NetTransformer(mg, vq, vqc, cfg, sample_iterations=4)
+    sd_m = W.maskgit_state_dict(cfg, 1234)
+    sd_v = W.vq_state_dict(dd, 64, 64, 99, with_encoder=True)
+    sd_c = W.vq_state_dict(dds, 64, 64, 77, with_encoder=True)
+    full = {("maskgit." + k): v for k, v in sd_m.items()}
+    full.update({("first_stage_model." + k): v for k, v in sd_v.items()})
+    full.update({("cond_stage_model." + k): v for k, v in sd_c.items()})
+    missing, unexpected = model.load_state_dict(full, strict=False)
+    assert not unexpected and missing == ["cond_stage_model.colorize"], (missing, unexpected)
+    model = model.to("cuda")
+    B = 2
+    bt = synthetic.make_batch(cfg, B, seed=8)
+    g = torch.Generator().manual_seed(5)
+    batch = {"image": torch.randn(B, cfg.num_cams, 64, 64, 3, generator=g), "segmentation": torch.randn(B, 64, 64, 7, generator=g),
+             "intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
+    out = model.log_images(batch, noise="greedy")
+    # oracle chain
+    seg = batch["segmentation"].movedim(-1, -3)
+    c_ids = R.vq_encode_ids(sd_c, dds, seg)
+    ids = R.maskgit_generate(sd_m, cfg, c_ids, bt["intrinsics_inv"], bt["extrinsics_inv"], depth=cfg.num_layers, heads=cfg.num_heads, timesteps=4)
+    gen_ref = R.vq_decode_ids(sd_v, dd, ids.reshape(B * cfg.num_cams, -1), (8, 8), denorm=True).reshape(B, cfg.num_cams, 3, 64, 64)
+    img = batch["image"].movedim(-1, -3).reshape(B * cfg.num_cams, 3, 64, 64)
+    z_ids = R.vq_encode_ids(sd_v, dd, img)
+    rec_ref = R.vq_decode_ids(sd_v, dd, z_ids, (8, 8), denorm=True).reshape(B, cfg.num_cams, 3, 64, 64)
+    assert (out["gen"].cpu() - gen_ref).abs().max() < 1e-3
+    assert (out["rec"].cpu() - rec_ref).abs().max() < 1e-3
+    assert (out["gt"].cpu() - R.denormalize(img).reshape(B, cfg.num_cams, 3, 64, 64)).abs().max() < 1e-6
