@@ -188,15 +188,20 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float*
         g.A = a; g.B = w; g.C = c; g.R = residual; g.bias_n = bias;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
         g.act = act_gelu ? ACT_GELU : ACT_NONE;
-        if (skinny == 2) {  // split-precision path with an on-the-fly split of W (tests / roofline probes)
-            ctx->arena.reserve((size_t)N * K * 4 + 1024);
+        if (skinny == 3 || skinny == 2) {  // split-precision paths with on-the-fly operand splits (tests / roofline probes): 3 = LDS-DMA kernel
+            ctx->arena.reserve(((size_t)N * K + (size_t)M * K) * 4 + 4096);
             ctx->arena.reset();
-            void* hi = ctx->arena.alloc((size_t)N * K * 2);
-            void* lo = ctx->arena.alloc((size_t)N * K * 2);
-            launch_split_weight(w, hi, lo, (long)N * K, (hipStream_t)stream);
-            g.B_hi = reinterpret_cast<const uint16_t*>(hi);
-            g.B_lo = reinterpret_cast<const uint16_t*>(lo);
-            launch_gemm_split(g, (hipStream_t)stream);
+            uint16_t* bp = reinterpret_cast<uint16_t*>(ctx->arena.alloc((size_t)N * K * 4));
+            launch_split_weight(w, bp, (long)N * K, (hipStream_t)stream);
+            g.B_hi = bp; g.B_lo = bp + 32;
+            if (skinny == 3) {
+                uint16_t* ap = reinterpret_cast<uint16_t*>(ctx->arena.alloc((size_t)M * K * 4));
+                launch_split_weight(a, ap, (long)M * K, (hipStream_t)stream);
+                g.A_hi = ap; g.A_lo = ap + 32;
+                launch_gemm_split_glds(g, (hipStream_t)stream);
+            } else {
+                launch_gemm_split(g, (hipStream_t)stream);
+            }
         } else if (skinny) launch_gemm_skinny(g, (hipStream_t)stream);
         else launch_gemm(g, (hipStream_t)stream);
     });

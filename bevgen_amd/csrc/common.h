@@ -55,6 +55,43 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
     tx = logical - ty * gx;
 }
 
+// Same, but the contiguous id range of an XCD walks bands of R row-tiles column by column, so that the ~32 workgroups resident on one XCD form
+// an (R x 32/R) patch of the output: the patch's R A-panels and 32/R B-panels are each fetched once per k-slice and shared through that L2
+// (R = 4 with 256x128 tiles = 1024 + 1024 operand rows per patch, the minimum for 32 tiles), and the A band stays warm while B streams past.
+__device__ __forceinline__ void xcd_tile_banded(int gx, int gy, int R, int& tx, int& ty) {
+    int lx, ly;
+    xcd_tile(gx, gy, lx, ly);
+    const int logical = ly * gx + lx;
+    const int band = logical / (R * gx);
+    const int within = logical - band * (R * gx);
+    const int h = min(R, gy - band * R);
+    tx = within / h;
+    ty = band * R + (within - tx * h);
+}
+
+// -------- split precision: v = hi + lo * 2^-11 with hi, lo in f16 (gemm_split.hip); interleaved plane layout [row][k/32][hi 32 | lo 32]
+__device__ __forceinline__ _Float16 split_hi(float v) { return (_Float16)v; }
+__device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) { return (_Float16)((v - (float)hi) * 2048.f); }
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+// store 4 (2) consecutive elements starting at column `col` (a multiple of 4 (2)) of one plane row
+__device__ __forceinline__ void store_planes4(_Float16* row, int col, float4 v) {
+    half4_t h, l;
+    h[0] = split_hi(v.x); h[1] = split_hi(v.y); h[2] = split_hi(v.z); h[3] = split_hi(v.w);
+    l[0] = split_lo(v.x, h[0]); l[1] = split_lo(v.y, h[1]); l[2] = split_lo(v.z, h[2]); l[3] = split_lo(v.w, h[3]);
+    _Float16* p = row + (col >> 5) * 64 + (col & 31);
+    *reinterpret_cast<half4_t*>(p) = h;
+    *reinterpret_cast<half4_t*>(p + 32) = l;
+}
+__device__ __forceinline__ void store_planes2(_Float16* row, int col, float2 v) {
+    half2_t h, l;
+    h[0] = split_hi(v.x); h[1] = split_hi(v.y);
+    l[0] = split_lo(v.x, h[0]); l[1] = split_lo(v.y, h[1]);
+    _Float16* p = row + (col >> 5) * 64 + (col & 31);
+    *reinterpret_cast<half2_t*>(p) = h;
+    *reinterpret_cast<half2_t*>(p + 32) = l;
+}
+
 constexpr float kNegBig = -1.0e30f;  // "minus infinity" that never produces inf-inf NaNs in online softmax
 
 // -------- wave-level helpers (wave = 64 lanes) --------

@@ -31,10 +31,9 @@ void Arena::release() {
 // ------------------------------------------------------------------------------------------------ ctx
 void Ctx::split_weight(const float* w, long n) {
     if (cfg.precision != BEVGEN_PRECISION_F16X3 || split.count(w)) return;
-    void* hi = own((size_t)n * 2);
-    void* lo = own((size_t)n * 2);
-    launch_split_weight(w, hi, lo, n, 0);
-    split[w] = SplitPlanes{reinterpret_cast<const uint16_t*>(hi), reinterpret_cast<const uint16_t*>(lo)};
+    void* planes = own((size_t)n * 4);
+    launch_split_weight(w, planes, n, 0);
+    split[w] = SplitPlanes{reinterpret_cast<const uint16_t*>(planes), reinterpret_cast<const uint16_t*>(planes) + 32};
 }
 
 void Ctx::retire_graph(hipGraphExec_t e, hipGraph_t g) {

@@ -196,16 +196,18 @@ void split_registry_set(const void* table) { g_split_table = reinterpret_cast<co
 
 void launch_gemm(const GemmArgs& g_in, hipStream_t stream) {
     const GemmArgs g = conv_defaults(g_in);
-    if (g.B_hi) return launch_gemm_split(g, stream);
+    if (g.B_hi) return g.A_hi ? launch_gemm_split_glds(g, stream) : launch_gemm_split(g, stream);
     if (g_split_table && g.strideB == 0) {  // the executing context runs in split-precision mode and B is one of its (pre-split) weights
         auto it = g_split_table->find(g.B);
         if (it != g_split_table->end()) {
             GemmArgs s = g;
             s.B_hi = it->second.hi;
             s.B_lo = it->second.lo;
+            if (s.A_hi) return launch_gemm_split_glds(s, stream);
             return launch_gemm_split(s, stream);
         }
     }
+    BG_REQUIRE(g.A != nullptr, "gemm: A was given as split planes but B has no split planes (weight not registered for the split-precision path)");
     BG_REQUIRE(g.K % BK == 0, "gemm: K=%d must be a multiple of %d (pad the operands)", g.K, BK);
     BG_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: lda/ldb must be multiples of 4 floats");
     BG_REQUIRE(g.M > 0 && g.N > 0 && g.batch > 0, "gemm: empty problem");

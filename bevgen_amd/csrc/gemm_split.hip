@@ -80,7 +80,7 @@ __device__ __forceinline__ void load_b(const GemmArgs& g, int n0, int k0, int ti
         const int n = n0 + row;
         uint4 h = make_uint4(0, 0, 0, 0), l = h;
         if (n < g.N) {
-            const long off = (long)n * g.ldb + k0 + c8 * 8;
+            const long off = ((long)n * g.ldb + k0) * 2 + c8 * 8;   // interleaved planes: (row, 32-k block) = 64 halves, lo = hi + 32
             h = *reinterpret_cast<const uint4*>(g.B_hi + off);
             l = *reinterpret_cast<const uint4*>(g.B_lo + off);
         }
@@ -255,19 +255,23 @@ void launch_gemm_split(const GemmArgs& g_in, hipStream_t stream) {
     LAUNCH_CHECK();
 }
 
-// one-time split of an fp32 weight matrix into its (hi, lo) f16 planes
-__global__ void split_weight_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo, long n) {
+// Split of an fp32 matrix (row length a multiple of 32) into the INTERLEAVED plane layout every split-precision kernel reads:
+//     planes[row][k/32][0][k%32] = hi,  planes[row][k/32][1][k%32] = lo          (2 halves per element, 128 bytes per (row, 32-k block))
+// so that the 32 hi and 32 lo values of one k-block share one 128-byte line: the LDS-DMA GEMM moves whole lines (a 64-byte half-line
+// request still costs a full line of L2->L1 bandwidth, measured) and a row needs one DMA piece instead of two.
+__global__ void split_weight_kernel(const float* __restrict__ w, _Float16* __restrict__ planes, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = w[i];
         const _Float16 h = (_Float16)v;
-        hi[i] = h;
-        lo[i] = (_Float16)((v - (float)h) * kLoScale);
+        const long o = (i >> 5) * 64 + (i & 31);
+        planes[o] = h;
+        planes[o + 32] = (_Float16)((v - (float)h) * kLoScale);
     }
 }
 
-void launch_split_weight(const float* w, void* hi, void* lo, long n, hipStream_t s) {
-    hipLaunchKernelGGL(split_weight_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(hi),
-                       reinterpret_cast<_Float16*>(lo), n);
+void launch_split_weight(const float* w, void* planes, long n, hipStream_t s) {
+    BG_REQUIRE(n % 32 == 0, "split_weight: element count %ld must be a multiple of 32", n);
+    hipLaunchKernelGGL(split_weight_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(planes), n);
     LAUNCH_CHECK();
 }
 

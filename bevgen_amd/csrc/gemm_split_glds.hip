@@ -1,0 +1,375 @@
+// Split-precision GEMM, LDS-DMA variant: BOTH operands arrive as (hi, lo) f16 planes in HBM and are moved global -> LDS by
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write: on gfx950 a ds_write_b128 costs 13 cycles of the SIMD->LDS path and the
+// register-staged kernel in gemm_split.hip spends more LDS-pipe time writing tiles than the matrix pipe spends on the MFMAs).
+//
+//   C[M,N] = (Ah + Al 2^-11)(Bh + Bl 2^-11)^T  ~=  Ah Bh^T + 2^-11 (Ah Bl^T + Al Bh^T)          (see gemm_split.hip for the numerics)
+//
+// * Block tile (WM*64) x 128 x 32: WM*2 waves, each a 64x64 patch = (2x2) v_mfma_f32_32x32x16_f16 tiles with a main and a correction
+//   accumulator.  WM = 4 (256x128, 8 waves = two per SIMD, one block per CU) is the production shape.
+// * Operands live in HBM in the interleaved plane layout [row][k/32][hi 32 | lo 32] (gemm_split.hip): one (row, k-block) is one 128-byte
+//   line, so every DMA request is a whole line (with separate hi / lo planes each k-tile touched only half of every line it fetched and
+//   the L2->L1 fill traffic was twice the useful bytes - the measured limiter).
+// * LDS image: per stage WM*64 A rows and 128 B rows of 128 bytes, UNPADDED because an LDS-DMA instruction writes base + lane*16 linearly
+//   (1 KiB = 8 rows per wave-instruction).  Bank conflicts of the ds_read_b128 operand fetch are removed by an XOR swizzle of the 16-byte
+//   chunk index (0-3 hi, 4-7 lo) with bits 1-3 of the row, applied on the SOURCE address of the DMA and again on the read (the destination
+//   stays linear; MI355X guide rule 21); the 16-lane service groups of ds_read_b128 then cover all 64 banks exactly once.
+// * Three-stage ring, ONE s_barrier per k-tile, software pipelined so that the matrix pipe never waits for the LDS:
+//        top of k-tile t :  ds_read fragments F1 (k-step 1 of tile t)            | MFMAs on F0 (k-step 0, fetched during tile t-1)
+//        middle          :  lgkmcnt(0); vmcnt(tile t+1 landed); s_barrier        -- every wave is done READING tile t, tile t+1 is complete
+//        bottom          :  ds_read F0 of tile t+1; DMA of tile t+3 -> stage of t | MFMAs on F1, DMA pieces interleaved between MFMA groups
+//   so every ds_read is issued a full 12-MFMA phase before its use and every DMA two k-tiles before its use.
+// * MODE_CONV3: implicit-GEMM 3x3 convolution over NHWC planes; taps that fall into the zero padding are fetched from a zero page.
+#include "common.h"
+#include "kernels.h"
+#include "profiler.h"
+#include <vector>
+#include <cstdio>
+
+namespace bevgen {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int GBN = 128, GBK = 32;
+constexpr float kGLoInv = 1.f / 2048.f;
+
+__device__ __forceinline__ void glds16(const _Float16* src, _Float16* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int MODE, int WM>
+__global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_kernel(GemmArgs g) {
+    constexpr int TBM = WM * 64;                 // block rows
+    constexpr int NW = WM * 2;                   // waves
+    constexpr int NBJ = 16 / NW;                 // 8-row B pieces per wave
+    constexpr int AREGION = TBM * 2 * GBK;       // halves: TBM rows x (32 hi | 32 lo)
+    constexpr int STAGE_H = AREGION + GBN * 2 * GBK;  // halves per stage
+    constexpr int DMA = 4 + NBJ;                      // DMA wave-instructions per k-tile
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_g[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    int tx, ty;
+    if (g.tile_band > 0) xcd_tile_banded(gridDim.x, gridDim.y, g.tile_band, tx, ty);
+    else xcd_tile(gridDim.x, gridDim.y, tx, ty);
+    const int n0 = tx * GBN, m0 = ty * TBM;
+    const int n0l = g.diag ? 0 : n0, m0l = g.diag ? 0 : m0;   // diag: every block loads tile (0,0) -> all-L2-hit upper bound (results wrong)
+
+    const _Float16* Ap = reinterpret_cast<const _Float16*>(g.A_hi);   // interleaved planes: (row, 32-k block) = 64 halves = one 128-byte line
+    const _Float16* Bp = reinterpret_cast<const _Float16*>(g.B_hi);
+    const _Float16* Z = reinterpret_cast<const _Float16*>(g.zero_page);
+
+    // ---- DMA descriptors of this lane.  One DMA piece = 8 rows x 128 B (hi|lo of one k-block): lane -> row lane>>3, 16-byte position lane&7.
+    // The wave owns 32 A rows (4 pieces) and 128/NW B rows (NBJ pieces).  Rows outside the problem (and convolution taps inside the zero
+    // padding) read the zero page; their pointers simply do not advance.
+    const _Float16 *pa[4], *pb[NBJ];
+    int a_step[4], b_step[NBJ];
+    int a_img[4], a_y[4], a_x[4], a_chunk[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+        const int R = wave * (8 * NBJ) + j * 8 + (lane >> 3);   // B row inside the tile
+        const int c = (lane & 7) ^ ((R >> 1) & 7);               // logical 16-byte chunk (0-3 hi, 4-7 lo) that lives at physical position lane&7 of row R
+        const int n = n0l + R;
+        const bool bok = n < g.N;
+        pb[j] = bok ? Bp + (long)n * 2 * g.ldb + c * 8 : Z;
+        b_step[j] = bok ? 2 * GBK : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int R = wave * 32 + j * 8 + (lane >> 3);   // A row inside the tile
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        a_chunk[j] = c;
+        const int m = m0l + R;
+        a_ok[j] = m < g.M;
+        if (MODE == MODE_PLAIN) {
+            pa[j] = a_ok[j] ? Ap + (long)m * 2 * g.lda + c * 8 : Z;
+            a_step[j] = a_ok[j] ? 2 * GBK : 0;
+            a_img[j] = a_y[j] = a_x[j] = 0;
+        } else {
+            pa[j] = Z; a_step[j] = 0;
+            const int hw = g.conv_h * g.conv_w;
+            const int img = m / hw, rem = m - img * hw;
+            a_img[j] = img; a_y[j] = rem / g.conv_w; a_x[j] = rem - a_y[j] * g.conv_w;
+        }
+    }
+    // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order, so the pointers just advance)
+    int k_issue = 0;
+    auto issue_a = [&](int stage, int j) {
+        _Float16* sa = smem_g + stage * STAGE_H + (wave * 32 + j * 8) * 2 * GBK;
+        if (MODE == MODE_CONV3) {
+            const int tap = k_issue / g.conv_cin;
+            const int c0 = k_issue - tap * g.conv_cin;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            int yy = a_y[j] * g.conv_stride + kh - g.conv_pad, xx = a_x[j] * g.conv_stride + kw - g.conv_pad;
+            const int lim_h = g.conv_up ? 2 * g.conv_hin : g.conv_hin, lim_w = g.conv_up ? 2 * g.conv_win : g.conv_win;
+            const bool ok = a_ok[j] && yy >= 0 && yy < lim_h && xx >= 0 && xx < lim_w;
+            if (g.conv_up) { yy >>= 1; xx >>= 1; }
+            const long ao = ((((long)a_img[j] * g.conv_hin + yy) * g.conv_win + xx) * g.conv_cin + c0) * 2 + a_chunk[j] * 8;
+            pa[j] = ok ? Ap + ao : Z;
+        }
+        glds16(pa[j], sa);
+        pa[j] += a_step[j];
+    };
+    auto issue_b = [&](int stage) {   // last piece(s) of a tile: advances k_issue
+        _Float16* sb = smem_g + stage * STAGE_H + AREGION + wave * (8 * NBJ) * 2 * GBK;
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+            glds16(pb[j], sb + j * 8 * 2 * GBK);
+            pb[j] += b_step[j];
+        }
+        k_issue += GBK;
+    };
+
+    f32x16 accM[2][2], accC[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { accM[i][j][q] = 0.f; accC[i][j][q] = 0.f; }
+
+    // operand fetch addresses (halves) inside a stage: row*64 + swizzled chunk*8; the lo chunk (logical +4) sits at the hi address ^ 32 halves
+    int a_rd[2][2], b_rd[2][2];   // [tile i/j][k-step]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ra = wm * 64 + i * 32 + r, rb = wn * 64 + i * 32 + r;
+            a_rd[i][ks] = ra * 2 * GBK + (((ks * 2 + h) ^ ((ra >> 1) & 7)) << 3);
+            b_rd[i][ks] = AREGION + rb * 2 * GBK + (((ks * 2 + h) ^ ((rb >> 1) & 7)) << 3);
+        }
+    struct Frag { half8 ah[2], al[2], bh[2], bl[2]; };
+    auto fetch = [&](Frag& f, int stage, int ks) {
+        const _Float16* st = smem_g + stage * STAGE_H;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = *reinterpret_cast<const half8*>(st + a_rd[i][ks]);
+            f.al[i] = *reinterpret_cast<const half8*>(st + (a_rd[i][ks] ^ 32));
+            f.bh[i] = *reinterpret_cast<const half8*>(st + b_rd[i][ks]);
+            f.bl[i] = *reinterpret_cast<const half8*>(st + (b_rd[i][ks] ^ 32));
+        }
+    };
+    auto mma_main = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], accM[i][j], 0, 0, 0);
+    };
+    auto mma_c1 = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], accC[i][j], 0, 0, 0);
+    };
+    auto mma_c2 = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], accC[i][j], 0, 0, 0);
+    };
+
+    const int nk = g.K / GBK;
+    // ---- prologue: tiles 0..2 in flight, tile 0 landed, F0 of tile 0 on its way
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        if (s < nk) { issue_a(s, 0); issue_a(s, 1); issue_a(s, 2); issue_a(s, 3); issue_b(s); }
+    if (nk >= 3) wait_vmcnt<2 * DMA>();
+    else if (nk == 2) wait_vmcnt<DMA>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frag f0, f1;
+    fetch(f0, 0, 0);
+
+    const bool late = wave >= NW / 2;
+    int stage = 0;
+#ifdef BG_GLDS_TIMING
+    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+    unsigned long long* dbg = (unsigned long long*)g.bias_m;   // timing build only: bias_m carries the dump buffer
+    const bool rec = dbg && (blockIdx.x + blockIdx.y * gridDim.x) == 300 && lane == 0;
+#endif
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage_next = stage == 2 ? 0 : stage + 1;
+#ifdef BG_GLDS_TIMING
+        if (rec && kt > 0) { unsigned long long* o = dbg + ((long)wave * 128 + kt - 1) * 4; o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = t_d; }
+        t_a = __builtin_amdgcn_s_memtime();
+#endif
+        fetch(f1, stage, 1);
+        // DMA issue is staggered: a glds costs its wave ~70 issue cycles during which the MFMAs queued behind it cannot start.  The low half
+        // of the waves issues tile kt+3 in the F1 phase (below), the high half issues the same tile one phase later (here, as tile kt+2 of
+        // the next iteration), so of the two waves sharing a SIMD one always runs bare MFMAs.
+        const bool late_more = late && kt >= 1 && kt + 2 < nk;
+        const int stage_prev = stage == 0 ? 2 : stage - 1;
+        mma_main(f0);
+        if (late_more) { issue_a(stage_prev, 0); issue_a(stage_prev, 1); }
+        mma_c1(f0);
+        if (late_more) { issue_a(stage_prev, 2); issue_a(stage_prev, 3); }
+        mma_c2(f0);
+        if (late_more) issue_b(stage_prev);
+        // this wave is done reading tile kt; tile kt+1 must be complete (own pieces; tile kt+2 may stay in flight).  The scheduling fences keep
+        // the MFMAs of F0 above the waits (they are not memory operations, nothing else would stop them sinking below) and F1's below.
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef BG_GLDS_TIMING
+        t_b = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) wait_vmcnt<DMA>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef BG_GLDS_TIMING
+        t_c = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = !late && kt + 3 < nk;   // tile kt+3 goes into the stage tile kt just vacated
+        mma_main(f1);                    // F1 landed before the barrier: the matrix pipe restarts at once
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(f0, stage_next, 0);        // unconditional (after the last tile it reads a stale stage and is never used): keeps the wait counters exact
+        if (more) { issue_a(stage, 0); issue_a(stage, 1); }
+        mma_c1(f1);
+        if (more) { issue_a(stage, 2); issue_a(stage, 3); }
+        mma_c2(f1);
+        if (more) issue_b(stage);
+#ifdef BG_GLDS_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        t_d = __builtin_amdgcn_s_memtime();
+#endif
+        stage = stage_next;
+    }
+
+    // ---- epilogue.  The MFMAs were issued with the operands swapped (B fragment first), so the accumulators hold the TRANSPOSED 32x32
+    // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
+    // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
+    // store tail is instruction-issue bound, MI355X guide T21).
+    float* C = g.C;
+    const float* Rp = g.R;
+    const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                        (!Rp || (reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + r;
+        if (m >= g.M) continue;
+#ifndef BG_GLDS_TIMING
+        const float bm = g.bias_m ? g.bias_m[m] : 0.f;
+#else
+        const float bm = 0.f;
+#endif
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * qq + 4 * h;
+                if (n >= g.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = qq * 4 + e;
+                    float t = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha + bm;
+                    if (g.bias_n && n + e < g.N) t += g.bias_n[n + e];
+                    if (g.act == ACT_GELU) t = gelu_erf(t);
+                    v[e] = t;
+                }
+                float* cp = C + (long)m * g.ldc + n;
+                if (vec_ok && n + 3 < g.N) {
+                    if (Rp) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(Rp + (long)m * g.ldr + n);
+                        v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+                    }
+                    f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+                    *reinterpret_cast<f32x4*>(cp) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < g.N) cp[e] = v[e] + (Rp ? Rp[(long)m * g.ldr + n + e] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+static const void* g_zero_page = nullptr;
+
+void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
+    GemmArgs g = g_in;
+    if (g.mode == MODE_CONV3) {
+        if (g.conv_stride == 0) g.conv_stride = 1;
+        if (g.conv_pad < 0) g.conv_pad = 1;
+        if (g.conv_hin == 0) g.conv_hin = g.conv_up ? g.conv_h / 2 : g.conv_h;
+        if (g.conv_win == 0) g.conv_win = g.conv_up ? g.conv_w / 2 : g.conv_w;
+        BG_REQUIRE(g.conv_cin % GBK == 0 && g.K == 9 * g.conv_cin, "conv3x3: Cin=%d must be a multiple of 32", g.conv_cin);
+    }
+    BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
+    BG_REQUIRE(g.K % GBK == 0 && g.lda % GBK == 0 && g.ldb % GBK == 0, "gemm_split_glds: K, lda, ldb must be multiples of 32 (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
+    BG_REQUIRE(g.batch == 1, "gemm_split_glds: batched form not provided");
+    if (!g_zero_page) {
+        void* z = nullptr;
+        HIP_CHECK(hipMalloc(&z, 4096));
+        HIP_CHECK(hipMemset(z, 0, 4096));
+        g_zero_page = z;
+    }
+    g.zero_page = g_zero_page;
+    static int band = -1, diag = 0, force_wm = 0;
+    if (band < 0) {
+        const char* e = getenv("BEVGEN_GLDS_BAND");
+        band = e ? atoi(e) : 4;
+        diag = getenv("BEVGEN_GLDS_DIAG") ? 1 : 0;
+        const char* w = getenv("BEVGEN_GLDS_WM");
+        force_wm = w ? atoi(w) : 0;
+    }
+    g.tile_band = band; g.diag = diag;
+    // 256-row tiles unless the problem is too small to give every CU one of them
+    const int wm = force_wm ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
+    const int tbm = wm * 64;
+    dim3 grid(cdiv(g.N, GBN), cdiv(g.M, tbm), 1);
+    const size_t lds = (size_t)3 * (2 * tbm + 2 * GBN) * GBK * sizeof(_Float16);
+    static bool attr_set = false;
+    if (!attr_set) {
+#define BG_SET(K, BYTES) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2>), 3 * 4 * 128 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2>), 3 * 4 * 128 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4>), 3 * 6 * 128 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4>), 3 * 6 * 128 * GBK * 2);
+#undef BG_SET
+        attr_set = true;
+    }
+#ifdef BG_GLDS_TIMING
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) HIP_CHECK(hipMalloc(&dbg, 8 * 128 * 4 * 8));
+    HIP_CHECK(hipMemset(dbg, 0, 8 * 128 * 4 * 8));
+    g.bias_m = reinterpret_cast<const float*>(dbg);
+#endif
+    ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : PROF_GEMM, 2.0 * g.M * (double)g.N * g.K, stream);
+    const bool conv = g.mode == MODE_CONV3;
+    if (wm == 2) {
+        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2>), grid, dim3(256), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2>), grid, dim3(256), lds, stream, g);
+    } else {
+        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 4>), grid, dim3(512), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 4>), grid, dim3(512), lds, stream, g);
+    }
+    LAUNCH_CHECK();
+#ifdef BG_GLDS_TIMING
+    {
+        static int printed = 0;
+        HIP_CHECK(hipDeviceSynchronize());
+        if (printed++ < 2) {
+            std::vector<unsigned long long> hbuf(8 * 128 * 4);
+            HIP_CHECK(hipMemcpy(hbuf.data(), dbg, hbuf.size() * 8, hipMemcpyDeviceToHost));
+            for (int w = 0; w < (wm == 4 ? 8 : 4); ++w) {
+                fprintf(stderr, "[glds timing] wave %d (M=%d N=%d K=%d):", w, g.M, g.N, g.K);
+                for (int kt = 8; kt < 14; ++kt) {
+                    const unsigned long long* o = &hbuf[((size_t)w * 128 + kt) * 4];
+                    const unsigned long long* o2 = &hbuf[((size_t)w * 128 + kt + 1) * 4];
+                    fprintf(stderr, "  [mfmaF0 %llu | wait+bar %llu | F1 phase %llu | iter %llu]", o[1] - o[0], o[2] - o[1], o[3] - o[2], o2[0] - o[0]);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
+}
+
+}  // namespace bevgen

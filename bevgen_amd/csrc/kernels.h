@@ -28,16 +28,24 @@ struct GemmArgs {
     // general form: stored input is conv_hin x conv_win, tap coordinate = out * conv_stride + k - conv_pad (0 = derive the 'same' defaults:
     // stride 1, pad 1, hin/win = output size or half of it with conv_up).  Downsample (stage1/model.py:56-75): stride 2, pad 0, hin = 2*conv_h.
     int conv_hin = 0, conv_win = 0, conv_stride = 0, conv_pad = -1;
-    // split-precision path (gemm_split.hip): the (hi, lo) f16 planes of B, same [N, ldb] layout; null = exact fp32 MFMA path
+    // split-precision path (gemm_split.hip): the (hi, lo) f16 planes of B in the interleaved layout [N][ldb/32][2][32] (B_lo = B_hi + 32);
+    // null = exact fp32 MFMA path
     const uint16_t* B_hi = nullptr;
     const uint16_t* B_lo = nullptr;
+    // LDS-DMA path (gemm_split_glds.hip): A also arrives as interleaved (hi, lo) f16 planes ([M][lda/32][2][32] / NHWC pixels x channels),
+    // written by the producing kernel; A_lo = A_hi + 32
+    const uint16_t* A_hi = nullptr;
+    const uint16_t* A_lo = nullptr;
+    const void* zero_page = nullptr;  // filled in by the launcher
+    int tile_band = 0, diag = 0;      // tile-order band height (0 = row-major) / diagnostic all-L2-hit mode; filled in by the launcher
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
+void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);
 
 // Split-precision (3x f16 MFMA, fp32-class accuracy) variant and its weight preparation
 struct SplitPlanes { const uint16_t* hi; const uint16_t* lo; };
 void launch_gemm_split(const GemmArgs& g, hipStream_t stream);
-void launch_split_weight(const float* w, void* hi, void* lo, long n, hipStream_t s);
+void launch_split_weight(const float* w, void* planes /* 2n halves, interleaved (gemm_split.hip) */, long n, hipStream_t s);
 // Table of pre-split weights of the context whose call is executing (null = exact fp32 everywhere): launch_gemm consults it by B pointer.
 void split_registry_set(const void* table /* const std::unordered_map<const float*, SplitPlanes>* */);
 
@@ -52,6 +60,9 @@ void launch_gemm_skinny_ws(const GemmArgs& g, float* ws, hipStream_t stream);  /
 void launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int rows, int D, float eps, hipStream_t s);
 // GEGLU + LayerNorm (muse_net:71-88): h[row, 0:F] = a, h[row, F:2F] = gate -> y = LN(gate * gelu(a)) * gamma ; y row stride ldy (zero padded)
 void launch_geglu_layernorm(const float* h, int ldh, const float* gamma, float* y, int ldy, int rows, int F, float eps, hipStream_t s);
+// Same two, writing the interleaved (hi, lo) f16 plane image [row][ldy/32][2][32] that the LDS-DMA split-precision GEMM reads (ldy % 32 == 0)
+void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const float* beta, void* planes, int ldy, int rows, int D, float eps, hipStream_t s);
+void launch_geglu_layernorm_planes(const float* h, int ldh, const float* gamma, void* planes, int ldy, int rows, int F, float eps, hipStream_t s);
 // GroupNorm(32 groups, eps) statistics over NHWC [n, hw, C] -> stats[n*32*2] = (mean, rstd)
 size_t groupnorm_ws_bytes(int n, int hw);
 void launch_groupnorm_stats(const float* x, float* stats, void* ws /*groupnorm_ws_bytes*/, int n, int hw, int C, float eps, hipStream_t s);
@@ -84,6 +95,7 @@ struct AttnSplitArgs {
     int ldbias; long bias_head_stride;
     float scale;
     long o_bstride, o_qstride, o_hstride;
+    _Float16* Op;   // non-null: write the output as interleaved (hi, lo) planes of the [B*Nq, H*64] matrix instead of fp32 O
 };
 void launch_attention_split(const AttnSplitArgs& a, hipStream_t s);
 void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, hipStream_t s);

@@ -47,6 +47,16 @@ void gemm(const float* A, int lda, const float* W, int ldb, float* C, int ldc, i
     launch_gemm(g, s);
 }
 
+// same with A given as interleaved (hi, lo) f16 planes [M][lda/32][2][32] (split-precision mode: the producer kernel wrote them)
+void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s) {
+    GemmArgs g;
+    g.A_hi = reinterpret_cast<const uint16_t*>(Aplanes); g.A_lo = g.A_hi + 32;
+    g.B = W; g.C = C; g.R = R;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    launch_gemm(g, s);
+}
+
 // per-batch constants: embeddings + cross-attention K/V
 void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s) {
     const auto& g = c.cfg;
@@ -111,10 +121,17 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
     for (int i = 0; i < g.num_layers; ++i) {
         const MuseLayer& l = c.muse[i];
         // ---- self attention
-        launch_layernorm(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
-        gemm(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
-        gemm(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
+        // split-precision mode: every GEMM input is produced directly as (hi, lo) f16 planes (same bytes as the fp32 buffer they replace)
         const bool split = g.precision == BEVGEN_PRECISION_F16X3;
+        if (split) {
+            launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm_planes(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+            gemm_planes(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
+        } else {
+            launch_layernorm(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+            gemm(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
+        }
         const size_t qN = (size_t)rows * D, kvS = (size_t)B * H * c.NkS_pad * 64, kvC = (size_t)B * H * c.NkC_pad * 64;
         _Float16 *Qh = reinterpret_cast<_Float16*>(w.Q), *Ksh = reinterpret_cast<_Float16*>(w.Ks), *VTsh = reinterpret_cast<_Float16*>(w.Vs);
         AttnSplitArgs sa{};
@@ -125,6 +142,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             sa.bias = c.bias_self; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
             sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f;
             sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
+            sa.Op = reinterpret_cast<_Float16*>(w.att);
             launch_attention_split(sa, s);
         } else {
             launch_muse_q_prep(w.qraw, l.q_scale[0], w.Q, B, H, N, s);
@@ -138,10 +156,16 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         a.ldbias = c.ldS; a.bias_head_stride = 0; a.scale = 8.0f;
         a.o_bstride = (long)N * D; a.o_qstride = D; a.o_hstride = 64;
         if (!split) launch_attention(a, s);
-        gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);  // x = to_out(att) + x
+        if (split) gemm_planes(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);
+        else gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);  // x = to_out(att) + x
         // ---- cross attention
-        launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
-        gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+        if (split) {
+            launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm_planes(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+        } else {
+            launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+        }
         if (split) {
             launch_muse_q_prep_split(w.qraw, l.q_scale[1], Qh, Qh + qN, B, H, N, s);
             _Float16 *ckh = reinterpret_cast<_Float16*>(w.crossK[i]), *cvh = reinterpret_cast<_Float16*>(w.crossV[i]);
@@ -155,12 +179,20 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             a.ldbias = c.ldC;
             launch_attention(a, s);
         }
-        gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
         // ---- feed forward
-        launch_layernorm(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
-        gemm(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
-        launch_geglu_layernorm(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
-        gemm(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s);
+        if (split) {
+            gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
+            launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm_planes(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
+            launch_geglu_layernorm_planes(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+            gemm_planes(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s);
+        } else {
+            gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
+            launch_layernorm(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
+            launch_geglu_layernorm(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+            gemm(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s);
+        }
     }
     launch_layernorm(w.x, D, c.pf(p + "transformer_blocks.norm.gamma"), nullptr, w.xn, D, rows, D, 1e-5f, s);
 }

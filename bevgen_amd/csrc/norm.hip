@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // kernel above is pure load latency (19 us per call measured); this one is a single round trip.
 constexpr int LN_MAXV = 12;  // float4 per lane -> D <= 3072
 
+// PLANES: y is the interleaved (hi, lo) f16 plane image [row][ldy/32][2][32] read by the split-precision GEMM (gemm_split.hip) instead of fp32
+template <bool PLANES>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, int ldy, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
@@ -70,9 +72,11 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
             const float4 g = g4[i];
             float4 o = make_float4((v[j].x - mean) * rstd * g.x, (v[j].y - mean) * rstd * g.y, (v[j].z - mean) * rstd * g.z, (v[j].w - mean) * rstd * g.w);
             if (beta) { const float4 bb = b4[i]; o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
-            yr[i] = o;
+            if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 4, o);
+            else yr[i] = o;
         } else if (i < (ldy >> 2)) {
-            yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+            else yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
@@ -82,15 +86,25 @@ void launch_layernorm(const float* x, int ldx, const float* gamma, const float* 
     const bool vec = D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && D <= 256 * LN_MAXV && ldy <= 256 * LN_MAXV &&
                      (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0;
     if (vec)
-        hipLaunchKernelGGL(layernorm_vec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+        hipLaunchKernelGGL(layernorm_vec_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
     else
         hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    LAUNCH_CHECK();
+}
+
+void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const float* beta, void* planes, int ldy, int rows, int D, float eps, hipStream_t s) {
+    if (rows <= 0) return;
+    BG_REQUIRE(D % 4 == 0 && ldx % 4 == 0 && ldy % 32 == 0 && ldy <= 256 * LN_MAXV &&
+                   (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0,
+               "layernorm_planes: unsupported shape D=%d ldx=%d ldy=%d", D, ldx, ldy);
+    hipLaunchKernelGGL(layernorm_vec_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps);
     LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------ GEGLU + LayerNorm
 constexpr int GEGLU_MAX_PER_LANE = 48;  // F <= 3072
 
+template <bool PLANES>
 __global__ __launch_bounds__(256) void geglu_layernorm_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ gamma,
                                                               float* __restrict__ y, int ldy, int rows, int F, float eps) {
     const int lane = threadIdx.x & 63;
@@ -121,8 +135,16 @@ __global__ __launch_bounds__(256) void geglu_layernorm_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < GEGLU_MAX_PER_LANE; ++j) {
         const int i = lane + 64 * j;
-        if (i < F) yr[i] = (g[j] - mean) * rstd * gamma[i];
-        else if (i < ldy) yr[i] = 0.f;
+        if (i < ldy) {
+            const float o = i < F ? (g[j] - mean) * rstd * gamma[i] : 0.f;
+            if (PLANES) {
+                _Float16* p = reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy + (i >> 5) * 64 + (i & 31);
+                const _Float16 hi = split_hi(o);
+                p[0] = hi; p[32] = split_lo(o, hi);
+            } else {
+                yr[i] = o;
+            }
+        }
     }
 }
 
@@ -130,6 +152,7 @@ __global__ __launch_bounds__(256) void geglu_layernorm_kernel(const float* __res
 // together, half the load/store instructions of the scalar kernel.
 constexpr int GEGLU_MAX2 = 24;  // float2 per lane -> F <= 3072
 
+template <bool PLANES>
 __global__ __launch_bounds__(256) void geglu_layernorm_vec2_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ gamma, float* __restrict__ y,
                                                                    int ldy, int rows, int F, float eps) {
     const int lane = threadIdx.x & 63;
@@ -169,9 +192,12 @@ __global__ __launch_bounds__(256) void geglu_layernorm_vec2_kernel(const float* 
         const int i = lane + 64 * j;
         if (i < n2) {
             const float2 g = gam[i];
-            yr[i] = make_float2((av[j].x - mean) * rstd * g.x, (av[j].y - mean) * rstd * g.y);
+            const float2 o = make_float2((av[j].x - mean) * rstd * g.x, (av[j].y - mean) * rstd * g.y);
+            if (PLANES) store_planes2(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 2, o);
+            else yr[i] = o;
         } else if (i < (ldy >> 1)) {
-            yr[i] = make_float2(0.f, 0.f);
+            if (PLANES) store_planes2(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 2, make_float2(0.f, 0.f));
+            else yr[i] = make_float2(0.f, 0.f);
         }
     }
 }
@@ -182,9 +208,21 @@ void launch_geglu_layernorm(const float* h, int ldh, const float* gamma, float* 
     const bool vec = F % 2 == 0 && ldh % 2 == 0 && ldy % 2 == 0 && F <= 128 * GEGLU_MAX2 && ldy <= 128 * GEGLU_MAX2 &&
                      (reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma)) % 8 == 0;
     if (vec)
-        hipLaunchKernelGGL(geglu_layernorm_vec2_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps);
+        hipLaunchKernelGGL(geglu_layernorm_vec2_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps);
     else
-        hipLaunchKernelGGL(geglu_layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps);
+        hipLaunchKernelGGL(geglu_layernorm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps);
+    LAUNCH_CHECK();
+}
+
+void launch_geglu_layernorm_planes(const float* h, int ldh, const float* gamma, void* planes, int ldy, int rows, int F, float eps, hipStream_t s) {
+    if (rows <= 0) return;
+    BG_REQUIRE(ldy % 32 == 0 && F <= 64 * GEGLU_MAX_PER_LANE && ldy <= 64 * GEGLU_MAX_PER_LANE, "geglu_layernorm_planes: unsupported shape F=%d ldy=%d", F, ldy);
+    const bool vec = F % 2 == 0 && ldh % 2 == 0 && F <= 128 * GEGLU_MAX2 && ldy <= 128 * GEGLU_MAX2 &&
+                     (reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(gamma)) % 8 == 0;
+    if (vec)
+        hipLaunchKernelGGL(geglu_layernorm_vec2_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, reinterpret_cast<float*>(planes), ldy, rows, F, eps);
+    else
+        hipLaunchKernelGGL(geglu_layernorm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, reinterpret_cast<float*>(planes), ldy, rows, F, eps);
     LAUNCH_CHECK();
 }
 

@@ -164,8 +164,9 @@ def test_groupnorm(gpu_ctx, n, hw, C, swish):
     assert rel(out.cpu().permute(0, 3, 1, 2), ref) < 1e-5
 
 
+@pytest.mark.parametrize("mode", [2, 3])  # 2: register-staged kernel (fp32 A split on the fly), 3: LDS-DMA kernel (pre-split A planes)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 136, 64), (777, 1024, 1024), (300, 5460, 1024), (260, 1024, 2752)])
-def test_gemm_split_precision(gpu_ctx, M, N, K):
+def test_gemm_split_precision(gpu_ctx, M, N, K, mode):
     """3x f16 MFMA on (hi, lo*2^-11) splits: fp32-class accuracy (a handful of fp32 ulps beyond the exact fp32 path)."""
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g) * 3.0          # LayerNorm-like magnitudes
@@ -176,13 +177,14 @@ def test_gemm_split_precision(gpu_ctx, M, N, K):
     out = torch.empty(M, N, device="cuda")
     from bevgen_amd.runtime import _ptr, _stream
     da, dw, db, dr = dev(a), dev(w), dev(b), dev(r)  # keep the device tensors alive across the raw-pointer call
-    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), _ptr(db), _ptr(dr), _ptr(out), M, N, K, 1, 2, _stream()))
+    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), _ptr(db), _ptr(dr), _ptr(out), M, N, K, 1, mode, _stream()))
     err = rel(out.cpu().double(), ref)
     exact = rel(gpu_ctx.op_gemm(dev(a), dev(w), dev(b), dev(r), gelu=True).cpu().double(), ref)
     assert err < 2e-6, (err, exact)
 
 
-def test_gemm_split_precision_small_and_large_magnitudes(gpu_ctx):
+@pytest.mark.parametrize("mode", [2, 3])
+def test_gemm_split_precision_small_and_large_magnitudes(gpu_ctx, mode):
     g = torch.Generator().manual_seed(0)
     a = torch.randn(256, 256, generator=g)
     a[:, ::7] *= 1e-5     # tiny entries (f16-subnormal hi parts) must not lose the result
@@ -192,5 +194,5 @@ def test_gemm_split_precision_small_and_large_magnitudes(gpu_ctx):
     out = torch.empty(256, 128, device="cuda")
     from bevgen_amd.runtime import _ptr, _stream
     da, dw = dev(a), dev(w)
-    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), None, None, _ptr(out), 256, 128, 256, 0, 2, _stream()))
+    gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), None, None, _ptr(out), 256, 128, 256, 0, mode, _stream()))
     assert rel(out.cpu().double(), ref) < 2e-6

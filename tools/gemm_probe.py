@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""GEMM probe for PMC / timing: bench-sized Route M projections through bevgen_op_gemm.  usage: gemm_probe.py [mode: 0 fp32 | 2 split] [reps]"""
+"""GEMM probe for PMC / timing: bench-sized Route M projections through bevgen_op_gemm.  usage: gemm_probe.py [mode: 0 fp32 | 2 split | 3 split LDS-DMA] [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,14 +8,18 @@ from bevgen_amd.runtime import Context, _ptr, _stream
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ctx = Context(None)
-for (M, N, K) in [(24576, 1024, 1024), (24576, 5460, 1024), (24576, 1024, 2752)]:
+shapes = [(24576, 1024, 1024), (24576, 5460, 1024), (24576, 1024, 2752)]
+if len(sys.argv) > 3:   # extra shapes "M,N,K M,N,K ..."
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:]]
+for (M, N, K) in shapes:
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.03
     out = torch.empty(M, N, device="cuda")
     def run():
         ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(a), _ptr(w), None, None, _ptr(out), M, N, K, 0, mode, _stream()))
     run(); torch.cuda.synchronize()
-    t0 = time.time()
+    ctx.profile_begin()
     for _ in range(reps): run()
     torch.cuda.synchronize()
-    dt = (time.time() - t0) / reps
-    print(f"mode={mode} M={M} N={N} K={K}: {dt*1e6:.0f} us  {2*M*N*K/dt/1e12:.1f} TF (incl. on-the-fly weight split in mode 2)")
+    prof = ctx.profile_end()["gemm"]
+    dt = prof["ms"] * 1e-3 / prof["launches"]
+    print(f"mode={mode} M={M} N={N} K={K}: {dt*1e6:.0f} us  {2*M*N*K/dt/1e12:.1f} TF (GEMM kernel only, HIP events)")
