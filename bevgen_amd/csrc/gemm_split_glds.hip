@@ -22,6 +22,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "profiler.h"
+#include <type_traits>
 #include <vector>
 #include <cstdio>
 
@@ -35,11 +36,15 @@ constexpr float kGLoInv = 1.f / 2048.f;
 __device__ __forceinline__ void glds16(const _Float16* src, _Float16* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// buffer form: wave-uniform resource + 32-bit per-lane byte offset (constant over k) + scalar byte offset (the k position)
+__device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, _Float16* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE, int WM>
-__global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_kernel(GemmArgs g) {
+template <int MODE, int WM, int S>
+__global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
     constexpr int TBM = WM * 64;                 // block rows
     constexpr int NW = WM * 2;                   // waves
     constexpr int NBJ = 16 / NW;                 // 8-row B pieces per wave
@@ -55,27 +60,27 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_kernel(GemmArgs g
     if (g.tile_band > 0) xcd_tile_banded(gridDim.x, gridDim.y, g.tile_band, tx, ty);
     else xcd_tile(gridDim.x, gridDim.y, tx, ty);
     const int n0 = tx * GBN, m0 = ty * TBM;
-    const int n0l = g.diag ? 0 : n0, m0l = g.diag ? 0 : m0;   // diag: every block loads tile (0,0) -> all-L2-hit upper bound (results wrong)
+    const int n0l = (g.diag & 1) ? 0 : n0, m0l = (g.diag & 1) ? 0 : m0;   // diag: every block loads tile (0,0) -> all-L2-hit upper bound (results wrong)
 
     const _Float16* Ap = reinterpret_cast<const _Float16*>(g.A_hi);   // interleaved planes: (row, 32-k block) = 64 halves = one 128-byte line
     const _Float16* Bp = reinterpret_cast<const _Float16*>(g.B_hi);
     const _Float16* Z = reinterpret_cast<const _Float16*>(g.zero_page);
 
     // ---- DMA descriptors of this lane.  One DMA piece = 8 rows x 128 B (hi|lo of one k-block): lane -> row lane>>3, 16-byte position lane&7.
-    // The wave owns 32 A rows (4 pieces) and 128/NW B rows (NBJ pieces).  Rows outside the problem (and convolution taps inside the zero
-    // padding) read the zero page; their pointers simply do not advance.
-    const _Float16 *pa[4], *pb[NBJ];
-    int a_step[4], b_step[NBJ];
+    // The wave owns 32 A rows (4 pieces) and 128/NW B rows (NBJ pieces).
+    // MODE_PLAIN: buffer_load ... lds with address = resource base + scalar k offset + a per-lane 32-bit byte offset that never changes:
+    // no per-iteration address VALU and 6 VGPRs of DMA state.  Rows outside the problem are CLAMPED to the last row: they only feed
+    // accumulator rows / columns that the epilogue never stores.
+    // MODE_CONV3: the A address depends on the tap (and taps inside the zero padding read a zero page), so it is rebuilt per piece.
+    unsigned a_off[4], b_off[NBJ];
     int a_img[4], a_y[4], a_x[4], a_chunk[4];
     bool a_ok[4];
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
         const int R = wave * (8 * NBJ) + j * 8 + (lane >> 3);   // B row inside the tile
         const int c = (lane & 7) ^ ((R >> 1) & 7);               // logical 16-byte chunk (0-3 hi, 4-7 lo) that lives at physical position lane&7 of row R
-        const int n = n0l + R;
-        const bool bok = n < g.N;
-        pb[j] = bok ? Bp + (long)n * 2 * g.ldb + c * 8 : Z;
-        b_step[j] = bok ? 2 * GBK : 0;
+        const int n = min(n0l + R, g.N - 1);
+        b_off[j] = (unsigned)(((long)n * 2 * g.ldb + c * 8) * 2);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -85,18 +90,19 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_kernel(GemmArgs g
         const int m = m0l + R;
         a_ok[j] = m < g.M;
         if (MODE == MODE_PLAIN) {
-            pa[j] = a_ok[j] ? Ap + (long)m * 2 * g.lda + c * 8 : Z;
-            a_step[j] = a_ok[j] ? 2 * GBK : 0;
+            a_off[j] = (unsigned)(((long)min(m, g.M - 1) * 2 * g.lda + c * 8) * 2);
             a_img[j] = a_y[j] = a_x[j] = 0;
         } else {
-            pa[j] = Z; a_step[j] = 0;
+            a_off[j] = 0;
             const int hw = g.conv_h * g.conv_w;
             const int img = m / hw, rem = m - img * hw;
             a_img[j] = img; a_y[j] = rem / g.conv_w; a_x[j] = rem - a_y[j] * g.conv_w;
         }
     }
-    // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order, so the pointers just advance)
+    // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order)
     int k_issue = 0;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ap), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bp), 0, -1, 0x00020000);
     auto issue_a = [&](int stage, int j) {
         _Float16* sa = smem_g + stage * STAGE_H + (wave * 32 + j * 8) * 2 * GBK;
         if (MODE == MODE_CONV3) {
@@ -108,18 +114,15 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_kernel(GemmArgs g
             const bool ok = a_ok[j] && yy >= 0 && yy < lim_h && xx >= 0 && xx < lim_w;
             if (g.conv_up) { yy >>= 1; xx >>= 1; }
             const long ao = ((((long)a_img[j] * g.conv_hin + yy) * g.conv_win + xx) * g.conv_cin + c0) * 2 + a_chunk[j] * 8;
-            pa[j] = ok ? Ap + ao : Z;
+            glds16(ok ? Ap + ao : Z, sa);
+        } else {
+            glds16_buf(a_rsrc, a_off[j], k_issue * 4, sa);   // (k/32) * 128 bytes
         }
-        glds16(pa[j], sa);
-        pa[j] += a_step[j];
     };
-    auto issue_b = [&](int stage) {   // last piece(s) of a tile: advances k_issue
+    auto issue_b = [&](int stage) {   // last piece(s) of a tile: advances the k position
         _Float16* sb = smem_g + stage * STAGE_H + AREGION + wave * (8 * NBJ) * 2 * GBK;
 #pragma unroll
-        for (int j = 0; j < NBJ; ++j) {
-            glds16(pb[j], sb + j * 8 * 2 * GBK);
-            pb[j] += b_step[j];
-        }
+        for (int j = 0; j < NBJ; ++j) glds16_buf(b_rsrc, b_off[j], k_issue * 4, sb + j * 8 * 2 * GBK);
         k_issue += GBK;
     };
 
@@ -174,71 +177,72 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_kernel(GemmArgs g
     const int nk = g.K / GBK;
     // ---- prologue: tiles 0..2 in flight, tile 0 landed, F0 of tile 0 on its way
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < S; ++s)
         if (s < nk) { issue_a(s, 0); issue_a(s, 1); issue_a(s, 2); issue_a(s, 3); issue_b(s); }
-    if (nk >= 3) wait_vmcnt<2 * DMA>();
-    else if (nk == 2) wait_vmcnt<DMA>();
+    if (S >= 3 && nk >= 3) wait_vmcnt<2 * DMA>();
+    else if (nk >= 2) wait_vmcnt<DMA>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     Frag f0, f1;
     fetch(f0, 0, 0);
 
-    const bool late = wave >= NW / 2;
+    // One k-tile.  WHERE selects the DMA work of this iteration at compile time (the steady-state loops below are branch free; a runtime
+    // `if (more)` around every DMA piece costs ~10 %: each one ends a scheduling region in the middle of the MFMA stream):
+    //   0  none (tail)      1  tile kt+S after the barrier, interleaved with the F1 MFMAs ("early" waves)
+    //   2  tile kt+S-1 before the barrier, interleaved with the F0 MFMAs ("late" waves: the same tile, one phase later)
+    // DMA issue is staggered because a glds costs its wave ~70 issue cycles during which the MFMAs queued behind it cannot start: of the
+    // two waves sharing a SIMD one always runs bare MFMAs.   STEADY: tile kt+2 exists, so one tile may stay in flight across the barrier.
     int stage = 0;
-#ifdef BG_GLDS_TIMING
-    unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
-    unsigned long long* dbg = (unsigned long long*)g.bias_m;   // timing build only: bias_m carries the dump buffer
-    const bool rec = dbg && (blockIdx.x + blockIdx.y * gridDim.x) == 300 && lane == 0;
-#endif
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage_next = stage == 2 ? 0 : stage + 1;
-#ifdef BG_GLDS_TIMING
-        if (rec && kt > 0) { unsigned long long* o = dbg + ((long)wave * 128 + kt - 1) * 4; o[0] = t_a; o[1] = t_b; o[2] = t_c; o[3] = t_d; }
-        t_a = __builtin_amdgcn_s_memtime();
-#endif
+    auto body = [&](auto where_c, auto steady_c, int kt) {
+        constexpr int WHERE = decltype(where_c)::value;
+        constexpr bool STEADY = decltype(steady_c)::value;
+        const int stage_next = stage == S - 1 ? 0 : stage + 1;
+        const int stage_prev = stage == 0 ? S - 1 : stage - 1;
+#define BG_FENCE() __builtin_amdgcn_sched_barrier(0)   /* pin the hand-placed order: the machine scheduler otherwise sinks the ds_reads below the MFMAs */
         fetch(f1, stage, 1);
-        // DMA issue is staggered: a glds costs its wave ~70 issue cycles during which the MFMAs queued behind it cannot start.  The low half
-        // of the waves issues tile kt+3 in the F1 phase (below), the high half issues the same tile one phase later (here, as tile kt+2 of
-        // the next iteration), so of the two waves sharing a SIMD one always runs bare MFMAs.
-        const bool late_more = late && kt >= 1 && kt + 2 < nk;
-        const int stage_prev = stage == 0 ? 2 : stage - 1;
+        BG_FENCE();
         mma_main(f0);
-        if (late_more) { issue_a(stage_prev, 0); issue_a(stage_prev, 1); }
+        BG_FENCE();
+        if (WHERE == 2) { issue_a(stage_prev, 0); issue_a(stage_prev, 1); BG_FENCE(); }
         mma_c1(f0);
-        if (late_more) { issue_a(stage_prev, 2); issue_a(stage_prev, 3); }
+        BG_FENCE();
+        if (WHERE == 2) { issue_a(stage_prev, 2); issue_a(stage_prev, 3); BG_FENCE(); }
         mma_c2(f0);
-        if (late_more) issue_b(stage_prev);
+        if (WHERE == 2) { BG_FENCE(); issue_b(stage_prev); }
         // this wave is done reading tile kt; tile kt+1 must be complete (own pieces; tile kt+2 may stay in flight).  The scheduling fences keep
         // the MFMAs of F0 above the waits (they are not memory operations, nothing else would stop them sinking below) and F1's below.
         __builtin_amdgcn_sched_barrier(0);
-#ifdef BG_GLDS_TIMING
-        t_b = __builtin_amdgcn_s_memtime();
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kt + 2 < nk) wait_vmcnt<DMA>();
+        if (S >= 3 && (STEADY || kt + 2 < nk)) wait_vmcnt<DMA>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifdef BG_GLDS_TIMING
-        t_c = __builtin_amdgcn_s_memtime();
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = !late && kt + 3 < nk;   // tile kt+3 goes into the stage tile kt just vacated
         mma_main(f1);                    // F1 landed before the barrier: the matrix pipe restarts at once
         __builtin_amdgcn_sched_barrier(0);
         fetch(f0, stage_next, 0);        // unconditional (after the last tile it reads a stale stage and is never used): keeps the wait counters exact
-        if (more) { issue_a(stage, 0); issue_a(stage, 1); }
+        BG_FENCE();
+        if (WHERE == 1) { issue_a(stage, 0); issue_a(stage, 1); BG_FENCE(); }
         mma_c1(f1);
-        if (more) { issue_a(stage, 2); issue_a(stage, 3); }
+        BG_FENCE();
+        if (WHERE == 1) { issue_a(stage, 2); issue_a(stage, 3); BG_FENCE(); }
         mma_c2(f1);
-        if (more) issue_b(stage);
-#ifdef BG_GLDS_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        t_d = __builtin_amdgcn_s_memtime();
-#endif
+        BG_FENCE();
+        if (WHERE == 1) { issue_b(stage); BG_FENCE(); }
+#undef BG_FENCE
         stage = stage_next;
+    };
+    using std::integral_constant;
+    const bool late = NW == 8 && wave >= NW / 2;   // staggering only matters when two waves of ONE block share a SIMD
+    int kt = 0;
+    if (!late) {
+        for (; kt < nk - S; ++kt) body(integral_constant<int, 1>{}, integral_constant<bool, true>{}, kt);   // tiles kt+S <= nk-1 exist
+    } else {
+        if (nk > 0) { body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, 0); kt = 1; }
+        for (; kt <= nk - S; ++kt) body(integral_constant<int, 2>{}, integral_constant<bool, true>{}, kt);  // tiles kt+S-1 <= nk-1 exist
     }
+    for (; kt < nk; ++kt) body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
 
     // ---- epilogue.  The MFMAs were issued with the operands swapped (B fragment first), so the accumulators hold the TRANSPOSED 32x32
     // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
@@ -252,11 +256,7 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_kernel(GemmArgs g
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + r;
         if (m >= g.M) continue;
-#ifndef BG_GLDS_TIMING
         const float bm = g.bias_m ? g.bias_m[m] : 0.f;
-#else
-        const float bm = 0.f;
-#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -320,56 +320,33 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         force_wm = w ? atoi(w) : 0;
     }
     g.tile_band = band; g.diag = diag;
-    // 256-row tiles unless the problem is too small to give every CU one of them
+    // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
+    // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU
     const int wm = force_wm ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
     const int tbm = wm * 64;
+    const int stages = wm == 4 ? 3 : 2;
     dim3 grid(cdiv(g.N, GBN), cdiv(g.M, tbm), 1);
-    const size_t lds = (size_t)3 * (2 * tbm + 2 * GBN) * GBK * sizeof(_Float16);
+    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
 #define BG_SET(K, BYTES) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2>), 3 * 4 * 128 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2>), 3 * 4 * 128 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4>), 3 * 6 * 128 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4>), 3 * 6 * 128 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), 3 * 384 * 2 * GBK * 2);
 #undef BG_SET
         attr_set = true;
     }
-#ifdef BG_GLDS_TIMING
-    static unsigned long long* dbg = nullptr;
-    if (!dbg) HIP_CHECK(hipMalloc(&dbg, 8 * 128 * 4 * 8));
-    HIP_CHECK(hipMemset(dbg, 0, 8 * 128 * 4 * 8));
-    g.bias_m = reinterpret_cast<const float*>(dbg);
-#endif
     ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : PROF_GEMM, 2.0 * g.M * (double)g.N * g.K, stream);
     const bool conv = g.mode == MODE_CONV3;
     if (wm == 2) {
-        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2>), grid, dim3(256), lds, stream, g);
-        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2>), grid, dim3(256), lds, stream, g);
+        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), grid, dim3(256), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), grid, dim3(256), lds, stream, g);
     } else {
-        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 4>), grid, dim3(512), lds, stream, g);
-        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 4>), grid, dim3(512), lds, stream, g);
+        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), grid, dim3(512), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), grid, dim3(512), lds, stream, g);
     }
     LAUNCH_CHECK();
-#ifdef BG_GLDS_TIMING
-    {
-        static int printed = 0;
-        HIP_CHECK(hipDeviceSynchronize());
-        if (printed++ < 2) {
-            std::vector<unsigned long long> hbuf(8 * 128 * 4);
-            HIP_CHECK(hipMemcpy(hbuf.data(), dbg, hbuf.size() * 8, hipMemcpyDeviceToHost));
-            for (int w = 0; w < (wm == 4 ? 8 : 4); ++w) {
-                fprintf(stderr, "[glds timing] wave %d (M=%d N=%d K=%d):", w, g.M, g.N, g.K);
-                for (int kt = 8; kt < 14; ++kt) {
-                    const unsigned long long* o = &hbuf[((size_t)w * 128 + kt) * 4];
-                    const unsigned long long* o2 = &hbuf[((size_t)w * 128 + kt + 1) * 4];
-                    fprintf(stderr, "  [mfmaF0 %llu | wait+bar %llu | F1 phase %llu | iter %llu]", o[1] - o[0], o[2] - o[1], o[3] - o[2], o2[0] - o[0]);
-                }
-                fprintf(stderr, "\n");
-            }
-        }
-    }
-#endif
 }
 
 }  // namespace bevgen
