@@ -1,4 +1,5 @@
-// Split-precision flash attention (head dim 64) for Route M:  O = softmax(scale * Q K^T + bias) V  with fp32-class accuracy on the f16
+// Split-precision flash attention (head dim 64) for Route M:  O = softmax(scale * Q K^T + bias) V  (scale and bias arrive multiplied by log2 e and
+// the exponentials are v_exp_f32 = 2^x: one instruction instead of the library expf's twelve in a VALU-bound loop) with fp32-class accuracy on the f16
 // matrix cores.  Same structure as attention.hip's fp32 kernel (scores computed transposed so the query index sits on the lane axis, the
 // softmax is in-lane plus one xor-32 exchange, exp(S^T) is already the B operand of O^T = V^T P^T), but every matrix product is evaluated as
 //        X Y^T ~= hi_x hi_y^T + 2^-11 (hi_x lo_y^T + lo_x hi_y^T),      x = hi + lo * 2^-11 (two f16 numbers, 22 mantissa bits)
@@ -74,7 +75,15 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         dl[0] = make_uint2(rvl.x, rvl.y); dl[1] = make_uint2(rvl.z, rvl.w);
     };
 
+    const float c_lo = kLoI * a.scale;
     const int ntiles = a.Nk_pad / SKT;
+    // bias row segment of a key tile (this lane's 16 keys), fetched one tile ahead: an L2 round trip is longer than the QK^T MFMAs in front of it
+    float4 bv[4];
+    auto gload_bias = [&](int tile) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = Bp ? *reinterpret_cast<const float4*>(Bp + tile * SKT + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    gload_bias(0);
     gload(0);
     lstore(0);
     __syncthreads();
@@ -103,23 +112,22 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         float mx = kNegBig;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (Bp) bv = *reinterpret_cast<const float4*>(Bp + tile * SKT + 8 * g);
-            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+            const float bb[4] = {bv[g].x, bv[g].y, bv[g].z, bv[g].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                sv[4 * g + j] = (sM[4 * g + j] + (sC[4 * g + j] + sD[4 * g + j]) * kLoI) * a.scale + bb[j];
+                sv[4 * g + j] = fmaf(sC[4 * g + j] + sD[4 * g + j], c_lo, fmaf(sM[4 * g + j], a.scale, bb[j]));
                 mx = fmaxf(mx, sv[4 * g + j]);
             }
         }
+        if (more) gload_bias(tile + 1);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
         half8 ph[2], pl[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = expf(sv[r] - m_new);
+            const float p = __builtin_amdgcn_exp2f(sv[r] - m_new);   // scores are in the base-2 domain (scale, bias pre-multiplied by log2 e)
             psum += p;
             const _Float16 hi = (_Float16)p;
             ph[r >> 3][r & 7] = hi;
@@ -127,10 +135,14 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        // rescale the output accumulators only when some row's running maximum moved (alpha == 1 otherwise: skipping is exact); after the
+        // first few key tiles that is rare, and it removes 64 multiplies per tile from a VALU-bound loop
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { oM[t][r] *= alpha; oC[t][r] *= alpha; }
+                for (int r = 0; r < 16; ++r) { oM[t][r] *= alpha; oC[t][r] *= alpha; }
+        }
 
         // ---- O^T += V^T P^T.  k-step s covers keys [16s, 16s+16); lane half h owns keys 16s + {0..3} + 4h and 16s + 8 + {0..3} + 4h
 #pragma unroll

@@ -106,6 +106,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// exp(x) for the online softmax: 2^n * 2^f with n = rint(x log2e) and f = x log2e - n evaluated with a two-term log2e (fma), so the argument
+// of v_exp_f32 is exact to ~2^-25 and |f| <= 0.5: ~1.5 ulp overall in 7 instructions (the library expf is ~12 with its range checks).
+// x <= 0 in every use; x = -1e30 (masked score) gives n -> INT_MIN and the result 0.
+__device__ __forceinline__ float exp_softmax(float x) {
+    const float t = x * 1.44269502162933349609375f;
+    const float n = __builtin_rintf(t);
+    float f = __builtin_fmaf(x, 1.44269502162933349609375f, -n);
+    f = __builtin_fmaf(x, 1.92596299112661746e-8f, f);
+    return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)fmaxf(n, -300.f));
+}
+
 // erf-based GELU (torch nn.GELU() / F.gelu default)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }

@@ -193,6 +193,10 @@ static void finalize_muse(Ctx& c) {
     c.bias_cross = reinterpret_cast<float*>(c.own((size_t)c.N * c.ldC * sizeof(float)));
     BG_REQUIRE(c.L == c.N + c.K, "Route M requires num_pad_tokens == 0 (sparse_block_size 1): L=%d, N+K=%d (muse_maskgit_pytorch.py:152-154 slices the bias at K)", c.L, c.N + c.K);
     launch_build_muse_bias(c.attn_bias, c.L, c.K, c.N, c.bias_self, c.ldS, c.bias_cross, c.ldC, 0);
+    if (g.precision == BEVGEN_PRECISION_F16X3) {  // the split-precision attention kernel evaluates the softmax as 2^x (kernels.h)
+        launch_scale(c.bias_self, (long)c.N * c.ldS, kLog2e, 0);
+        launch_scale(c.bias_cross, (long)c.N * c.ldC, kLog2e, 0);
+    }
 }
 
 static void finalize_ar(Ctx& c) {

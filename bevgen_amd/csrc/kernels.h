@@ -87,7 +87,9 @@ struct AttnArgs {
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
 // Split-precision flash attention (attention_split.hip): operands pre-split into (hi, lo) f16 planes by the preparation kernels.
+//   The softmax is evaluated in the base-2 domain: `scale` and `bias` must arrive PRE-MULTIPLIED by log2(e) (kLog2e below).
 //   Qh/Ql [B,H,Nq,64], Kh/Kl [B,H,Nk_pad,64], VTh/VTl [B,H,64,Nk_pad] (V transposed); bias / output conventions as AttnArgs.
+constexpr float kLog2e = 1.44269504088896340736f;
 struct AttnSplitArgs {
     const _Float16 *Qh, *Ql, *Kh, *Kl, *VTh, *VTl;
     const float* bias; float* O;
@@ -180,5 +182,6 @@ void launch_row_softmax(float* x, int rows, int cols, float scale, hipStream_t s
 // misc
 void launch_fill(float* p, long n, float v, hipStream_t s);
 void launch_add(const float* a, const float* b, float* c, long n, hipStream_t s);
+void launch_scale(float* p, long n, float v, hipStream_t s);
 
 }  // namespace bevgen

@@ -140,7 +140,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             launch_muse_kv_prep_split(w.kvraw, l.null_kv[0], l.k_scale[0], Ksh, Ksh + kvS, VTsh, VTsh + kvS, B, H, N, c.NkS_pad, s);
             sa.Qh = Qh; sa.Ql = Qh + qN; sa.Kh = Ksh; sa.Kl = Ksh + kvS; sa.VTh = VTsh; sa.VTl = VTsh + kvS;
             sa.bias = c.bias_self; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
-            sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f;
+            sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f * kLog2e;
             sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
             sa.Op = reinterpret_cast<_Float16*>(w.att);
             launch_attention_split(sa, s);

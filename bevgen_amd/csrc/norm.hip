@@ -358,6 +358,14 @@ void launch_fill(float* p, long n, float v, hipStream_t s) {
     hipLaunchKernelGGL(fill_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, p, n, v);
     LAUNCH_CHECK();
 }
+__global__ void scale_kernel(float* p, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] *= v;
+}
+void launch_scale(float* p, long n, float v, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scale_kernel, dim3((int)std::min<long>((n + 255) / 256, 4096)), dim3(256), 0, s, p, n, v);
+    LAUNCH_CHECK();
+}
 __global__ void add_kernel(const float* a, const float* b, float* c, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) c[i] = a[i] + b[i];
 }
