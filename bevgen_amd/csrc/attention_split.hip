@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
             }
         }
         if (more) gload_bias(tile + 1);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx, xor32(mx));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         cur ^= 1;
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + xor32(l_run);
     const float inv = 1.f / l_tot;
     if (qvalid) {
         const long orow = (long)b * a.o_bstride + (long)qrow * a.o_qstride + (long)head * a.o_hstride;

@@ -95,6 +95,12 @@ __device__ __forceinline__ void store_planes2(_Float16* row, int col, float2 v) 
 constexpr float kNegBig = -1.0e30f;  // "minus infinity" that never produces inf-inf NaNs in online softmax
 
 // -------- wave-level helpers (wave = 64 lanes) --------
+// value held by lane ^ 32: v_permlane32_swap (VALU, gfx950) instead of a ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ float xor32(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
