@@ -248,6 +248,49 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
+    if (g.epi == EPI_MUSE_Q) {
+        // Route M query preparation fused into the to_q projection (muse_net:132-137; replaces muse_q_prep_split): the wave's 64 columns are
+        // exactly one head, so q = l2norm(8 x) * q_scale is a per-lane reduction over its 32 registers plus one lane-half exchange; the
+        // result leaves as the (hi, lo) f16 planes [B, H, Nq, 64] the attention kernel reads.
+        _Float16* Qh = reinterpret_cast<_Float16*>(g.epi_hi);
+        _Float16* Ql = reinterpret_cast<_Float16*>(g.epi_lo);
+        const int head = (n0 + wn * 64) >> 6;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + r;
+            float v[2][16];
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    v[j][q] = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha * 8.0f;
+                    ss = fmaf(v[j][q], v[j][q], ss);
+                }
+            ss += xor32(ss);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            if (m >= g.M) continue;
+            const int bb = m / g.epi_rows, nq = m - bb * g.epi_rows;
+            const long dst = (((long)bb * g.epi_heads + head) * g.epi_rows + nq) * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int d = j * 32 + 8 * qq + 4 * h;
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(g.epi_scale + d);
+                    half4_t hi4, lo4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float qv = (v[j][qq * 4 + e] / nrm) * sc[e];
+                        hi4[e] = split_hi(qv);
+                        lo4[e] = split_lo(qv, hi4[e]);
+                    }
+                    *reinterpret_cast<half4_t*>(Qh + dst + d) = hi4;
+                    *reinterpret_cast<half4_t*>(Ql + dst + d) = lo4;
+                }
+        }
+        return;
+    }
     float* C = g.C;
     const float* Rp = g.R;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
@@ -304,6 +347,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
     BG_REQUIRE(g.K % GBK == 0 && g.lda % GBK == 0 && g.ldb % GBK == 0, "gemm_split_glds: K, lda, ldb must be multiples of 32 (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
     BG_REQUIRE(g.batch == 1, "gemm_split_glds: batched form not provided");
+    if (g.epi == EPI_MUSE_Q)
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
+                   "gemm_split_glds: bad fused q-preparation arguments");
     if (!g_zero_page) {
         void* z = nullptr;
         HIP_CHECK(hipMalloc(&z, 4096));

@@ -8,6 +8,7 @@ namespace bevgen {
 // ---------------------------------------------------------------- gemm.hip
 enum { MODE_PLAIN = 0, MODE_CONV3 = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1 };
+enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1 };
 
 struct GemmArgs {
     const float* A = nullptr;  // [M,K] row-major (lda)   | MODE_CONV3: NHWC input [n, Hin, Win, Cin]
@@ -37,6 +38,13 @@ struct GemmArgs {
     const uint16_t* A_hi = nullptr;
     const uint16_t* A_lo = nullptr;
     const void* zero_page = nullptr;  // filled in by the launcher
+    // fused epilogues of the LDS-DMA kernel: EPI_MUSE_Q writes l2norm(8 x) * epi_scale[d] per head as (hi, lo) f16 planes [B, epi_heads, epi_rows, 64]
+    // (rows of the GEMM = B * epi_rows tokens) instead of C
+    int epi = 0;
+    const float* epi_scale = nullptr;
+    void* epi_hi = nullptr;
+    void* epi_lo = nullptr;
+    int epi_rows = 0, epi_heads = 0;
     int tile_band = 0, diag = 0;      // tile-order band height (0 = row-major) / diagnostic all-L2-hit mode; filled in by the launcher
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);

@@ -57,6 +57,17 @@ void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C
     launch_gemm(g, s);
 }
 
+// to_q projection with the query preparation (l2norm, q_scale, hi/lo split, head-major layout) fused into the GEMM epilogue
+void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, int D, hipStream_t s) {
+    GemmArgs g;
+    g.A_hi = reinterpret_cast<const uint16_t*>(Aplanes); g.A_lo = g.A_hi + 32;
+    g.B = W;
+    g.M = B * Nq; g.N = H * 64; g.K = D;
+    g.lda = lda; g.ldb = D; g.ldc = H * 64;
+    g.epi = EPI_MUSE_Q; g.epi_scale = q_scale; g.epi_hi = Qh; g.epi_lo = Ql; g.epi_rows = Nq; g.epi_heads = H;
+    launch_gemm(g, s);
+}
+
 // per-batch constants: embeddings + cross-attention K/V
 void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s) {
     const auto& g = c.cfg;
@@ -125,7 +136,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         const bool split = g.precision == BEVGEN_PRECISION_F16X3;
         if (split) {
             launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            gemm_planes(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+            gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s);
             gemm_planes(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
         } else {
             launch_layernorm(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
@@ -136,7 +147,6 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         _Float16 *Qh = reinterpret_cast<_Float16*>(w.Q), *Ksh = reinterpret_cast<_Float16*>(w.Ks), *VTsh = reinterpret_cast<_Float16*>(w.Vs);
         AttnSplitArgs sa{};
         if (split) {
-            launch_muse_q_prep_split(w.qraw, l.q_scale[0], Qh, Qh + qN, B, H, N, s);
             launch_muse_kv_prep_split(w.kvraw, l.null_kv[0], l.k_scale[0], Ksh, Ksh + kvS, VTsh, VTsh + kvS, B, H, N, c.NkS_pad, s);
             sa.Qh = Qh; sa.Ql = Qh + qN; sa.Kh = Ksh; sa.Kl = Ksh + kvS; sa.VTh = VTsh; sa.VTl = VTsh + kvS;
             sa.bias = c.bias_self; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
@@ -161,13 +171,12 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         // ---- cross attention
         if (split) {
             launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            gemm_planes(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
+            gemm_planes_q(w.xn, D, l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s);
         } else {
             launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
             gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
         }
         if (split) {
-            launch_muse_q_prep_split(w.qraw, l.q_scale[1], Qh, Qh + qN, B, H, N, s);
             _Float16 *ckh = reinterpret_cast<_Float16*>(w.crossK[i]), *cvh = reinterpret_cast<_Float16*>(w.crossV[i]);
             sa.Kh = ckh; sa.Kl = ckh + kvC; sa.VTh = cvh; sa.VTl = cvh + kvC;
             sa.bias = c.bias_cross; sa.Nk_pad = c.NkC_pad; sa.ldbias = c.ldC;
