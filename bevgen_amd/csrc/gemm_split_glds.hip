@@ -64,7 +64,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
 
     const _Float16* Ap = reinterpret_cast<const _Float16*>(g.A_hi);   // interleaved planes: (row, 32-k block) = 64 halves = one 128-byte line
     const _Float16* Bp = reinterpret_cast<const _Float16*>(g.B_hi);
-    const _Float16* Z = reinterpret_cast<const _Float16*>(g.zero_page);
 
     // ---- DMA descriptors of this lane.  One DMA piece = 8 rows x 128 B (hi|lo of one k-block): lane -> row lane>>3, 16-byte position lane&7.
     // The wave owns 32 A rows (4 pieces) and 128/NW B rows (NBJ pieces).
@@ -73,8 +72,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     // accumulator rows / columns that the epilogue never stores.
     // MODE_CONV3: the A address depends on the tap (and taps inside the zero padding read a zero page), so it is rebuilt per piece.
     unsigned a_off[4], b_off[NBJ];
-    int a_img[4], a_y[4], a_x[4], a_chunk[4];
-    bool a_ok[4];
+    int a_img[4], a_yx[4];   // MODE_CONV3: image index and (y << 16 | x) of the output pixel; rows past M have a_img >= number of images
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
         const int R = wave * (8 * NBJ) + j * 8 + (lane >> 3);   // B row inside the tile
@@ -86,35 +84,37 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     for (int j = 0; j < 4; ++j) {
         const int R = wave * 32 + j * 8 + (lane >> 3);   // A row inside the tile
         const int c = (lane & 7) ^ ((R >> 1) & 7);
-        a_chunk[j] = c;
         const int m = m0l + R;
-        a_ok[j] = m < g.M;
         if (MODE == MODE_PLAIN) {
             a_off[j] = (unsigned)(((long)min(m, g.M - 1) * 2 * g.lda + c * 8) * 2);
-            a_img[j] = a_y[j] = a_x[j] = 0;
+            a_img[j] = a_yx[j] = 0;
         } else {
-            a_off[j] = 0;
+            a_off[j] = (unsigned)(c * 16);   // byte position of the lane's chunk inside the 128-byte (pixel, k-block) line
             const int hw = g.conv_h * g.conv_w;
             const int img = m / hw, rem = m - img * hw;
-            a_img[j] = img; a_y[j] = rem / g.conv_w; a_x[j] = rem - a_y[j] * g.conv_w;
+            const int y = rem / g.conv_w;
+            a_img[j] = img; a_yx[j] = (y << 16) | (rem - y * g.conv_w);
         }
     }
     // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order)
     int k_issue = 0;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ap), 0, -1, 0x00020000);
+    const int n_img = MODE == MODE_CONV3 ? g.M / (g.conv_h * g.conv_w) : 0;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ap), 0, MODE == MODE_CONV3 ? g.a_bytes : -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bp), 0, -1, 0x00020000);
     auto issue_a = [&](int stage, int j) {
         _Float16* sa = smem_g + stage * STAGE_H + (wave * 32 + j * 8) * 2 * GBK;
         if (MODE == MODE_CONV3) {
+            // scalar part (tap of this k-tile) + a dozen 32-bit VALU per piece; taps inside the zero padding (and rows past M) use an offset
+            // beyond the resource's num_records: the buffer load returns zeros and the DMA writes them (checked on gfx950)
             const int tap = k_issue / g.conv_cin;
             const int c0 = k_issue - tap * g.conv_cin;
             const int kh = tap / 3, kw = tap - kh * 3;
-            int yy = a_y[j] * g.conv_stride + kh - g.conv_pad, xx = a_x[j] * g.conv_stride + kw - g.conv_pad;
+            int yy = (a_yx[j] >> 16) * g.conv_stride + kh - g.conv_pad, xx = (a_yx[j] & 0xffff) * g.conv_stride + kw - g.conv_pad;
             const int lim_h = g.conv_up ? 2 * g.conv_hin : g.conv_hin, lim_w = g.conv_up ? 2 * g.conv_win : g.conv_win;
-            const bool ok = a_ok[j] && yy >= 0 && yy < lim_h && xx >= 0 && xx < lim_w;
+            const bool ok = a_img[j] < n_img && yy >= 0 && yy < lim_h && xx >= 0 && xx < lim_w;
             if (g.conv_up) { yy >>= 1; xx >>= 1; }
-            const long ao = ((((long)a_img[j] * g.conv_hin + yy) * g.conv_win + xx) * g.conv_cin + c0) * 2 + a_chunk[j] * 8;
-            glds16(ok ? Ap + ao : Z, sa);
+            const unsigned off = (unsigned)((a_img[j] * g.conv_hin + yy) * g.conv_win + xx) * (unsigned)(g.conv_cin * 4) + (unsigned)(c0 * 4) + a_off[j];
+            glds16_buf(a_rsrc, ok ? off : 0xFFFFFF00u, 0, sa);
         } else {
             glds16_buf(a_rsrc, a_off[j], k_issue * 4, sa);   // (k/32) * 128 bytes
         }
@@ -333,8 +333,6 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     }
 }
 
-static const void* g_zero_page = nullptr;
-
 void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     GemmArgs g = g_in;
     if (g.mode == MODE_CONV3) {
@@ -343,6 +341,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         if (g.conv_hin == 0) g.conv_hin = g.conv_up ? g.conv_h / 2 : g.conv_h;
         if (g.conv_win == 0) g.conv_win = g.conv_up ? g.conv_w / 2 : g.conv_w;
         BG_REQUIRE(g.conv_cin % GBK == 0 && g.K == 9 * g.conv_cin, "conv3x3: Cin=%d must be a multiple of 32", g.conv_cin);
+        const long a_bytes = (long)(g.M / (g.conv_h * g.conv_w)) * g.conv_hin * g.conv_win * g.conv_cin * 4;
+        BG_REQUIRE(a_bytes < 0xFFFFFF00L, "conv3x3 (LDS-DMA): the activation planes (%ld bytes) must stay below 4 GiB per launch", a_bytes);
+        g.a_bytes = (int)(unsigned)a_bytes;
     }
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
     BG_REQUIRE(g.K % GBK == 0 && g.lda % GBK == 0 && g.ldb % GBK == 0, "gemm_split_glds: K, lda, ldb must be multiples of 32 (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
@@ -350,13 +351,6 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     if (g.epi == EPI_MUSE_Q)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");
-    if (!g_zero_page) {
-        void* z = nullptr;
-        HIP_CHECK(hipMalloc(&z, 4096));
-        HIP_CHECK(hipMemset(z, 0, 4096));
-        g_zero_page = z;
-    }
-    g.zero_page = g_zero_page;
     static int band = -1, diag = 0, force_wm = 0;
     if (band < 0) {
         const char* e = getenv("BEVGEN_GLDS_BAND");

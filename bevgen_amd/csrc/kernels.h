@@ -45,6 +45,7 @@ struct GemmArgs {
     void* epi_hi = nullptr;
     void* epi_lo = nullptr;
     int epi_rows = 0, epi_heads = 0;
+    int a_bytes = 0;                  // MODE_CONV3: size of the activation plane image (buffer-resource bound), filled in by the launcher
     int tile_band = 0, diag = 0;      // tile-order band height (0 = row-major) / diagnostic all-L2-hit mode; filled in by the launcher
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -76,6 +77,7 @@ size_t groupnorm_ws_bytes(int n, int hw);
 void launch_groupnorm_stats(const float* x, float* stats, void* ws /*groupnorm_ws_bytes*/, int n, int hw, int C, float eps, hipStream_t s);
 // y = (x-mean)*rstd*gamma+beta, optionally followed by swish (x*sigmoid(x)); NHWC
 void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s);
+void launch_groupnorm_apply_planes(const float* x, const float* stats, const float* gamma, const float* beta, void* planes, int n, int hw, int C, int do_swish, hipStream_t s);
 
 // ---------------------------------------------------------------- attention.hip
 // Flash attention, fp32 MFMA, head dim 64:  O = softmax(scale * Q K^T + bias) V

@@ -298,6 +298,7 @@ void launch_groupnorm_stats(const float* x, float* stats, void* ws, int n, int h
     LAUNCH_CHECK();
 }
 
+template <bool PLANES>   // PLANES: y is the interleaved (hi, lo) f16 plane image [pixel][C/32][2][32] read by the LDS-DMA split-precision convolution
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ y, long total4, int hw, int C, int do_swish) {
     const int cpg = C / GN_GROUPS;
@@ -317,14 +318,23 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
             if (do_swish) o = o / (1.f + expf(-o));
             out[k] = o;
         }
-        reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
+        if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + pix * 2 * C, cq * 4, make_float4(out[0], out[1], out[2], out[3]));
+        else reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
 void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s) {
     const long total4 = (long)n * hw * C / 4;
     const int blocks = (int)std::min<long>((total4 + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, total4, hw, C, do_swish);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<false>, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, total4, hw, C, do_swish);
+    LAUNCH_CHECK();
+}
+
+void launch_groupnorm_apply_planes(const float* x, const float* stats, const float* gamma, const float* beta, void* planes, int n, int hw, int C, int do_swish, hipStream_t s) {
+    BG_REQUIRE(C % 32 == 0, "groupnorm_apply_planes: C=%d must be a multiple of 32", C);
+    const long total4 = (long)n * hw * C / 4;
+    const int blocks = (int)std::min<long>((total4 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<true>, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, reinterpret_cast<float*>(planes), total4, hw, C, do_swish);
     LAUNCH_CHECK();
 }
 

@@ -54,11 +54,14 @@ AttnBlockW load_attn(Ctx& c, const std::string& p) {
 
 struct Act { float* p; int n, h, w, c; long elems() const { return (long)n * h * w * c; } };
 
-void conv3(const Act& x, const ConvW& w, float* y, const float* residual, int up, hipStream_t s) {
+// planes: x.p holds the interleaved (hi, lo) f16 plane image of the activation (written by gn(..., planes = true)) instead of fp32
+void conv3(const Act& x, const ConvW& w, float* y, const float* residual, int up, hipStream_t s, bool planes = false) {
     GemmArgs g;
     const int oh = up ? x.h * 2 : x.h, ow = up ? x.w * 2 : x.w;
     g.mode = MODE_CONV3;
-    g.A = x.p; g.B = w.w; g.C = y; g.R = residual; g.bias_n = w.b;
+    if (planes) { g.A_hi = reinterpret_cast<const uint16_t*>(x.p); g.A_lo = g.A_hi + 32; }
+    else g.A = x.p;
+    g.B = w.w; g.C = y; g.R = residual; g.bias_n = w.b;
     g.M = x.n * oh * ow; g.N = w.cout; g.K = 9 * w.cin;
     g.lda = w.cin; g.ldb = 9 * w.cin; g.ldc = w.cout; g.ldr = w.cout;
     g.conv_h = oh; g.conv_w = ow; g.conv_cin = w.cin; g.conv_up = up;
@@ -80,26 +83,27 @@ struct DecWs {
     float *q, *k, *vT, *S;
 };
 
-void gn(const Act& x, const float* w, const float* b, float* y, int swish, DecWs& ws, hipStream_t s) {
+void gn(const Act& x, const float* w, const float* b, float* y, int swish, DecWs& ws, hipStream_t s, bool planes = false) {
     launch_groupnorm_stats(x.p, ws.stats, ws.gn_ws, x.n, x.h * x.w, x.c, 1e-6f, s);
-    launch_groupnorm_apply(x.p, ws.stats, w, b, y, x.n, x.h * x.w, x.c, swish, s);
+    if (planes) launch_groupnorm_apply_planes(x.p, ws.stats, w, b, y, x.n, x.h * x.w, x.c, swish, s);
+    else launch_groupnorm_apply(x.p, ws.stats, w, b, y, x.n, x.h * x.w, x.c, swish, s);
 }
 
 // x (in ws.a-or-b) -> out buffer `y`; uses ws.t and the other ping-pong buffer as scratch
-void resblock(const ResBlockW& r, Act& x, float* y, float* scratch, DecWs& ws, hipStream_t s) {
-    // h = conv1(swish(norm1(x)))
-    gn(x, r.n1w, r.n1b, ws.t, 1, ws, s);
+void resblock(const ResBlockW& r, Act& x, float* y, float* scratch, DecWs& ws, hipStream_t s, bool planes) {
+    // h = conv1(swish(norm1(x)));  split-precision mode: the normalised activation is written directly as the (hi, lo) planes the convolution reads
+    gn(x, r.n1w, r.n1b, ws.t, 1, ws, s, planes);
     Act t{ws.t, x.n, x.h, x.w, r.cin};
-    conv3(t, r.c1, scratch, nullptr, 0, s);
+    conv3(t, r.c1, scratch, nullptr, 0, s, planes);
     Act h1{scratch, x.n, x.h, x.w, r.cout};
-    gn(h1, r.n2w, r.n2b, ws.t, 1, ws, s);
+    gn(h1, r.n2w, r.n2b, ws.t, 1, ws, s, planes);
     Act t2{ws.t, x.n, x.h, x.w, r.cout};
     const float* shortcut = x.p;
     if (r.has_nin) {  // x = nin_shortcut(x)  (1x1), written over h1 (no longer needed after norm2)
         conv1(x.p, (long)x.n * x.h * x.w, r.nin, scratch, nullptr, s);
         shortcut = scratch;
     }
-    conv3(t2, r.c2, y, shortcut, 0, s);  // y = x + conv2(...)
+    conv3(t2, r.c2, y, shortcut, 0, s, planes);  // y = x + conv2(...)
     x = Act{y, x.n, x.h, x.w, r.cout};
 }
 
@@ -185,6 +189,7 @@ void vq_finalize(Ctx& c) {
 void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_total, int denorm, float* out, hipStream_t s) {
     BG_REQUIRE(c.has_vq, "this context holds no VQGAN decoder weights (decoder.* tensors were not loaded)");
     const auto& g = c.cfg;
+    const bool planes = g.precision == BEVGEN_PRECISION_F16X3;   // split-precision mode: GroupNorm writes (hi, lo) planes, convolutions read them by LDS-DMA
     const int lat = g.vq_resolution >> (g.vq_num_levels - 1);
     const int R = g.vq_resolution;
     BG_REQUIRE(!denorm || g.vq_out_ch == 3, "denormalize needs 3 output channels");
@@ -240,7 +245,7 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
             float* bufs[3] = {ws.a, ws.b, o};
             float* scratch = nullptr; float* y = nullptr;
             for (float* b : bufs) { if (b != x.p) { if (!scratch) scratch = b; else y = b; } }
-            resblock(r, x, y, scratch, ws, s);
+            resblock(r, x, y, scratch, ws, s, planes);
         };
         auto attn_step = [&](const AttnBlockW& ab) {
             float* bufs[3] = {ws.a, ws.b, o};
@@ -265,9 +270,9 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
                 x = Act{y, x.n, x.h * 2, x.w * 2, u.up.cout};
             }
         }
-        gn(x, c.norm_out_w, c.norm_out_b, ws.t, 1, ws, s);
+        gn(x, c.norm_out_w, c.norm_out_b, ws.t, 1, ws, s, planes);
         Act t{ws.t, x.n, x.h, x.w, x.c};
-        conv3(t, c.conv_out, img, nullptr, 0, s);  // [n, R*R, out_ch]
+        conv3(t, c.conv_out, img, nullptr, 0, s, planes);  // [n, R*R, out_ch]
         launch_nhwc_to_nchw(img, out + (long)i0 * g.vq_out_ch * R * R, n, R * R, g.vq_out_ch, g.vq_out_ch, denorm ? c.denorm_mean : nullptr,
                             denorm ? c.denorm_std : nullptr, denorm ? 1 : 0, s);
     }
@@ -329,6 +334,7 @@ static void vq_enc_finalize(Ctx& c) {
 void vq_encode(Ctx& c, const float* x_nchw, int n_total, int64_t* ids, hipStream_t s) {
     BG_REQUIRE(c.has_vq_enc, "this context holds no VQGAN encoder weights (encoder.* tensors were not loaded)");
     const auto& g = c.cfg;
+    const bool planes = g.precision == BEVGEN_PRECISION_F16X3;   // split-precision mode: GroupNorm writes (hi, lo) planes, convolutions read them by LDS-DMA
     const int R = g.vq_resolution;
     const int lat = R >> (g.vq_num_levels - 1);
     long per_img = (long)R * R * std::max(c.enc_cin_pad, g.vq_ch);
@@ -376,7 +382,7 @@ void vq_encode(Ctx& c, const float* x_nchw, int n_total, int64_t* ids, hipStream
             scratch = nullptr; y = nullptr;
             for (float* b : bufs) { if (b != x.p) { if (!scratch) scratch = b; else y = b; } }
         };
-        auto res_step = [&](const ResBlockW& r) { float *sc, *y; pick2(sc, y); resblock(r, x, y, sc, ws, s); };
+        auto res_step = [&](const ResBlockW& r) { float *sc, *y; pick2(sc, y); resblock(r, x, y, sc, ws, s, planes); };
         auto attn_step = [&](const AttnBlockW& ab) { float *sc, *y; pick2(sc, y); attnblock(ab, x, y, ws, s); };
         for (int lvl = 0; lvl < g.vq_num_levels; ++lvl) {
             const DownLevelW& d = c.down[lvl];
@@ -400,10 +406,10 @@ void vq_encode(Ctx& c, const float* x_nchw, int n_total, int64_t* ids, hipStream
         res_step(c.enc_mid1);
         attn_step(c.enc_mid_attn);
         res_step(c.enc_mid2);
-        gn(x, c.enc_norm_out_w, c.enc_norm_out_b, ws.t, 1, ws, s);
+        gn(x, c.enc_norm_out_w, c.enc_norm_out_b, ws.t, 1, ws, s, planes);
         Act t{ws.t, x.n, x.h, x.w, x.c};
         float *sc, *y; pick2(sc, y);
-        conv3(t, c.enc_conv_out, y, nullptr, 0, s);                     // [n, lat*lat, z_channels]
+        conv3(t, c.enc_conv_out, y, nullptr, 0, s, planes);                     // [n, lat*lat, z_channels]
         conv1(y, lrows, c.quant_conv, zq, nullptr, s);                  // quant_conv (1x1)
         // distances to the codebook: (|z|^2 + |e|^2) - 2 z.e, arg-min (exact fp32 products: the codebook is never split)
         launch_row_sqnorm(zq, zz, lrows, g.vq_embed_dim, s);
