@@ -232,7 +232,7 @@ def main():
         if precision == "fp32":
             peak, kern, note = MFMA_FP32_PEAK_TF, "gemm_f32_kernel<MODE_PLAIN>", "v_mfma_f32_32x32x2_f32, exact fp32"
         else:
-            peak, kern, note = MFMA_F16_PEAK_TF / 3.0, "gemm_split_kernel<MODE_PLAIN>", "3 v_mfma_f32_32x32x16_f16 per fp32 product (hi/lo split): ceiling = f16 dense peak / 3"
+            peak, kern, note = MFMA_F16_PEAK_TF / 3.0, "gemm_split_glds_kernel<MODE_PLAIN, 4, 3>", "3 v_mfma_f32_32x32x16_f16 per fp32 product (hi/lo split): ceiling = f16 dense peak / 3"
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(kern), "kernel": kern, "note": note,
                 "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1)}
 

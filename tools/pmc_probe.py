@@ -13,6 +13,12 @@ M, N, K = 24576, 1024, 1024
 a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda")
 for _ in range(5):
     ctx.op_gemm(a, w)
+# split-precision LDS-DMA GEMM (the production path of the default f16x3 mode): operands are split on the fly by the op entry point,
+# the GEMM kernel itself reads 4 B per element of A and B (interleaved hi/lo f16 planes) and writes fp32 C -> same algorithmic bytes
+from bevgen_amd.runtime import _ptr, _stream
+out = torch.empty(M, N, device="cuda")
+for _ in range(5):
+    ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(a), _ptr(w), None, None, _ptr(out), M, N, K, 0, 3, _stream()))
 B, H, n, L = 16, 16, 1500, 2368
 q = torch.randn(B, H * 64, device="cuda")
 kc = torch.randn(B, H, L, 64, device="cuda"); vc = torch.randn(B, H, L, 64, device="cuda")
