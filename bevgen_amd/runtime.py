@@ -6,6 +6,7 @@ raw ``data_ptr()``; all arithmetic of the hot path happens inside libbevgen_hip'
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Mapping, Optional, Sequence
 
@@ -51,7 +52,7 @@ class Context:
     """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
-                 device: Optional[int] = None, max_batch: int = 0, precision: str = "fp32"):
+                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bevgen_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product")
@@ -61,6 +62,11 @@ class Context:
         c = bevgen_cfg()
         c.abi_version = _lib.ABI_VERSION
         c.route = _lib.ROUTE_MASKGIT if route == "maskgit" else _lib.ROUTE_AR
+        # arithmetic mode of the matrix products: explicit argument, else $BEVGEN_PRECISION (how the drop-in modules are switched), else exact fp32
+        precision = precision or os.environ.get("BEVGEN_PRECISION", "fp32")
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError(f"precision must be 'fp32' or 'f16x3', got {precision!r}")
+        self.precision = precision
         c.precision = {"fp32": _lib.PRECISION_FP32, "f16x3": _lib.PRECISION_F16X3}[precision]
         c.max_batch = max_batch
         if cfg is not None:
