@@ -60,6 +60,7 @@ SIGNATURES = {
     "bevgen_ar_logits": (_i, [_p, _p, _p]),
     "bevgen_ar_decode_step": (_i, [_p, _p, _p]),
     "bevgen_ar_sample": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _p, _p]),
+    "bevgen_ar_sample_forced": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _p, _p, _p]),
     "bevgen_vq_decode": (_i, [_p, _p, _i, _i, _p, _p]),
     "bevgen_vq_decode_latents": (_i, [_p, _p, _i, _i, _p, _p]),
     "bevgen_vq_encode": (_i, [_p, _p, _i, _p, _p]),

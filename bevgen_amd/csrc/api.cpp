@@ -152,7 +152,17 @@ int bevgen_ar_sample(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, c
         need_final(ctx);
         BG_REQUIRE(cond && I_inv && E_inv && out, "ar_sample: null argument");
         BG_REQUIRE(temperature > 0.f, "ar_sample: temperature must be positive");
-        ar_sample(*ctx, cond, I_inv, E_inv, B, steps, top_k, temperature, greedy, noise_u, samples_per_layout, out, step_logits, (hipStream_t)stream);
+        ar_sample(*ctx, cond, I_inv, E_inv, B, steps, top_k, temperature, greedy, noise_u, samples_per_layout, nullptr, out, step_logits, (hipStream_t)stream);
+    });
+}
+
+int bevgen_ar_sample_forced(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
+                            const float* noise_u, int samples_per_layout, const int64_t* forced, int64_t* out, float* step_logits, void* stream) {
+    return guarded(ctx, [&] {
+        need_final(ctx);
+        BG_REQUIRE(cond && I_inv && E_inv && out, "ar_sample_forced: null argument");
+        BG_REQUIRE(temperature > 0.f, "ar_sample_forced: temperature must be positive");
+        ar_sample(*ctx, cond, I_inv, E_inv, B, steps, top_k, temperature, greedy, noise_u, samples_per_layout, forced, out, step_logits, (hipStream_t)stream);
     });
 }
 

@@ -230,7 +230,7 @@ void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s) {
 }
 
 void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
-               const float* noise_u, int samples_per_layout, int64_t* out, float* step_logits, hipStream_t s) {
+               const float* noise_u, int samples_per_layout, const int64_t* forced, int64_t* out, float* step_logits, hipStream_t s) {
     (void)samples_per_layout;
     BG_REQUIRE(steps >= 1 && steps <= c.N, "steps=%d out of range [1,%d]", steps, c.N);
     BG_REQUIRE(greedy || noise_u, "stochastic sampling needs explicit uniform noise d_noise_u [steps, B]");
@@ -246,7 +246,7 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     auto head_and_pick = [&](float* lg, hipStream_t q) {
         launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, B, c.D, 1e-5f, q);
         small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, lg, c.V, B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, q);
-        launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u, st.d_step, w.tok, B, c.V, top_k, temperature, q);
+        launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u, st.d_step, forced, w.tok, B, c.V, top_k, temperature, q);
         launch_store_tokens(w.tok, c.fwd_idx, st.d_step, out, B, c.N, q);
     };
 

@@ -179,8 +179,9 @@ void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float
 void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u /*or null*/, float noise_scale, float frac,
                           float* scores, int rows, int D, hipStream_t s);
 // Route A token pick (ar_lm:204-219): logits/temperature, top-k (ties kept), softmax, argmax or inverse-CDF draw with explicit u
-void launch_ar_pick(const float* logits, int ldl, const float* u /*[steps, rows] or null*/, const int* d_step /*or null: u is this step's row*/, int64_t* out, int rows, int V, int top_k,
-                    float temperature, hipStream_t s);
+//   forced [steps, rows] (or null): entries >= 0 are emitted instead of a drawn token (partial decoding, ar_lm:161-165,181-182)
+void launch_ar_pick(const float* logits, int ldl, const float* u /*[steps, rows] or null*/, const int* d_step /*or null: u is this step's row*/, const int64_t* forced,
+                    int64_t* out, int rows, int V, int top_k, float temperature, hipStream_t s);
 
 // ---------------------------------------------------------------- vq.hip
 void launch_codebook_gather(const int64_t* ids, const float* codebook, float* out, int rows, int dim, int n_embed, hipStream_t s);

@@ -140,7 +140,7 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
 void ar_logits(Ctx& c, float* logits, hipStream_t s);
 void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s);
 void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
-               const float* noise_u, int samples_per_layout, int64_t* out, float* step_logits, hipStream_t s);
+               const float* noise_u, int samples_per_layout, const int64_t* forced, int64_t* out, float* step_logits, hipStream_t s);
 // vqdec.cpp
 void vq_finalize(Ctx& c);
 void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n, int denorm, float* out, hipStream_t s);

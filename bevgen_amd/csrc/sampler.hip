@@ -144,9 +144,17 @@ void launch_critic_scores(const float* embed, int lde, const float* w, const flo
 // ---------------------------------------------------------------------------------------------- Route A token pick
 // lane owns the contiguous index range [lane*VPL, lane*VPL + VPL) so that the cumulative distribution runs in index order
 __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ u_base, const int* __restrict__ d_step,
-                                                     int64_t* __restrict__ out, int V, int top_k, float temperature) {
+                                                     const int64_t* __restrict__ forced, int64_t* __restrict__ out, int V, int top_k, float temperature) {
     const int lane = threadIdx.x;
     const long row = blockIdx.x;
+    // partial decoding (ar_lm:161-165, 181-182): positions of the fixed cameras keep their given token, laid out [steps, rows] like the noise
+    if (forced) {
+        const int64_t f = forced[(d_step ? (long)(*d_step) * gridDim.x : 0) + row];
+        if (f >= 0) {
+            if (lane == 0) out[row] = f;
+            return;
+        }
+    }
     // explicit uniforms are laid out [steps, rows]; the step comes from the device counter so that one captured launch serves every step
     const float* u = u_base ? u_base + (d_step ? (long)(*d_step) * gridDim.x : 0) : nullptr;
     const float* lr = logits + row * ldl;
@@ -205,9 +213,10 @@ __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ l
     if (lane == 0) out[row] = min(cnt, V - 1);
 }
 
-void launch_ar_pick(const float* logits, int ldl, const float* u, const int* d_step, int64_t* out, int rows, int V, int top_k, float temperature, hipStream_t s) {
+void launch_ar_pick(const float* logits, int ldl, const float* u, const int* d_step, const int64_t* forced, int64_t* out, int rows, int V, int top_k, float temperature,
+                    hipStream_t s) {
     BG_REQUIRE(V <= 64 * VPL_MAX, "ar_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
-    hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, d_step, out, V, top_k, temperature);
+    hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, d_step, forced, out, V, top_k, temperature);
     LAUNCH_CHECK();
 }
 

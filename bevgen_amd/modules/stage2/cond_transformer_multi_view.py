@@ -60,12 +60,22 @@ class Net2NetTransformer(_Base):
         B = c.shape[0]
         if self.skip_sampling:
             return torch.zeros((B, cfg.num_cams, cfg.num_cam_tokens), dtype=torch.int64, device=c.device)
-        if partial_decoding_idx is not None:
-            raise NotImplementedError("partial decoding for the autoregressive route is listed as a follow-up (SURVEY.md 8f-4)")
         ctx = self.transformer.context()
+        forced = None
+        if partial_decoding_idx is not None:
+            # ar_lm:161-165: the fixed cameras take the tokens of their encoded ground-truth images (precomputed batch['z_ids'] short-circuits)
+            from ...partial import partial_forced_ids
+            if "z_ids" in batch:
+                z = batch["z_ids"].to(ctx.device)
+            else:
+                img = batch[self.first_stage_key].to(ctx.device).float().movedim(-1, -3)
+                z = self.first_stage_model.encode_ids(img.reshape(-1, *img.shape[-3:]))
+            idx = partial_decoding_idx.tolist() if isinstance(partial_decoding_idx, torch.Tensor) else list(partial_decoding_idx)
+            forced = partial_forced_ids(cfg, idx, z.reshape(B, cfg.num_cams, cfg.num_cam_tokens))
         if sample and noise_u is None:
             noise_u = torch.rand((cfg.num_img_tokens, B), device=ctx.device)
-        out = ctx.ar_sample(c, batch["intrinsics_inv"], batch["extrinsics_inv"], top_k=top_k, temperature=temperature, greedy=not sample, noise_u=noise_u)
+        out = ctx.ar_sample(c, batch["intrinsics_inv"], batch["extrinsics_inv"], top_k=top_k, temperature=temperature, greedy=not sample, noise_u=noise_u,
+                            forced_ids=forced)
         assert out.max() < cfg.vocab_size
         return out
 

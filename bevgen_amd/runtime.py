@@ -220,7 +220,9 @@ class Context:
         token = _req(token, torch.int64, self.device, "token")
         self._check(self.lib.bevgen_ar_decode_step(self._h, _ptr(token), _stream()))
 
-    def ar_sample(self, cond_ids, I_inv, E_inv, *, steps=None, top_k=None, temperature=1.0, greedy=True, noise_u=None, samples_per_layout=1, return_logits=False):
+    def ar_sample(self, cond_ids, I_inv, E_inv, *, steps=None, top_k=None, temperature=1.0, greedy=True, noise_u=None, samples_per_layout=1, return_logits=False,
+                  forced_ids=None):
+        """Route A sampling with the KV cache.  forced_ids [steps, B] int64 in decode order (>= 0: emit this token, < 0: draw) = partial decoding."""
         cfg = self.cfg
         d = self.device
         cond_ids = _req(cond_ids, torch.int64, d, "cond_ids")
@@ -233,8 +235,11 @@ class Context:
             assert tuple(noise_u.shape) == (steps, B)
         out = torch.empty((B, cfg.num_cams, cfg.num_cam_tokens), dtype=torch.int64, device=d)
         logits = torch.empty((steps, B, cfg.vocab_size), dtype=torch.float32, device=d) if return_logits else None
-        self._check(self.lib.bevgen_ar_sample(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, steps, int(top_k or 0), float(temperature), int(bool(greedy)),
-                                               _ptr(noise_u), int(samples_per_layout), _ptr(out), _ptr(logits), _stream()))
+        if forced_ids is not None:
+            forced_ids = _req(forced_ids, torch.int64, d, "forced_ids")
+            assert tuple(forced_ids.shape) == (steps, B)
+        self._check(self.lib.bevgen_ar_sample_forced(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, steps, int(top_k or 0), float(temperature), int(bool(greedy)),
+                                                      _ptr(noise_u), int(samples_per_layout), _ptr(forced_ids), _ptr(out), _ptr(logits), _stream()))
         return (out, logits) if return_logits else out
 
     # ------------------------------------------------------------------------------------------ stage 1

@@ -150,6 +150,13 @@ int bevgen_ar_sample(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_
                      int top_k, float temperature, int greedy, const float* d_noise_u, int samples_per_layout,
                      int64_t* d_out_ids, float* d_step_logits /* [steps,B,V] or NULL */, void* stream);
 
+/* Same with partial decoding (cond_transformer_multi_view.py:161-165, 181-182: the tokens of the cameras in `partial_decoding_idx` are taken from the
+ * encoded ground-truth images and their positions are skipped by the sampling loop): d_forced_ids [steps, B] int64 in DECODE order, entry >= 0 = the
+ * token to emit at that step (it is still pushed through the stack so that later positions attend to it), < 0 = draw the token.  NULL = bevgen_ar_sample. */
+int bevgen_ar_sample_forced(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_I_inv, const float* d_E_inv, int B, int steps,
+                            int top_k, float temperature, int greedy, const float* d_noise_u, int samples_per_layout,
+                            const int64_t* d_forced_ids, int64_t* d_out_ids, float* d_step_logits, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * stage-1 VQGAN decode                                                                                            */
 

@@ -155,6 +155,24 @@ def golden_route_a(case: cases.Case, full: bool):
         xs2 = R.ar_sample_cached(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], temperature=0.9, top_k=8, noise_u=noise_u)
         assert torch.equal(xs, xs2)
         out.update(logits_full=lr, step_logits=sl, sample_topk8=xs.to(torch.int16))
+        # partial decoding (ar_lm:161-165, 181-182) with the reference's loop structure driven through the reference GPT: the fixed cameras start from
+        # "ground-truth" ids (encode_to_z output in the reference; seeded random ids here) and their positions are skipped
+        partial_idx = [1] if C < 6 else [0, 2]
+        z = torch.randint(0, cfg.vocab_size, (B, C, T), generator=g)
+        xp = torch.full((B, C, T), cfg.vocab_size, dtype=torch.long)
+        xp[:, partial_idx, :] = z[:, partial_idx]
+        with torch.no_grad():
+            for s in range(N):
+                j = int(cfg.forward_shuffle_idx[s])
+                if j // T in partial_idx:
+                    continue
+                logits = gpt(xp, bt["cond_ids"], batch, sampling=True)[:, j]
+                xp[:, j // T, j % T] = logits.softmax(-1).topk(1).indices[:, 0]
+        xp_or = R.ar_sample_full_recompute(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], partial_decoding_idx=partial_idx, z_indices=z)
+        xp_kv = R.ar_sample_cached(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], forced_ids=R.partial_forced_ids(cfg, partial_idx, z))
+        assert torch.equal(xp, xp_or), "oracle partial decoding != reference loop"
+        assert torch.equal(xp, xp_kv), "KV-cache partial decoding (forced tokens) != reference loop"
+        out.update(partial_idx=np.array(partial_idx), partial_z=z.to(torch.int16), sample_partial=xp.to(torch.int16))
     else:
         keep = sorted({0, 1, 17, N // 2, N - 1})
         out.update(step_logits_idx=np.array(keep), step_logits=sl[keep])

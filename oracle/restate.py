@@ -326,14 +326,24 @@ def pick_token(logits: Tensor, temperature: float, top_k: Optional[int], u: Opti
 
 
 def ar_sample_full_recompute(sd, cfg, cond_ids: Tensor, I_inv: Tensor, E_inv: Tensor, *, temperature: float = 1.0, top_k: Optional[int] = None,
-                             noise_u: Optional[Tensor] = None, steps: Optional[int] = None, logits_out: Optional[List[Tensor]] = None) -> Tensor:
-    """Net2NetTransformer.sample exactly as the reference runs it (ar_lm:154-227): one full L-token forward per generated token."""
+                             noise_u: Optional[Tensor] = None, steps: Optional[int] = None, logits_out: Optional[List[Tensor]] = None,
+                             partial_decoding_idx=None, z_indices: Optional[Tensor] = None) -> Tensor:
+    """Net2NetTransformer.sample exactly as the reference runs it (ar_lm:154-227): one full L-token forward per generated token.
+    Partial decoding (ar_lm:161-165, 181-182): the cameras in ``partial_decoding_idx`` start from the ground-truth ids ``z_indices`` [B,C,T]
+    and their positions are skipped by the loop."""
     B = cond_ids.shape[0]
     C, T = cfg.num_cams, cfg.num_cam_tokens
     x = torch.full((B, C, T), cfg.vocab_size, dtype=torch.long)
+    fixed = set()
+    if partial_decoding_idx is not None:
+        fixed = {int(i) for i in partial_decoding_idx}
+        for i in fixed:
+            x[:, i, :] = z_indices[:, i]
     n_steps = cfg.num_img_tokens if steps is None else steps
     for s in range(n_steps):
         j = int(cfg.forward_shuffle_idx[s])
+        if j // T in fixed:
+            continue
         logits = gpt_forward(sd, cfg, x, cond_ids, I_inv, E_inv)[:, j]
         if logits_out is not None:
             logits_out.append(logits.clone())
@@ -421,9 +431,11 @@ class ARCache:
 
 def ar_sample_cached(sd, cfg, cond_ids: Tensor, I_inv: Tensor, E_inv: Tensor, *, temperature: float = 1.0, top_k: Optional[int] = None,
                      noise_u: Optional[Tensor] = None, steps: Optional[int] = None, logits_out: Optional[List[Tensor]] = None,
-                     teacher: Optional[Tensor] = None) -> Tensor:
+                     teacher: Optional[Tensor] = None, forced_ids: Optional[Tensor] = None) -> Tensor:
     """Same result as ``ar_sample_full_recompute`` via prefill + per-token decode.  ``teacher`` [B,C,T] forces the fed-back tokens
-    (teacher forcing for per-step logits comparisons); the returned ids are still the model's own picks."""
+    (teacher forcing for per-step logits comparisons); the returned ids are still the model's own picks.
+    ``forced_ids`` [steps, B] (decode order, >= 0 = emit that token, < 0 = draw): partial decoding with the KV cache - a fixed position still
+    appends its K/V row, it just does not draw (``partial_forced_ids`` builds the array from ``partial_decoding_idx`` + ground-truth ids)."""
     B = cond_ids.shape[0]
     C, T = cfg.num_cams, cfg.num_cam_tokens
     x = torch.full((B, C, T), cfg.vocab_size, dtype=torch.long)
@@ -435,10 +447,26 @@ def ar_sample_cached(sd, cfg, cond_ids: Tensor, I_inv: Tensor, E_inv: Tensor, *,
         if logits_out is not None:
             logits_out.append(logits.clone())
         ix = pick_token(logits, temperature, top_k, None if noise_u is None else noise_u[s])
+        if forced_ids is not None:
+            ix = torch.where(forced_ids[s] >= 0, forced_ids[s], ix)
         x[:, j // T, j % T] = ix
         if s + 1 < n_steps:
             cache.append(s, ix if teacher is None else teacher[:, j // T, j % T])
     return x
+
+
+def partial_forced_ids(cfg, partial_decoding_idx, z_indices: Tensor, steps: Optional[int] = None) -> Tensor:
+    """[steps, B] forced-token array of a partial decode: step s of the decode order visits token j = forward_shuffle_idx[s] = (camera j // T,
+    position j % T); cameras in ``partial_decoding_idx`` emit their ground-truth id, the others -1."""
+    T = cfg.num_cam_tokens
+    n_steps = cfg.num_img_tokens if steps is None else steps
+    fixed = {int(i) for i in partial_decoding_idx}
+    out = torch.full((n_steps, z_indices.shape[0]), -1, dtype=torch.long)
+    for s in range(n_steps):
+        j = int(cfg.forward_shuffle_idx[s])
+        if j // T in fixed:
+            out[s] = z_indices[:, j // T, j % T]
+    return out
 
 
 # ================================================================================================
