@@ -109,10 +109,15 @@ void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const floa
 }
 
 // ------------------------------------------------------------------------------------------------ prefill
-void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s) {
+// samples_per_layout = S > 1 (BASELINE config 5): consecutive groups of S sequences share their condition (BEV ids and cameras), so the condition
+// prefix is pushed through the stack once per LAYOUT (B / S sequences) and its K/V rows are then replicated into the S cache slots of the group.
+void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s, int samples_per_layout) {
     const auto& g = c.cfg;
     BG_REQUIRE(g.route == BEVGEN_ROUTE_AR, "context was not created for the autoregressive route");
     BG_REQUIRE(B >= 1, "batch must be positive");
+    const int S = samples_per_layout < 1 ? 1 : samples_per_layout;
+    BG_REQUIRE(B % S == 0, "batch %d is not a multiple of samples_per_layout %d", B, S);
+    const int G = B / S;   // layouts = sequences actually prefilled
     const int D = c.D, H = c.H, K = c.K, L = c.L;
     auto& st = c.ars;
     // persistent per-batch state
@@ -134,8 +139,8 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     HIP_CHECK(hipMemsetAsync(st.d_step, 0, sizeof(int), s));
 
     // workspace: the decode-step buffers first (stable addresses), then the prefill activations
-    const size_t rows = (size_t)B * K;
-    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)B * H * K * 64) * sizeof(float) + 16 * 256;
+    const size_t rows = (size_t)G * K;
+    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)G * H * K * 64) * sizeof(float) + (size_t)G * (K * 8 + (size_t)(g.num_cams + 1) * D * 4) + 24 * 256;
     c.arena.reserve(step_ws_bytes(c, B) + pre_b);
     c.arena.reset();
     (void)step_ws(c, B);
@@ -145,12 +150,21 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     float* h = c.arena.get<float>(rows * D);
     float* qkv = c.arena.get<float>(rows * 3 * D);
     float* m1 = c.arena.get<float>(rows * 4 * D);
-    float* Q = c.arena.get<float>((size_t)B * H * K * 64);
+    float* Q = c.arena.get<float>((size_t)G * H * K * 64);
 
-    if (g.image_embed)
+    if (g.image_embed)   // per-sequence state of the decode steps: for all B sequences
         launch_camera_embed(I_inv, E_inv, c.image_plane, c.pf("img_embed.weight"), c.pf("cam_embed.weight"), st.img_embed, st.c_embed, B, g.num_cams, c.T, D, s);
-    launch_cond_embed(cond, c.pf("cond_tok_emb.weight"), c.pf("cond_pos_emb"), g.bev_embed ? c.pf("bev_grid") : nullptr, g.bev_embed ? c.pf("bev_embed.weight") : nullptr,
-                      g.bev_embed ? c.pf("bev_embed.bias") : nullptr, g.bev_embed ? c.pf("bev_cam_pos_emb") : nullptr, st.c_embed, x, B, g.num_cams, K, D,
+    const int64_t* cond_g = cond;
+    const float* c_embed_g = st.c_embed;
+    if (S > 1) {   // first sequence of every group -> contiguous [G, ...] inputs of the prefill
+        int64_t* cg = c.arena.get<int64_t>((size_t)G * K);
+        float* eg = c.arena.get<float>((size_t)G * g.num_cams * D);
+        HIP_CHECK(hipMemcpy2DAsync(cg, (size_t)K * 8, cond, (size_t)S * K * 8, (size_t)K * 8, G, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpy2DAsync(eg, (size_t)g.num_cams * D * 4, st.c_embed, (size_t)S * g.num_cams * D * 4, (size_t)g.num_cams * D * 4, G, hipMemcpyDeviceToDevice, s));
+        cond_g = cg; c_embed_g = eg;
+    }
+    launch_cond_embed(cond_g, c.pf("cond_tok_emb.weight"), c.pf("cond_pos_emb"), g.bev_embed ? c.pf("bev_grid") : nullptr, g.bev_embed ? c.pf("bev_embed.weight") : nullptr,
+                      g.bev_embed ? c.pf("bev_embed.bias") : nullptr, g.bev_embed ? c.pf("bev_cam_pos_emb") : nullptr, c_embed_g, x, G, g.num_cams, K, D,
                       g.cond_vocab_size, s);
     BG_REQUIRE(cache_dtype(c) == 0, "prefill with a bf16 KV cache is not implemented yet");
     const size_t layer_elems = (size_t)B * H * L * 64;
@@ -160,10 +174,10 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
         float* vc = reinterpret_cast<float*>(st.vcache) + i * layer_elems;
         launch_layernorm(x, D, l.ln1_w, l.ln1_b, xn, D, (int)rows, D, 1e-5f, s);
         gemm(xn, D, l.wqkv, D, l.bqkv, qkv, 3 * D, (int)rows, 3 * D, D, ACT_NONE, nullptr, 0, s);
-        launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, B, H, K, 0, L, s);
+        launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, G, H, K, 0, L, s);   // cache slots [0, G) for now
         AttnArgs a{};
         a.Q = Q; a.K = kc; a.V = vc; a.bias = c.prefill_bias; a.R = xn; a.O = x2;
-        a.B = B; a.H = H; a.Nq = K; a.Nk_pad = c.Kpad;
+        a.B = G; a.H = H; a.Nq = K; a.Nk_pad = c.Kpad;
         a.q_bstride = (long)H * K * 64; a.q_hstride = (long)K * 64;
         a.kv_bstride = (long)H * L * 64; a.kv_hstride = (long)L * 64;
         a.ldbias = c.Kpad; a.bias_head_stride = c.keep_heads > 1 ? (long)K * c.Kpad : 0; a.scale = 0.125f;
@@ -174,7 +188,17 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
         gemm(h, D, l.mlp0_w, D, l.mlp0_b, m1, 4 * D, (int)rows, 4 * D, D, ACT_GELU, nullptr, 0, s);
         gemm(m1, 4 * D, l.mlp2_w, 4 * D, l.mlp2_b, x, D, (int)rows, D, 4 * D, ACT_NONE, x2, D, s);
     }
-    launch_gather_rows(x, st.hidden, B, K - 1, K, D, s);
+    if (S == 1) {
+        launch_gather_rows(x, st.hidden, B, K - 1, K, D, s);
+        return;
+    }
+    // fan the shared prefix out: slot g -> slots [g*S, g*S + S), highest group first (a destination never holds a source that is still needed)
+    for (int gi = G - 1; gi >= 0; --gi)
+        launch_replicate_prefix(st.kcache, st.vcache, g.num_layers, B, H, L, K, gi, gi * S, S, (int)cache_elem_bytes(c), s);
+    float* hid = c.arena.get<float>((size_t)G * D);
+    launch_gather_rows(x, hid, G, K - 1, K, D, s);
+    for (int j = 0; j < S; ++j)
+        HIP_CHECK(hipMemcpy2DAsync(st.hidden + (size_t)j * D, (size_t)S * D * 4, hid, (size_t)D * 4, (size_t)D * 4, G, hipMemcpyDeviceToDevice, s));
 }
 
 void ar_logits(Ctx& c, float* logits, hipStream_t s) {
@@ -231,10 +255,9 @@ void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s) {
 
 void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
                const float* noise_u, int samples_per_layout, const int64_t* forced, int64_t* out, float* step_logits, hipStream_t s) {
-    (void)samples_per_layout;
     BG_REQUIRE(steps >= 1 && steps <= c.N, "steps=%d out of range [1,%d]", steps, c.N);
     BG_REQUIRE(greedy || noise_u, "stochastic sampling needs explicit uniform noise d_noise_u [steps, B]");
-    ar_prefill(c, cond, I_inv, E_inv, B, s);
+    ar_prefill(c, cond, I_inv, E_inv, B, s, samples_per_layout);
     auto& st = c.ars;
     c.arena.reset();
     StepWs w = step_ws(c, B);

@@ -136,7 +136,7 @@ void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const flo
 // ar.cpp
 void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const float* v, const int64_t* layout, const float* mask, const float* add, int B, int H,
                               int L, int block, float* out, hipStream_t s);
-void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s);
+void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s, int samples_per_layout = 1);
 void ar_logits(Ctx& c, float* logits, hipStream_t s);
 void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s);
 void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
@@ -160,6 +160,7 @@ void launch_ar_step_embed(const int64_t* tok, const float* tok_emb, const float*
                           float* x, int B, int C, int T, int D, int vocab_rows, hipStream_t s);
 void launch_store_tokens(const int64_t* tok, const int64_t* fwd_idx, const int* d_step, int64_t* out, int B, int N, hipStream_t s);
 void launch_gather_rows(const float* x, float* out, int B, int row, int rows_per_batch, int D, hipStream_t s);
+void launch_replicate_prefix(void* kc, void* vc, int layers, int B, int H, int L, int rows, int src, int dst0, int count, int elem_bytes, hipStream_t s);
 void launch_increment(int* p, hipStream_t s);
 void launch_relayout_conv_weight(const float* w_oihw, float* w_ohwi, int cout, int cin, int kh, int kw, hipStream_t s);
 void launch_fuse_qkv(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, float* w, float* b, int D, hipStream_t s);

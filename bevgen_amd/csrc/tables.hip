@@ -105,6 +105,29 @@ void launch_gather_rows(const float* x, float* out, int B, int row, int rows_per
     LAUNCH_CHECK();
 }
 
+// Shared condition prefix (BASELINE config 5: several samples per BEV layout): copy the first `rows` cache rows of sequence slot `src` to the
+// slots [dst0, dst0 + count) of every layer and head; cache layout [layer][B][H][L][64] (elem_bytes per element), src itself is skipped.
+__global__ void replicate_prefix_kernel(char* __restrict__ kc, char* __restrict__ vc, int B, int H, int L, int rows, int src, int dst0, int count, int elem_bytes) {
+    const int layer = blockIdx.z, h = blockIdx.y;
+    const long row_b = 64L * elem_bytes;
+    const long blk = ((long)layer * B * H + h) * L * row_b;                 // + slot * H * L * row_b
+    const long slot_b = (long)H * L * row_b;
+    const long n16 = (long)rows * row_b / 16;
+    for (int j = 0; j < count; ++j) {
+        const int d = dst0 + j;
+        if (d == src) continue;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+            reinterpret_cast<uint4*>(kc + blk + d * slot_b)[i] = reinterpret_cast<const uint4*>(kc + blk + src * slot_b)[i];
+            reinterpret_cast<uint4*>(vc + blk + d * slot_b)[i] = reinterpret_cast<const uint4*>(vc + blk + src * slot_b)[i];
+        }
+    }
+}
+void launch_replicate_prefix(void* kc, void* vc, int layers, int B, int H, int L, int rows, int src, int dst0, int count, int elem_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(replicate_prefix_kernel, dim3(8, H, layers), dim3(256), 0, s, reinterpret_cast<char*>(kc), reinterpret_cast<char*>(vc), B, H, L, rows, src, dst0, count,
+                       elem_bytes);
+    LAUNCH_CHECK();
+}
+
 __global__ void increment_kernel(int* p) { *p += 1; }
 void launch_increment(int* p, hipStream_t s) {
     hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(1), 0, s, p);
