@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbevgen_hip.so")
+LIB_PATH = os.environ.get("BEVGEN_LIB_PATH") or os.path.join(_HERE, "csrc", "libbevgen_hip.so")   # override: A/B runs of two builds on one GPU box
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevgen_hip.h")
 
 ABI_VERSION = 1
