@@ -1,9 +1,19 @@
+#!/bin/bash
+# SQ-level PMC counters of the LDS-DMA GEMM over tools/gemm_probe.py (one --pmc pass, kernel trace only)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-for c in 2 0; do
-export BEVGEN_GLDS_CONFIG=$c
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_sq_$c -o sq --output-format csv -- python $R/tools/gemm_probe.py 3 3 > $R/gpurun_out/pmc_sq_$c.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $R/gpurun_out/pmc_tcc_$c -o tcc --output-format csv -- python $R/tools/gemm_probe.py 3 3 > $R/gpurun_out/pmc_tcc_$c.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_MISS_sum TCC_REQ_sum -d $R/gpurun_out/pmc_tcc2_$c -o tcc --output-format csv -- python $R/tools/gemm_probe.py 3 3 > $R/gpurun_out/pmc_tcc2_$c.log 2>&1
-done
-ls -R $R/gpurun_out | head -50
+R=${GRAFT_REPO_ROOT:-/root/repo}
+rm -rf $R/gpurun_out/pmc_sq
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_sq -o sq --output-format csv -- python $R/tools/gemm_probe.py 3 3 24576,1024,4096 > $R/gpurun_out/pmc_sq.log 2>&1
+python - <<PY
+import csv, collections, glob
+f = glob.glob("$R/gpurun_out/pmc_sq/**/*counter_collection.csv", recursive=True)[0]
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if "glds" in r["Kernel_Name"]:
+        agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+m = {k: sum(v) / len(v) for k, v in agg.items()}
+wc = m["SQ_WAVE_CYCLES"]
+print({k: f"{v:.4g}" for k, v in m.items()})
+print("wait_any %.3f  wait_inst %.3f (lds %.3f)  active %.3f | mfma busy / (GUI_ACTIVE/8 * 1024 SIMDs) = %.3f" % (m["SQ_WAIT_ANY"] / wc, m["SQ_WAIT_INST_ANY"] / wc, m["SQ_WAIT_INST_LDS"] / wc, m["SQ_ACTIVE_INST_ANY"] / wc, m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)))
+PY
+rm -rf $R/gpurun_out/pmc_sq
