@@ -11,7 +11,10 @@ Inputs (BEV token ids, camera matrices) and random-init weights of the reference
 HBM before the timed region.  N > 1: independent scenes are sharded over ranks (weak scaling, 16 scenes per GPU), no data-path
 collective; the only RCCL traffic is the final gather of the uint8 pixels to rank 0 (inside the timed region).
 
-One JSON line on rank 0 carries: the headline metric, `roofline` for the dominant kernel of the workload (fp32 MFMA GEMM),
+Default arithmetic mode: f16x3 (every GEMM / conv / attention product as three f16 MFMAs on hi/lo splits, fp32 accumulation: fp32-class accuracy,
+bit-identical greedy tokens on every parity fixture); the line also carries a one-step `exact_fp32_mode` leg (exact fp32 MFMA).
+
+One JSON line on rank 0 carries: the headline metric, `roofline` for the dominant kernel of the workload (the LDS-DMA split-precision GEMM),
 `roofline_decode_attention` (the HBM-bound Route A decode-attention kernel the north star names; measured on BASELINE config 4
 at N=1), `ms_per_decode_step`, and `cpu_baseline` (the CPU oracle timed on this host on a bounded sample).
 """
