@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         dl[0] = make_uint2(rvl.x, rvl.y); dl[1] = make_uint2(rvl.z, rvl.w);
     };
 
-    const float c_lo = kLoI * a.scale;
     const int ntiles = a.Nk_pad / SKT;
     // bias row segment of a key tile (this lane's 16 keys), fetched one tile ahead: an L2 round trip is longer than the QK^T MFMAs in front of it
     float4 bv[4];
@@ -93,18 +92,18 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         if (more) gload(tile + 1);
 
         // ---- S^T = K Q^T
-        f32x16 sM, sC, sD;  // main, and two correction accumulators so that no MFMA depends on its predecessor
+        f32x16 sM, sC;  // main and correction accumulator (the two correction products of a k-step are chained on sC with the main MFMA between them)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sM[r] = 0.f; sC[r] = 0.f; sD[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { sM[r] = 0.f; sC[r] = 0.f; }
         const _Float16* kh = &Kh[cur][qi * SKLD + 8 * h];
         const _Float16* kl = &Kl[cur][qi * SKLD + 8 * h];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const half8 ah = *reinterpret_cast<const half8*>(kh + 16 * s);
             const half8 al = *reinterpret_cast<const half8*>(kl + 16 * s);
-            sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], sM, 0, 0, 0);
             sC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], sC, 0, 0, 0);
-            sD = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], sD, 0, 0, 0);
+            sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], sM, 0, 0, 0);
+            sC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], sC, 0, 0, 0);
         }
 
         // ---- scale + bias, online softmax
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
             const float bb[4] = {bv[g].x, bv[g].y, bv[g].z, bv[g].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                sv[4 * g + j] = fmaf(sC[4 * g + j] + sD[4 * g + j], c_lo, fmaf(sM[4 * g + j], a.scale, bb[j]));
+                sv[4 * g + j] = fmaf(sC[4 * g + j], kLoI, sM[4 * g + j]) + bb[j];   // the score scale lives in the Q planes
                 mx = fmaxf(mx, sv[4 * g + j]);
             }
         }
@@ -129,9 +128,11 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
         for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(sv[r] - m_new);   // scores are in the base-2 domain (scale, bias pre-multiplied by log2 e)
             psum += p;
+            // p in [0,1] = hi + lo with lo stored UNSCALED: |lo| <= 2^-12, and what the f16 subnormal range drops is below 2^-25 ABSOLUTE, which is
+            // what matters for a probability (a weight of the row sum); saves the 2^11 scaling and lets V_hi P_lo accumulate straight into oM
             const _Float16 hi = (_Float16)p;
             ph[r >> 3][r & 7] = hi;
-            pl[r >> 3][r & 7] = (_Float16)((p - (float)hi) * kLo);
+            pl[r >> 3][r & 7] = (_Float16)(p - (float)hi);
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -160,10 +161,10 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
             // interleave the two head-dim halves so that consecutive MFMAs never share an accumulator
             oM[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[0], ph[s], oM[0], 0, 0, 0);
             oM[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[1], ph[s], oM[1], 0, 0, 0);
-            oC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[0], pl[s], oC[0], 0, 0, 0);
-            oC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[1], pl[s], oC[1], 0, 0, 0);
-            oC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[0], ph[s], oC[0], 0, 0, 0);
+            oC[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[0], ph[s], oC[0], 0, 0, 0);   // V_lo (scaled 2^11) P_hi
             oC[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[1], ph[s], oC[1], 0, 0, 0);
+            oM[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[0], pl[s], oM[0], 0, 0, 0);   // V_hi P_lo (unscaled)
+            oM[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[1], pl[s], oM[1], 0, 0, 0);
         }
 
         if (more) lstore(cur ^ 1);
@@ -206,7 +207,7 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
 }
 
 __global__ __launch_bounds__(256) void muse_q_prep_split_kernel(const float* __restrict__ qraw, const float* __restrict__ q_scale, _Float16* __restrict__ Qh,
-                                                                _Float16* __restrict__ Ql, int H, int Nq, long total) {
+                                                                _Float16* __restrict__ Ql, int H, int Nq, long total, float post) {
     const int lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= total) return;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void muse_q_prep_split_kernel(const float* __r
     const long b = bn / Nq;
     const float v = qraw[bn * (H * 64) + h * 64 + lane] * 8.0f;
     const float nrm = fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);
-    const float q = (v / nrm) * q_scale[lane];
+    const float q = ((v / nrm) * q_scale[lane]) * post;
     _Float16 hi, lo;
     split1(q, hi, lo);
     const long dst = ((b * H + h) * Nq + n) * 64 + lane;
@@ -224,10 +225,10 @@ __global__ __launch_bounds__(256) void muse_q_prep_split_kernel(const float* __r
     Ql[dst] = lo;
 }
 
-void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, hipStream_t s) {
+void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, float post, hipStream_t s) {
     const long total = (long)B * Nq * H;
     hipLaunchKernelGGL(muse_q_prep_split_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, s, qraw, q_scale, reinterpret_cast<_Float16*>(Qh),
-                       reinterpret_cast<_Float16*>(Ql), H, Nq, total);
+                       reinterpret_cast<_Float16*>(Ql), H, Nq, total, post);
     LAUNCH_CHECK();
 }
 

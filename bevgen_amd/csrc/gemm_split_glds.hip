@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
                     half4_t hi4, lo4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float qv = (v[j][qq * 4 + e] / nrm) * sc[e];
+                        const float qv = ((v[j][qq * 4 + e] / nrm) * sc[e]) * g.epi_post;   // epi_post: the attention's score scale, folded into q
                         hi4[e] = split_hi(qv);
                         lo4[e] = split_lo(qv, hi4[e]);
                     }

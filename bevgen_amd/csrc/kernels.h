@@ -45,6 +45,7 @@ struct GemmArgs {
     void* epi_hi = nullptr;
     void* epi_lo = nullptr;
     int epi_rows = 0, epi_heads = 0;
+    float epi_post = 1.f;             // EPI_MUSE_Q: extra factor on the prepared query (the attention kernel's score scale, folded in here)
     int a_bytes = 0;                  // MODE_CONV3: size of the activation plane image (buffer-resource bound), filled in by the launcher
     int tile_band = 0, diag = 0;      // tile-order band height (0 = row-major) / diagnostic all-L2-hit mode; filled in by the launcher
 };
@@ -97,7 +98,8 @@ struct AttnArgs {
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
 // Split-precision flash attention (attention_split.hip): operands pre-split into (hi, lo) f16 planes by the preparation kernels.
-//   The softmax is evaluated in the base-2 domain: `scale` and `bias` must arrive PRE-MULTIPLIED by log2(e) (kLog2e below).
+//   The softmax is evaluated in the base-2 domain: `bias` must arrive PRE-MULTIPLIED by log2(e) (kLog2e below) and the score scale (x log2 e) must
+//   already be folded into the Q planes (EPI_MUSE_Q epilogue / muse_q_prep_split's `post` factor); `scale` is ignored.
 //   Qh/Ql [B,H,Nq,64], Kh/Kl [B,H,Nk_pad,64], VTh/VTl [B,H,64,Nk_pad] (V transposed); bias / output conventions as AttnArgs.
 constexpr float kLog2e = 1.44269504088896340736f;
 struct AttnSplitArgs {
@@ -110,7 +112,7 @@ struct AttnSplitArgs {
     _Float16* Op;   // non-null: write the output as interleaved (hi, lo) planes of the [B*Nq, H*64] matrix instead of fp32 O
 };
 void launch_attention_split(const AttnSplitArgs& a, hipStream_t s);
-void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, hipStream_t s);
+void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, float post, hipStream_t s);
 void launch_muse_kv_prep_split(const float* kvraw, const float* null_kv, const float* k_scale, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nk,
                                int Nk_pad, hipStream_t s);
 

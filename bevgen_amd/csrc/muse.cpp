@@ -65,6 +65,7 @@ void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_
     g.M = B * Nq; g.N = H * 64; g.K = D;
     g.lda = lda; g.ldb = D; g.ldc = H * 64;
     g.epi = EPI_MUSE_Q; g.epi_scale = q_scale; g.epi_hi = Qh; g.epi_lo = Ql; g.epi_rows = Nq; g.epi_heads = H;
+    g.epi_post = 8.0f * kLog2e;   // sim = 8 q.k (muse_net:150) in the base-2 domain of the split attention kernel
     launch_gemm(g, s);
 }
 
