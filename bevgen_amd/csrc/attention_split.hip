@@ -93,12 +93,18 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
 
         // ---- S^T = K Q^T
         f32x16 sM, sC;  // main and correction accumulator (the two correction products of a k-step are chained on sC with the main MFMA between them)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sM[r] = 0.f; sC[r] = 0.f; }
         const _Float16* kh = &Kh[cur][qi * SKLD + 8 * h];
         const _Float16* kl = &Kl[cur][qi * SKLD + 8 * h];
+        {   // first k-step: accumulate onto the inline constant 0 (no 32 v_mov per tile to clear the accumulators)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const half8 ah = *reinterpret_cast<const half8*>(kh);
+            const half8 al = *reinterpret_cast<const half8*>(kl);
+            sC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[0], zero, 0, 0, 0);
+            sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[0], zero, 0, 0, 0);
+            sC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[0], sC, 0, 0, 0);
+        }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 1; s < 4; ++s) {
             const half8 ah = *reinterpret_cast<const half8*>(kh + 16 * s);
             const half8 al = *reinterpret_cast<const half8*>(kl + 16 * s);
             sC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], sC, 0, 0, 0);
