@@ -85,11 +85,16 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
     gload_bias(0);
     gload(0);
     lstore(0);
+    if (ntiles > 1) gload(1);
     __syncthreads();
     int cur = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
         const bool more = tile + 1 < ntiles;
-        if (more) gload(tile + 1);
+        // staging (guide T14, "write after the barrier"): the registers hold tile+1 (requested one iteration ago); it goes into the buffer the previous
+        // iteration just finished reading, and the same registers are re-issued at once for tile+2 - the ds_writes no longer queue behind this
+        // iteration's MFMAs in front of the barrier
+        if (more) lstore(cur ^ 1);
+        if (tile + 2 < ntiles) gload(tile + 2);
 
         // ---- S^T = K Q^T
         f32x16 sM, sC;  // main and correction accumulator (the two correction products of a k-step are chained on sC with the main MFMA between them)
@@ -173,7 +178,6 @@ __global__ __launch_bounds__(256, 2) void attention_split_kernel(AttnSplitArgs a
             oM[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[1], pl[s], oM[1], 0, 0, 0);
         }
 
-        if (more) lstore(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
