@@ -127,7 +127,7 @@ def cpu_baseline_route_m(cams):
             "reference_schedule_value": 1.0 / scene_ref_alg}
 
 
-def decode_leg(device, batch, steps):
+def decode_leg(device, batch, steps, kv_cache="f32"):
     """Route A (BASELINE config 4: nuScenes 6-view 224x400, 24 layers, L=2368, blk 16, camera bias): greedy decode of `steps`
     tokens for `batch` sequences; returns ms/step and the decode-attention roofline from HIP events."""
     from bevgen_amd import presets, synthetic
@@ -135,7 +135,7 @@ def decode_leg(device, batch, steps):
     from bevgen_amd.weights import gpt_state_dict
 
     cfg = presets.config4()
-    ctx = Context(cfg, route="ar", device=device, max_batch=batch)
+    ctx = Context(cfg, route="ar", device=device, max_batch=batch, kv_cache=kv_cache)
     ctx.load_state_dict(gpt_state_dict(cfg, 1234))
     ctx.set_tables()
     ctx.finalize()
@@ -165,9 +165,9 @@ def decode_leg(device, batch, steps):
     out = {
         "ms_per_decode_step": wall * 1e3 / steps,
         "decode_prefill_ms": prefill_ms,
-        "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("decode_attention_kernel"),
+        "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("decode_attention_kernel") if kv_cache == "f32" else None,
                                       "launches": int(da["launches"]), "avg_us": da["ms"] * 1e3 / max(da["launches"], 1),
-                                      "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of a full decode, fp32 KV cache, L=2368"},
+                                      "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of a full decode, {kv_cache} KV cache, L=2368"},
         "decode_scenes_per_s": batch / wall,
         "decode_weight_stream": {"achieved_GBs": gs["work"] / (gs["ms"] * 1e-3) / 1e9 if gs["ms"] > 0 else 0.0, "launches": int(gs["launches"])},
     }
@@ -262,6 +262,10 @@ def main():
                                    "note": "bit-exact-parity mode (every product in fp32 on the matrix cores), same workload, 1 step"}
     if world == 1 and not args.no_decode_leg:
         line.update(decode_leg(local_rank, args.decode_batch, args.decode_steps))
+        # BASELINE config 4 names fp16 storage: the same decode with the KV cache stored as fp16 (fp32 accumulate; tokens not guaranteed bit-exact)
+        f16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16")
+        line["decode_f16_kv_cache"] = {"ms_per_decode_step": f16["ms_per_decode_step"], "decode_scenes_per_s": f16["decode_scenes_per_s"],
+                                       "roofline_decode_attention": f16["roofline_decode_attention"]}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_route_m(args.cams)
     print(json.dumps(line), flush=True)

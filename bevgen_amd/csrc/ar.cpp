@@ -23,8 +23,8 @@ void gemm(const float* A, int lda, const float* W, int ldb, const float* bias, f
     launch_gemm(g, s);
 }
 
-size_t cache_elem_bytes(const Ctx& c) { return c.cfg.precision == BEVGEN_PRECISION_BF16 ? 2 : 4; }
-int cache_dtype(const Ctx& c) { return c.cfg.precision == BEVGEN_PRECISION_BF16 ? 1 : 0; }
+size_t cache_elem_bytes(const Ctx& c) { return c.cfg.kv_cache_dtype == BEVGEN_KV_F16 ? 2 : 4; }
+int cache_dtype(const Ctx& c) { return c.cfg.kv_cache_dtype == BEVGEN_KV_F16 ? 1 : 0; }
 
 struct StepWs {
     float *x, *xn, *qkv, *x2, *h, *m1, *dec_ws, *gemm_ws, *logits;
@@ -140,7 +140,8 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
 
     // workspace: the decode-step buffers first (stable addresses), then the prefill activations
     const size_t rows = (size_t)G * K;
-    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)G * H * K * 64) * sizeof(float) + (size_t)G * (K * 8 + (size_t)(g.num_cams + 1) * D * 4) + 24 * 256;
+    const size_t tmp_kv = cache_dtype(c) ? (size_t)2 * G * H * c.Kpad * 64 : 0;   // fp16 cache: the prefill attention reads exact fp32 K/V from a scratch pair
+    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)G * H * K * 64 + tmp_kv) * sizeof(float) + (size_t)G * (K * 8 + (size_t)(g.num_cams + 1) * D * 4) + 32 * 256;
     c.arena.reserve(step_ws_bytes(c, B) + pre_b);
     c.arena.reset();
     (void)step_ws(c, B);
@@ -166,20 +167,31 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     launch_cond_embed(cond_g, c.pf("cond_tok_emb.weight"), c.pf("cond_pos_emb"), g.bev_embed ? c.pf("bev_grid") : nullptr, g.bev_embed ? c.pf("bev_embed.weight") : nullptr,
                       g.bev_embed ? c.pf("bev_embed.bias") : nullptr, g.bev_embed ? c.pf("bev_cam_pos_emb") : nullptr, c_embed_g, x, G, g.num_cams, K, D,
                       g.cond_vocab_size, s);
-    BG_REQUIRE(cache_dtype(c) == 0, "prefill with a bf16 KV cache is not implemented yet");
-    const size_t layer_elems = (size_t)B * H * L * 64;
+    const int kvd = cache_dtype(c);
+    float *tk = nullptr, *tv = nullptr;
+    if (kvd) {
+        tk = c.arena.get<float>((size_t)G * H * c.Kpad * 64);
+        tv = c.arena.get<float>((size_t)G * H * c.Kpad * 64);
+        HIP_CHECK(hipMemsetAsync(tk, 0, (size_t)G * H * c.Kpad * 64 * sizeof(float), s));   // pad rows K..Kpad stay zero
+        HIP_CHECK(hipMemsetAsync(tv, 0, (size_t)G * H * c.Kpad * 64 * sizeof(float), s));
+    }
+    const size_t layer_bytes_p = (size_t)B * H * L * 64 * cache_elem_bytes(c);
     for (int i = 0; i < g.num_layers; ++i) {
         const ArLayer& l = c.ar[i];
-        float* kc = reinterpret_cast<float*>(st.kcache) + i * layer_elems;
-        float* vc = reinterpret_cast<float*>(st.vcache) + i * layer_elems;
+        char* kcb = reinterpret_cast<char*>(st.kcache) + i * layer_bytes_p;
+        char* vcb = reinterpret_cast<char*>(st.vcache) + i * layer_bytes_p;
+        float* kc = kvd ? tk : reinterpret_cast<float*>(kcb);   // what the prefill attention reads
+        float* vc = kvd ? tv : reinterpret_cast<float*>(vcb);
+        const int Lk = kvd ? c.Kpad : L;                        // row capacity per (sequence, head) of that buffer
         launch_layernorm(x, D, l.ln1_w, l.ln1_b, xn, D, (int)rows, D, 1e-5f, s);
         gemm(xn, D, l.wqkv, D, l.bqkv, qkv, 3 * D, (int)rows, 3 * D, D, ACT_NONE, nullptr, 0, s);
-        launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, G, H, K, 0, L, s);   // cache slots [0, G) for now
+        launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, G, H, K, 0, Lk, s);   // cache slots [0, G) for now
+        if (kvd) launch_ar_qkv_scatter(qkv, nullptr, kcb, vcb, kvd, G, H, K, 0, L, s);   // the fp16 image the decode steps read
         AttnArgs a{};
         a.Q = Q; a.K = kc; a.V = vc; a.bias = c.prefill_bias; a.R = xn; a.O = x2;
         a.B = G; a.H = H; a.Nq = K; a.Nk_pad = c.Kpad;
         a.q_bstride = (long)H * K * 64; a.q_hstride = (long)K * 64;
-        a.kv_bstride = (long)H * L * 64; a.kv_hstride = (long)L * 64;
+        a.kv_bstride = (long)H * Lk * 64; a.kv_hstride = (long)Lk * 64;
         a.ldbias = c.Kpad; a.bias_head_stride = c.keep_heads > 1 ? (long)K * c.Kpad : 0; a.scale = 0.125f;
         a.o_bstride = (long)K * D; a.o_qstride = D; a.o_hstride = 64;
         BG_REQUIRE(c.Kpad <= L, "condition length padded to %d exceeds the cache length %d", c.Kpad, L);

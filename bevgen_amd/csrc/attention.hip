@@ -183,16 +183,13 @@ template <> struct KvTraits<0> {  // fp32 rows: 256 B = 16 lanes x 16 B
         out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
     }
 };
-template <> struct KvTraits<1> {  // bf16 rows: 128 B = 8 lanes x 16 B
+template <> struct KvTraits<1> {  // fp16 rows: 128 B = 8 lanes x 16 B
     static constexpr int LPK = 8, DPL = 8;
     __device__ static __forceinline__ void load(const void* base, long row, int sub, float (&out)[8]) {
-        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + row * 64 + sub * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        const h8 v = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(base) + row * 64 + sub * 8);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            out[2 * i] = __uint_as_float(w[i] << 16);
-            out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-        }
+        for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
     }
 };
 
@@ -237,11 +234,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
             void* cache = const_cast<void*>(is_v ? a.vcache : a.kcache);
             const long idx = (cache_row0 + row) * 64 + d;
             if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
-            else {
-                uint32_t u = __float_as_uint(val);
-                u += 0x7fffu + ((u >> 16) & 1u);
-                reinterpret_cast<uint16_t*>(cache)[idx] = (uint16_t)(u >> 16);
-            }
+            else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)val;
         }
         __syncthreads();
     }

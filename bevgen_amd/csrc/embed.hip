@@ -165,12 +165,7 @@ void launch_muse_kv_prep(const float* kvraw, const float* null_kv, const float* 
 // ---------------------------------------------------------------------------------------------- Route A q/k/v scatter into the KV cache
 __device__ __forceinline__ void cache_store(void* cache, int kv_dtype, long idx, float v) {
     if (kv_dtype == 0) reinterpret_cast<float*>(cache)[idx] = v;
-    else {
-        // round-to-nearest-even fp32 -> bf16
-        uint32_t u = __float_as_uint(v);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        reinterpret_cast<uint16_t*>(cache)[idx] = (uint16_t)(u >> 16);
-    }
+    else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)v;   // fp16 storage (round to nearest even)
 }
 
 __global__ __launch_bounds__(256) void ar_qkv_scatter_kernel(const float* __restrict__ qkv, float* __restrict__ Q, void* kcache, void* vcache, int kv_dtype,

@@ -138,7 +138,7 @@ struct DecodeAttnArgs {
     int n_hint = 0;                  // host's copy of *d_n (profiling only)
     int Lmax = 0;
     float scale = 1.f;               // dh^-0.5, applied to (q.k + bias)
-    int kv_dtype = 0;                // 0 = fp32, 1 = bf16
+    int kv_dtype = 0;                // 0 = fp32, 1 = fp16 storage (fp32 accumulate)
     int shared_prefix = 0;           // reserved: leading keys shared by groups of `group` consecutive sequences
     int group = 1;
 };

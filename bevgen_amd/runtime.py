@@ -52,7 +52,7 @@ class Context:
     """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
-                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None):
+                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bevgen_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product")
@@ -69,6 +69,9 @@ class Context:
         self.precision = precision
         c.precision = {"fp32": _lib.PRECISION_FP32, "f16x3": _lib.PRECISION_F16X3}[precision]
         c.max_batch = max_batch
+        # Route A KV-cache storage: 'f32' (bit-exact tokens) or 'f16' (fp16 storage / fp32 accumulate, BASELINE config 4: half the decode traffic)
+        c.kv_cache_dtype = {"f32": _lib.KV_F32, "f16": _lib.KV_F16}[kv_cache]
+        self.kv_cache = kv_cache
         if cfg is not None:
             c.num_layers, c.num_heads, c.dim = cfg.num_layers, cfg.num_heads, cfg.num_embed
             c.vocab_size, c.cond_vocab_size = cfg.vocab_size, cfg.cond_vocab_size

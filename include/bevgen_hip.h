@@ -34,6 +34,7 @@ enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
  * F16X3 : large GEMMs / convolutions as 3 f16 MFMAs per k-step on (hi, lo*2^-11) splits of the fp32 operands: ~2^-22 relative error per product,
  *         fp32 accumulation, up to 5x the fp32 MFMA rate.  Everything else (attention, norms, samplers, decode-step GEMMs) stays fp32. */
 enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 /* reserved */, BEVGEN_PRECISION_F16X3 = 2 };
+enum { BEVGEN_KV_F32 = 0, BEVGEN_KV_F16 = 1 };
 enum { BEVGEN_DTYPE_F32 = 0, BEVGEN_DTYPE_I64 = 1, BEVGEN_DTYPE_U8 = 2, BEVGEN_DTYPE_F64 = 3 };
 
 enum {
@@ -64,7 +65,9 @@ typedef struct bevgen_cfg {
     int32_t vq_ch_mult[8];
     int32_t vq_attn_resolution;                        /* spatial size at which AttnBlocks are inserted (16) */
     int32_t vq_in_channels;                            /* encoder input channels (3 images / 7 Argoverse BEV classes); 0 = decoder only */
-    int32_t reserved[15];
+    int32_t kv_cache_dtype;                            /* Route A KV-cache storage: BEVGEN_KV_F32 (default, bit-exact tokens) or BEVGEN_KV_F16 (fp16 storage,
+                                                          fp32 accumulate: half the decode-attention HBM traffic; tokens no longer guaranteed identical) */
+    int32_t reserved[14];
 } bevgen_cfg;
 
 typedef struct bevgen_ctx bevgen_ctx;
