@@ -198,6 +198,8 @@ constexpr int DEC_UNROLL = 4;
 // partial results: ws[((b*H + h)*S + split)*66 + {0: m, 1: l, 2..65: o[64]}]
 // NW = waves per workgroup.  S == 1 (one workgroup sees the whole context): the epilogue normalises, adds the residual and writes O
 // directly - no workspace round trip, no second kernel.  S > 1: partials go to `ws` and decode_attention_combine_kernel merges them.
+constexpr float kLog2eDec = 1.44269504088896340736f;
+
 template <int DT, int NW>
 __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArgs a, float* __restrict__ ws, int S) {
     using T = KvTraits<DT>;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
     {
         const float* qp = a.q + (long)b * a.ldq + head * 64 + sub * DPL;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) qv[i] = qp[i] * a.scale;
+        for (int i = 0; i < DPL; ++i) qv[i] = qp[i] * (a.scale * kLog2eDec);   // scores live in the base-2 domain: exp(x) = 2^(x log2 e), one v_exp_f32
     }
     const long cache_row0 = ((long)b * a.H + head) * a.Lmax;
     const uint8_t* keep = a.keep ? a.keep + (long)head * a.keep_head_stride + (long)row * a.ldkeep : nullptr;
@@ -265,16 +267,16 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
             for (int o = LPK / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
             const int kc = min(key[u], k_end - 1);
             const bool ok = key[u] < k_end && (!keep || keep[kc]);
-            sc[u] = ok ? d + (bias_row ? bias_row[kc] * a.scale : 0.f) : kNegBig;
+            sc[u] = ok ? d + (bias_row ? bias_row[kc] * (a.scale * kLog2eDec) : 0.f) : kNegBig;
             mx = fmaxf(mx, sc[u]);
         }
-        const float alpha = expf(m_run - mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mx);
         l_run *= alpha;
 #pragma unroll
         for (int i = 0; i < DPL; ++i) acc[i] *= alpha;
 #pragma unroll
         for (int u = 0; u < DEC_UNROLL; ++u) {
-            const float p = sc[u] <= kNegBig ? 0.f : expf(sc[u] - mx);
+            const float p = sc[u] <= kNegBig ? 0.f : __builtin_amdgcn_exp2f(sc[u] - mx);
             l_run += p;
 #pragma unroll
             for (int i = 0; i < DPL; ++i) acc[i] = fmaf(p, vx[u][i], acc[i]);
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
     float m_all = m_run;
 #pragma unroll
     for (int o = LPK; o < 64; o <<= 1) m_all = fmaxf(m_all, __shfl_xor(m_all, o, 64));
-    const float f = expf(m_run - m_all);
+    const float f = __builtin_amdgcn_exp2f(m_run - m_all);
     l_run *= f;
 #pragma unroll
     for (int i = 0; i < DPL; ++i) acc[i] *= f;
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
         float l = 0.f, o = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const float fw = expf(red[w][0] - mm);
+            const float fw = __builtin_amdgcn_exp2f(red[w][0] - mm);
             l += red[w][1] * fw;
             o += red[w][2 + tid] * fw;
         }
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64) void decode_attention_combine_kernel(DecodeAttn
     for (int s = 0; s < S; ++s) mm = fmaxf(mm, p[s * 66]);
     float l = 0.f, o = 0.f;
     for (int s = 0; s < S; ++s) {
-        const float f = expf(p[s * 66] - mm);
+        const float f = __builtin_amdgcn_exp2f(p[s * 66] - mm);   // partial maxima are in the base-2 domain (decode_attention_kernel)
         l += p[s * 66 + 1] * f;
         o += p[s * 66 + 2 + d] * f;
     }
