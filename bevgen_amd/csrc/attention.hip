@@ -200,6 +200,18 @@ constexpr int DEC_UNROLL = 4;
 // directly - no workspace round trip, no second kernel.  S > 1: partials go to `ws` and decode_attention_combine_kernel merges them.
 constexpr float kLog2eDec = 1.44269504088896340736f;
 
+// all-reduce (sum) inside aligned groups of LPK = 8 or 16 lanes with DPP row operations (VALU speed) instead of ds_bpermute round trips through
+// the LDS crossbar: quad_perm xor 1, quad_perm xor 2, row_half_mirror (lane i <-> 7-i of its 8), row_mirror (i <-> 15-i of its 16) - the mirror steps
+// are valid for a symmetric reduction because every lane of a quad already holds the quad's sum
+template <int LPK>
+__device__ __forceinline__ float group_sum(float d) {
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    if (LPK == 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xf, 0xf, true));   // row_mirror
+    return d;
+}
+
 template <int DT, int NW>
 __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArgs a, float* __restrict__ ws, int S) {
     using T = KvTraits<DT>;
@@ -263,8 +275,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
             float d = 0.f;
 #pragma unroll
             for (int i = 0; i < DPL; ++i) d = fmaf(qv[i], kx[u][i], d);
-#pragma unroll
-            for (int o = LPK / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            d = group_sum<LPK>(d);
             const int kc = min(key[u], k_end - 1);
             const bool ok = key[u] < k_end && (!keep || keep[kc]);
             sc[u] = ok ? d + (bias_row ? bias_row[kc] * (a.scale * kLog2eDec) : 0.f) : kNegBig;
