@@ -126,7 +126,7 @@ int gemm_skinny_ksplit(int M, int N, int K) {
     const int blocks = cdiv(N, SK_NT);
     int s = 1;
     // split across workgroups only for narrow layers, and keep >= 64 k per wave
-    while (blocks * s < 128 && K % (s * 2 * SK_WAVES * 16) == 0 && K / (s * 2 * SK_WAVES) >= 64) s *= 2;
+    while (blocks * s < 256 && K % (s * 2 * SK_WAVES * 16) == 0 && K / (s * 2 * SK_WAVES) >= 64) s *= 2;
     return s;
 }
 
