@@ -37,6 +37,8 @@ CASES: Dict[str, Case] = {
     # full-size models: token ids + a few logits rows only
     "a_config1": Case("a_config1", "a", presets.config1, 1234, 0, 1),  # BASELINE config 1: 24 layers, L=512, greedy, B=1
     "m_full_3cam": Case("m_full_3cam", "m", lambda: presets.config2(3), 1234, 0, 1, timesteps=18),  # released Argoverse shape
+    # BASELINE config 2 (the bench workload: 6 views of 256x256, N=1536, L=1792) at full size, 4 MaskGit iterations
+    "m_full_6cam": Case("m_full_6cam", "m", lambda: presets.config2(6), 1234, 0, 1, timesteps=4),
     # BASELINE config 4 at full size (nuScenes 6-view 224x400, L=2368, blk 16, centre-outward decode order): the first decode steps only
     "a_config4_head": Case("a_config4_head", "a", presets.config4, 1234, 0, 1, steps=6),
 }

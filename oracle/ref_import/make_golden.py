@@ -259,7 +259,7 @@ def main():
         print("keys")
         golden_keys()
     for name, case in cases.CASES.items():
-        full = name in ("a_config1", "m_full_3cam", "a_config4_head")
+        full = name in ("a_config1", "m_full_3cam", "m_full_6cam", "a_config4_head")
         if not want(name) or (full and args.skip_full):
             continue
         print(name)
