@@ -64,4 +64,6 @@ def maskgit_noise(case: Case, cfg, seed: int = 5):
 
 
 VQ_TINY = dict(dd=presets.VQ_DDCONFIG_TINY, n_embed=64, embed_dim=64, seed=99, n_images=3)
+# the released first-stage decoder at full size (f16: ch 128, ch_mult [1,1,2,2,4], 256x256, codebook 1024 x 256, configs/model/stage_2.yaml:36-55)
+VQ_FULL = dict(dd=presets.VQ_DDCONFIG_F16, n_embed=1024, embed_dim=256, seed=99, n_images=1)
 VQ_TINY_SEG = dict(dd=dict(presets.VQ_DDCONFIG_TINY, in_channels=7, out_ch=7), n_embed=64, embed_dim=64, seed=77, n_images=2)  # BEV cond stage (7 Argoverse classes)

@@ -181,6 +181,28 @@ def golden_route_a(case: cases.Case, full: bool):
 
 
 # ------------------------------------------------------------------------------------------------ VQGAN decode
+def golden_vq_full():
+    """Full-size f16 decoder (42 M parameters, 252 GFLOP per image): one image, pixels stored as float16 of the denormalised [0,1] output
+    (quantisation 2.4e-4, inside the 1e-3 parity tolerance) plus exact per-channel statistics of the fp32 reference output."""
+    v = cases.VQ_FULL
+    dd = v["dd"]
+    sd = cases.vq_state_dict(dd, v["n_embed"], v["embed_dim"], v["seed"], with_encoder=True)   # strict load in the reference; decoder tensors do not depend on it
+    lat = dd["resolution"] // 2 ** (len(dd["ch_mult"]) - 1)
+    vq = RM.build_ref_vqmodel(dd, v["n_embed"], v["embed_dim"], sd, (dd["resolution"],) * 2, (lat, lat))
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, v["n_embed"], (v["n_images"], lat * lat), generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        zq = vq.quantize.get_codebook_entry(ids.reshape(-1), shape=(v["n_images"], lat, lat, v["embed_dim"]))
+        xr = vq.decode(zq)
+        xd = stubs.import_reference().util.denormalize_tensor(xr, keep_tensor=True)
+    t_ref = time.time() - t0
+    xo = R.vq_decode_ids(sd, dd, ids, (lat, lat), denorm=False)
+    assert rel(xo, xr) < 2e-5, rel(xo, xr)
+    save("vq_full", ids=ids.to(torch.int16), pixels_denorm_f16=xd.to(torch.float16), raw_mean=xr.mean(dim=(0, 2, 3)), raw_absmax=np.array(float(xr.abs().max())),
+         raw_rows=xr[:, :, ::64, :].clone(), ref_decode_seconds=np.array(t_ref))
+
+
 def golden_vq():
     v = cases.VQ_TINY
     dd = v["dd"]
@@ -246,6 +268,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--vq-full", action="store_true", help="also (re)generate the full-size VQGAN decode golden")
     args = ap.parse_args()
     torch.manual_seed(0)
     want = lambda n: args.only is None or n in args.only
@@ -258,6 +281,9 @@ def main():
     if want("keys"):
         print("keys")
         golden_keys()
+    if (args.only is not None and "vq_full" in args.only) or (args.only is None and not args.skip_full) or args.vq_full:
+        print("vq_full")
+        golden_vq_full()
     for name, case in cases.CASES.items():
         full = name in ("a_config1", "m_full_3cam", "m_full_6cam", "a_config4_head")
         if not want(name) or (full and args.skip_full):
