@@ -36,6 +36,20 @@ def _null_ckpts(node: Any) -> None:
             _null_ckpts(v)
 
 
+def _cfg_nodes(node: Any, target: Any) -> List[dict]:
+    """every GPTConfig node of the model tree (the config is interpolated into several places: model.cfg, model.maskgit.transformer.cfg, ...)"""
+    out: List[dict] = []
+    if isinstance(node, dict):
+        if node.get("_target_") == target and "num_cams" in node:
+            out.append(node)
+        for v in node.values():
+            out.extend(_cfg_nodes(v, target))
+    elif isinstance(node, list):
+        for v in node:
+            out.extend(_cfg_nodes(v, target))
+    return out
+
+
 def _synthetic_batches(cfg, n_scenes: int, batch_size: int, seed: int) -> Iterable[Dict[str, Any]]:
     done = 0
     while done < n_scenes:
@@ -60,6 +74,9 @@ def main(argv: List[str] = None) -> int:
     ap.add_argument("--synthetic", type=int, default=0, metavar="N", help="generate N synthetic scenes instead of reading --batches")
     ap.add_argument("--batches", default=None, help="torch.save'd list of collated batch dicts")
     ap.add_argument("--random-weights", action="store_true", help="ignore every ckpt_path (deterministic generated weights)")
+    ap.add_argument("--synthetic-calibration", action="store_true",
+                    help="legacy_prob_matrix=false needs pretrained/cam_data_<dataset>.pt (the rig calibration the reference's dataset class writes); "
+                         "use a synthetic ring rig instead when that file is absent (smoke runs)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--print-config", action="store_true", help="print the composed configuration and exit")
     ap.add_argument("overrides", nargs="*")
@@ -68,9 +85,26 @@ def main(argv: List[str] = None) -> int:
     cfg = hydra_lite.compose(args.config_dir, args.config_name, args.overrides)
     if args.random_weights:
         _null_ckpts(cfg.get("model"))
+    if args.synthetic_calibration:
+        gcfg = (cfg.get("model") or {}).get("cfg") or ((cfg.get("model") or {}).get("transformer") or {}).get("cfg")
+        if isinstance(gcfg, dict) and not gcfg.get("legacy_prob_matrix", True):
+            name = str(gcfg.get("dataset", "NUSCENES")).lower()
+            if not os.path.exists(os.path.join("pretrained", f"cam_data_{name}.pt")):
+                intr, extr = synthetic.rig_calibration(int(gcfg["num_cams"]))
+                for node in _cfg_nodes(cfg.get("model"), gcfg.get("_target_")):
+                    node["cam_intrinsics"], node["cam_extrinsics"] = intr, extr
     if args.print_config:
         import yaml
-        yaml.safe_dump({k: v for k, v in cfg.items() if k != "hydra"}, sys.stdout, sort_keys=False)
+
+        def plain(v):
+            if isinstance(v, torch.Tensor):
+                return v.tolist()
+            if isinstance(v, dict):
+                return {k: plain(x) for k, x in v.items()}
+            if isinstance(v, list):
+                return [plain(x) for x in v]
+            return v
+        yaml.safe_dump(plain({k: v for k, v in cfg.items() if k != "hydra"}), sys.stdout, sort_keys=False)
         return 0
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
