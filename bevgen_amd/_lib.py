@@ -17,6 +17,7 @@ ABI_VERSION = 1
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
+DECODE_FUSED, DECODE_PER_OP = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_F64 = 0, 1, 2, 3
 
 
@@ -36,7 +37,7 @@ class bevgen_cfg(C.Structure):
         ("ff_inner", C.c_int32), ("max_batch", C.c_int32),
         ("vq_ch", C.c_int32), ("vq_num_res_blocks", C.c_int32), ("vq_z_channels", C.c_int32), ("vq_embed_dim", C.c_int32),
         ("vq_n_embed", C.c_int32), ("vq_resolution", C.c_int32), ("vq_out_ch", C.c_int32), ("vq_num_levels", C.c_int32),
-        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("vq_in_channels", C.c_int32), ("kv_cache_dtype", C.c_int32), ("reserved", C.c_int32 * 14),
+        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("vq_in_channels", C.c_int32), ("kv_cache_dtype", C.c_int32), ("decode_path", C.c_int32), ("reserved", C.c_int32 * 13),
     ]
 
 
@@ -75,6 +76,7 @@ SIGNATURES = {
     "bevgen_decode_attention_splits": (_i, [_i, _i, _i]),
     "bevgen_profile_begin": (_i, [_p]),
     "bevgen_profile_end": (_i, [_p, C.POINTER(C.c_double)]),
+    "bevgen_set_trace_buffer": (_i, [_p, _p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -288,4 +288,8 @@ int bevgen_profile_end(bevgen_ctx* ctx, double* out) {
     });
 }
 
+int bevgen_set_trace_buffer(bevgen_ctx* ctx, void* d_buf) {
+    return guarded(ctx, [&] { ctx->trace = reinterpret_cast<long long*>(d_buf); });
+}
+
 }  // extern "C"

@@ -28,9 +28,19 @@ int cache_dtype(const Ctx& c) { return c.cfg.kv_cache_dtype == BEVGEN_KV_F16 ? 1
 
 struct StepWs {
     float *x, *xn, *qkv, *x2, *h, *m1, *dec_ws, *gemm_ws, *logits;
+    float *x2b, *part;   // fused path: second x2 buffer (layers alternate), split-K partials of the MLP down-projection
     int64_t* tok;
     int splits;
 };
+
+bool fused_path(const Ctx& c, int B, int G) {
+    if (c.cfg.decode_path != BEVGEN_DECODE_FUSED) return false;
+    const int D = c.D;
+    return ar_attn_fused_supported(B, G, D, c.H) && skinny_fused_supported(B, 4 * D, D, true) && skinny_fused_supported(B, D, 4 * D, false) &&
+           skinny_fused_supported(B, c.V, D, true) && ((size_t)round_up(c.L, 4) + (size_t)G * D + G * 192 + 16 * (G + 1) * 66 + 16 * G) * 4 <= 64 * 1024;
+}
+
+size_t part_floats(const Ctx& c, int B) { return (size_t)skinny_fused_ksplit(c.D, 4 * c.D) * B * c.D; }
 
 StepWs step_ws(Ctx& c, int B) {
     // fixed layout at the start of the per-call arena (so a captured graph keeps seeing the same addresses)
@@ -50,6 +60,8 @@ StepWs step_ws(Ctx& c, int B) {
     w.gemm_ws = reinterpret_cast<float*>(a.alloc(gw));
     w.logits = a.get<float>((size_t)B * c.V);
     w.tok = a.get<int64_t>((size_t)B);
+    w.x2b = a.get<float>((size_t)B * D);
+    w.part = a.get<float>(part_floats(c, B));
     return w;
 }
 
@@ -59,7 +71,7 @@ size_t step_ws_bytes(const Ctx& c, int B) {
     const int S = decode_attention_splits(B, c.H, c.L);
     size_t gw = std::max(std::max(gemm_skinny_ws_bytes(B, 3 * D, D), gemm_skinny_ws_bytes(B, 4 * D, D)),
                          std::max(gemm_skinny_ws_bytes(B, D, 4 * D), gemm_skinny_ws_bytes(B, c.V, D)));
-    return f * sizeof(float) + decode_attention_ws_bytes(B, c.H, S) + gw + B * sizeof(int64_t) + 16 * 256;
+    return f * sizeof(float) + decode_attention_ws_bytes(B, c.H, S) + gw + B * sizeof(int64_t) + ((size_t)B * D + part_floats(c, B)) * sizeof(float) + 16 * 256;
 }
 
 void small_gemm(const float* A, int lda, const float* W, int ldb, const float* bias, float* C, int ldc, int M, int N, int K, int act, const float* R, int ldr,
@@ -200,17 +212,43 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
         gemm(h, D, l.mlp0_w, D, l.mlp0_b, m1, 4 * D, (int)rows, 4 * D, D, ACT_GELU, nullptr, 0, s);
         gemm(m1, 4 * D, l.mlp2_w, 4 * D, l.mlp2_b, x, D, (int)rows, D, 4 * D, ACT_NONE, x2, D, s);
     }
+    st.G = 1;
     if (S == 1) {
         launch_gather_rows(x, st.hidden, B, K - 1, K, D, s);
         return;
     }
-    // fan the shared prefix out: slot g -> slots [g*S, g*S + S), highest group first (a destination never holds a source that is still needed)
-    for (int gi = G - 1; gi >= 0; --gi)
-        launch_replicate_prefix(st.kcache, st.vcache, g.num_layers, B, H, L, K, gi, gi * S, S, (int)cache_elem_bytes(c), s);
+    if (fused_path(c, B, S)) {
+        // the fused decode kernel reads the K prefix rows of a group from the group's FIRST cache slot: move slot g -> slot g*S, highest group first
+        // (a destination never holds a source that is still needed); the other slots of the group keep only their private rows >= K
+        st.G = S;
+        for (int gi = G - 1; gi >= 1; --gi)
+            launch_replicate_prefix(st.kcache, st.vcache, g.num_layers, B, H, L, K, gi, gi * S, 1, (int)cache_elem_bytes(c), s);
+    } else {
+        // per-operator path: fan the shared prefix out into every slot of the group
+        for (int gi = G - 1; gi >= 0; --gi)
+            launch_replicate_prefix(st.kcache, st.vcache, g.num_layers, B, H, L, K, gi, gi * S, S, (int)cache_elem_bytes(c), s);
+    }
     float* hid = c.arena.get<float>((size_t)G * D);
     launch_gather_rows(x, hid, G, K - 1, K, D, s);
     for (int j = 0; j < S; ++j)
         HIP_CHECK(hipMemcpy2DAsync(st.hidden + (size_t)j * D, (size_t)S * D * 4, hid, (size_t)D * 4, (size_t)D * 4, G, hipMemcpyDeviceToDevice, s));
+}
+
+// ln_f + head on the newest rows (mingpt_sparse.py:386-387)
+static void head_logits(Ctx& c, StepWs& w, int B, float* logits, hipStream_t s) {
+    auto& st = c.ars;
+    if (fused_path(c, B, st.G)) {
+        SkinnyFusedArgs g;
+        g.a.base = st.hidden; g.a.ld = c.D;
+        g.ln_w = c.pf("ln_f.weight"); g.ln_b = c.pf("ln_f.bias"); g.eps = 1e-5f;
+        g.W = c.pf("head.weight"); g.ldw = c.D;
+        g.C = logits; g.ldc = c.V;
+        g.M = B; g.N = c.V; g.K = c.D; g.ksplit = 1;
+        launch_skinny_fused(g, s);
+        return;
+    }
+    launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, B, c.D, 1e-5f, s);
+    small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, logits, c.V, B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, s);
 }
 
 void ar_logits(Ctx& c, float* logits, hipStream_t s) {
@@ -218,14 +256,73 @@ void ar_logits(Ctx& c, float* logits, hipStream_t s) {
     BG_REQUIRE(st.B > 0, "bevgen_ar_prefill must be called first");
     c.arena.reset();
     StepWs w = step_ws(c, st.B);
-    launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, st.B, c.D, 1e-5f, s);
-    small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, logits, c.V, st.B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, s);
+    head_logits(c, w, st.B, logits, s);
+}
+
+// Fused form of the step (decode_fused.hip): per layer {ln1 + qkv + attention, ln2 + MLP up + GELU, MLP down split over K}; the down-projection's
+// partial sums, bias and residual are folded into the next consumer's row fetch (RowSrc), the last layer's into the hidden-state write.
+static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipStream_t s) {
+    const auto& g = c.cfg;
+    auto& st = c.ars;
+    const int D = c.D, H = c.H, B = st.B, L = c.L;
+    launch_ar_step_embed(tok, c.pf("x_tok_emb.weight"), st.img_embed, c.pf("x_pos_emb"), c.fwd_idx, st.d_step, w.x, B, g.num_cams, c.T, D, g.vocab_size + 1, s);
+    const size_t layer_bytes = (size_t)B * H * L * 64 * cache_elem_bytes(c);
+    const int ks = skinny_fused_ksplit(D, 4 * D);
+    RowSrc src;
+    src.base = w.x; src.ld = D;
+    for (int i = 0; i < g.num_layers; ++i) {
+        const ArLayer& l = c.ar[i];
+        float* x2 = (i & 1) ? w.x2b : w.x2;
+        ArAttnFusedArgs a;
+        a.x = src;
+        a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;
+        a.wqkv = l.wqkv; a.bqkv = l.bqkv;
+        a.kcache = reinterpret_cast<char*>(st.kcache) + i * layer_bytes;
+        a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes;
+        a.kv_dtype = cache_dtype(c);
+        a.bias = c.attn_bias; a.ldbias = L;
+        a.keep = c.keep; a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
+        a.out = x2; a.ldo = D;
+        a.B = B; a.G = st.G; a.H = H; a.D = D; a.Lmax = L;
+        a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step;
+        a.prefix = c.K; a.scale = 0.125f;
+        a.trace = c.trace;
+        launch_ar_attn_fused(a, s);
+        SkinnyFusedArgs up;
+        up.a.base = x2; up.a.ld = D;
+        up.ln_w = l.ln2_w; up.ln_b = l.ln2_b; up.eps = 1e-5f;
+        up.W = l.mlp0_w; up.ldw = D; up.bias = l.mlp0_b;
+        up.C = w.m1; up.ldc = 4 * D;
+        up.M = B; up.N = 4 * D; up.K = D; up.ksplit = 1; up.act = ACT_GELU;
+        up.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
+        launch_skinny_fused(up, s);
+        SkinnyFusedArgs dn;
+        dn.a.base = w.m1; dn.a.ld = 4 * D;
+        dn.W = l.mlp2_w; dn.ldw = 4 * D;
+        dn.M = B; dn.N = D; dn.K = 4 * D; dn.ksplit = ks;
+        dn.trace = c.trace ? c.trace + 2 * 4096 * 8 : nullptr;
+        if (ks > 1) {
+            dn.C = w.part;
+            src = RowSrc{};
+            src.base = x2; src.ld = D; src.partial = w.part; src.ns = ks; src.pstride = (long)B * D; src.pld = D; src.bias = l.mlp2_b;
+        } else {   // narrow models: the whole K fits one workgroup; bias here, residual through the row source
+            dn.C = w.h; dn.ldc = D; dn.bias = l.mlp2_b;
+            src = RowSrc{};
+            src.base = x2; src.ld = D; src.partial = w.h; src.ns = 1; src.pstride = 0; src.pld = D;
+        }
+        launch_skinny_fused(dn, s);
+    }
+    launch_rowsrc_materialize(src, st.hidden, B, D, st.d_step, s);   // hidden state of the new row + the step counter
 }
 
 // one new row through all layers; position / bias row / cache slot are derived from the device-side step counter
 static void decode_step_launch(Ctx& c, StepWs& w, const int64_t* tok, hipStream_t s) {
     const auto& g = c.cfg;
     auto& st = c.ars;
+    if (fused_path(c, st.B, st.G)) {
+        decode_step_launch_fused(c, w, tok, s);
+        return;
+    }
     const int D = c.D, H = c.H, B = st.B, L = c.L;
     launch_ar_step_embed(tok, c.pf("x_tok_emb.weight"), st.img_embed, c.pf("x_pos_emb"), c.fwd_idx, st.d_step, w.x, B, g.num_cams, c.T, D, g.vocab_size + 1, s);
     const size_t layer_bytes = (size_t)B * H * L * 64 * cache_elem_bytes(c);
@@ -279,8 +376,7 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     // Every position-dependent quantity (decode-order index, cache slot, bias row, context length, noise row) is read from the device-side
     // step counter, so the launch sequence is identical for every step and can be captured once and replayed as a hipGraph.
     auto head_and_pick = [&](float* lg, hipStream_t q) {
-        launch_layernorm(st.hidden, c.D, c.pf("ln_f.weight"), c.pf("ln_f.bias"), w.xn, c.D, B, c.D, 1e-5f, q);
-        small_gemm(w.xn, c.D, c.pf("head.weight"), c.D, nullptr, lg, c.V, B, c.V, c.D, ACT_NONE, nullptr, 0, w.gemm_ws, q);
+        head_logits(c, w, B, lg, q);
         launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u, st.d_step, forced, w.tok, B, c.V, top_k, temperature, q);
         launch_store_tokens(w.tok, c.fwd_idx, st.d_step, out, B, c.N, q);
     };

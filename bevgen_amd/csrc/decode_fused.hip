@@ -1,0 +1,651 @@
+// Route A decode step, fused form: three launches per transformer layer instead of eight.
+//
+// A decode step pushes ONE new row per sequence through the 24 layers (Block.forward, transformer/mingpt_sparse.py:240-253:
+// x = ln1(x); x = x + attn(x); x = x + mlp(ln2(x))).  With 16-64 rows the step is a chain of short, strictly dependent kernels, and what
+// it costs is the fixed price of every link (launch + ramp + tail, 4-7 us each on MI355X), not arithmetic.  The row only has three
+// global dependencies per layer (the attention of a head needs that head's q/k/v; ln2 needs the whole attention row; the MLP
+// down-projection needs the whole hidden row), so the layer is cut exactly there:
+//
+//   ar_attn_fused_kernel   one workgroup per (layout group, head):  reduce the previous layer's split-K partials (+bias +residual)
+//                          -> ln1 -> q/k/v projection of THIS head (192 rows of the fused QKV weight, shared through the XCD's L2 by the
+//                          sequences of the head) -> append k/v to the cache -> softmax(dh^-0.5 (q k^T + camera bias) + mask) v over the
+//                          cache (SparseSelfAttention.forward, transformer/sparse_self_attention.py:150-176) -> + ln1(x) -> x2
+//   skinny_fused_kernel<LN>   ln2 fused into the MLP up-projection (+bias, GELU): every workgroup normalises the <= 16 rows itself
+//                          while its weight slice is in flight
+//   skinny_fused_kernel<no LN> MLP down-projection, split over K across workgroups; the partial sums are NOT reduced by a kernel of
+//                          their own: the consumer (next layer's ar_attn_fused_kernel / the head) adds them in a fixed order.
+//
+// Shared condition prefix (BASELINE config 5, several samples per BEV layout): a workgroup serves the G sequences of one layout
+// and one head; the K prefix rows are streamed ONCE and scored against the G queries, the private suffixes are split over wave teams.
+#include "common.h"
+#include "kernels.h"
+#include "profiler.h"
+
+namespace bevgen {
+
+// ----------------------------------------------------------------------------------------------------------------- row source
+__device__ __forceinline__ float rowsrc_at(const RowSrc& r, int m, int c) {
+    float s = 0.f;
+    for (int k = 0; k < r.ns; ++k) s += r.partial[(long)k * r.pstride + (long)m * r.pld + c];
+    if (r.bias) s += r.bias[c];
+    return s + r.base[(long)m * r.ld + c];
+}
+__device__ __forceinline__ float4 rowsrc_at4(const RowSrc& r, int m, int c) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < r.ns; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(r.partial + (long)k * r.pstride + (long)m * r.pld + c);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    if (r.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(r.bias + c);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    const float4 x = *reinterpret_cast<const float4*>(r.base + (long)m * r.ld + c);
+    return make_float4(s.x + x.x, s.y + x.y, s.z + x.z, s.w + x.w);
+}
+
+__global__ __launch_bounds__(256) void rowsrc_materialize_kernel(RowSrc r, float* __restrict__ out, int M, int D, int* counter) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)M * D) out[i] = rowsrc_at(r, (int)(i / D), (int)(i % D));
+    if (counter && i == 0) *counter += 1;   // the step counter: no kernel of this launch reads it
+}
+
+void launch_rowsrc_materialize(const RowSrc& r, float* out, int M, int D, int* counter, hipStream_t s) {
+    hipLaunchKernelGGL(rowsrc_materialize_kernel, dim3(cdiv((long)M * D, 256)), dim3(256), 0, s, r, out, M, D, counter);
+    LAUNCH_CHECK();
+}
+
+// ----------------------------------------------------------------------------------------------------------------- helpers
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+template <int DT> struct KvRow;
+template <> struct KvRow<0> {  // fp32 rows: 256 B = 16 lanes x 16 B
+    static constexpr int LPK = 16, DPL = 4;
+    typedef f32x4 Raw;
+    __device__ static __forceinline__ Raw load(const void* base, long row, int sub) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * 64 + sub * 4);
+    }
+    __device__ static __forceinline__ float get(const Raw& r, int i) { return r[i]; }
+};
+template <> struct KvRow<1> {  // fp16 rows: 128 B = 8 lanes x 16 B; kept packed in registers, widened at the point of use
+    static constexpr int LPK = 8, DPL = 8;
+    typedef half8_t Raw;
+    __device__ static __forceinline__ Raw load(const void* base, long row, int sub) {
+        return *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(base) + row * 64 + sub * 8);
+    }
+    __device__ static __forceinline__ float get(const Raw& r, int i) { return (float)r[i]; }
+};
+
+// sum over aligned groups of 8 / 16 lanes with DPP row operations (every lane of the group ends with the group's sum)
+template <int LPK>
+__device__ __forceinline__ float lane_group_sum(float d) {
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    if (LPK == 16) d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xf, 0xf, true));   // row_mirror
+    return d;
+}
+__device__ __forceinline__ float wave_sum_dpp(float d) {
+    d = lane_group_sum<16>(d);
+    d += __shfl_xor(d, 16, 64);
+    return d + xor32(d);
+}
+
+constexpr float kLog2eF = 1.44269504088896340736f;
+constexpr int AF_WAVES = 16;
+
+// One online-softmax state per query: running maximum (base-2 domain), denominator, weighted value sum of this lane's DPL dims.
+template <int DT, int NQ, int U>
+struct Attend {
+    using T = KvRow<DT>;
+    static constexpr int LPK = T::LPK, DPL = T::DPL;
+    struct Buf { typename T::Raw k[U], v[U]; };
+
+    __device__ static __forceinline__ void load(Buf& b, const void* kc, const void* vc, long row0, int key0, int stride, int k_end, int sub) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kcl = min(key0 + u * stride, k_end - 1);   // clamped address, masked in compute()
+            b.k[u] = T::load(kc, row0 + kcl, sub);
+            b.v[u] = T::load(vc, row0 + kcl, sub);
+        }
+    }
+    __device__ static __forceinline__ void compute(const Buf& b, int key0, int stride, int k_end, const float* bias_s, const float (&q)[NQ][DPL], float (&m)[NQ],
+                                                   float (&l)[NQ], float (&acc)[NQ][DPL]) {
+        float sc[NQ][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int key = key0 + u * stride;
+            const float bv = key < k_end ? bias_s[min(key, k_end - 1)] : kNegBig;
+#pragma unroll
+            for (int qi = 0; qi < NQ; ++qi) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) d = fmaf(q[qi][i], T::get(b.k[u], i), d);
+                d = lane_group_sum<LPK>(d);
+                sc[qi][u] = bv <= kNegBig ? kNegBig : d + bv;
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            float mx = m[qi];
+#pragma unroll
+            for (int u = 0; u < U; ++u) mx = fmaxf(mx, sc[qi][u]);
+            const float alpha = __builtin_amdgcn_exp2f(m[qi] - mx);
+            l[qi] *= alpha;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) acc[qi][i] *= alpha;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = sc[qi][u] <= kNegBig ? 0.f : __builtin_amdgcn_exp2f(sc[qi][u] - mx);
+                l[qi] += p;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) acc[qi][i] = fmaf(p, T::get(b.v[u], i), acc[qi][i]);
+            }
+            m[qi] = mx;
+        }
+    }
+    // keys k_begin + slot + i * stride (i = 0, 1, ...) < k_end belong to this lane group; two register buffers: the loads of iteration
+    // it + 1 are in flight while iteration it is scored
+    __device__ static __forceinline__ void run(const void* kc, const void* vc, long row0, int k_begin, int k_end, int slot, int stride, int sub, const float* bias_s,
+                                               const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL]) {
+        const int first = k_begin + slot;
+        if (k_end <= k_begin) return;
+        const int span = stride * U;
+        // the whole wave iterates the same number of times (slot differs per lane group): based on the wave's smallest slot
+        const int wave_first = k_begin + (slot / (64 / LPK)) * (64 / LPK);
+        const int iters = wave_first < k_end ? (k_end - wave_first + span - 1) / span : 0;
+        if (iters == 0) return;
+        Buf b0, b1;
+        load(b0, kc, vc, row0, first, stride, k_end, sub);
+        for (int it = 0; it < iters; it += 2) {
+            if (it + 1 < iters) load(b1, kc, vc, row0, first + (it + 1) * span, stride, k_end, sub);
+            compute(b0, first + it * span, stride, k_end, bias_s, q, m, l, acc);
+            if (it + 2 < iters) load(b0, kc, vc, row0, first + (it + 2) * span, stride, k_end, sub);
+            if (it + 1 < iters) compute(b1, first + (it + 1) * span, stride, k_end, bias_s, q, m, l, acc);
+        }
+    }
+};
+
+// merge the key slots of a wave (lanes with equal `sub`); afterwards every lane holds the wave's state for its dims
+template <int LPK, int DPL>
+__device__ __forceinline__ void wave_merge(float& m, float& l, float (&acc)[DPL]) {
+    float m_all = m;
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) m_all = fmaxf(m_all, __shfl_xor(m_all, o, 64));
+    const float f = __builtin_amdgcn_exp2f(m - m_all);
+    l *= f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) acc[i] *= f;
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) {
+        l += __shfl_xor(l, o, 64);
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    m = m_all;
+}
+
+// ----------------------------------------------------------------------------------------------------------------- ln1 + qkv + attention
+// grid (H, B / G), 1024 threads.  Dynamic LDS: bias row [Lpad] | xn [G][D] | qkv [G][192] | red [16][G+1][66] | stat [16][G]
+template <int DT, int G>
+__global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) {
+    using T = KvRow<DT>;
+    constexpr int LPK = T::LPK, DPL = T::DPL, KPI = 64 / LPK, NW = AF_WAVES, TW = NW / G;
+    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // keys per lane group and pipeline stage
+    constexpr int UP = G >= 4 ? 1 : U;   // same for the shared-prefix phase (G queries' state lives in registers)
+    extern __shared__ float smem[];
+    const int D = a.D;
+    float* bias_s = smem;
+    float* xn_s = bias_s + a.Lpad;
+    float* qkv_s = xn_s + G * D;
+    float* red = qkv_s + G * 192;
+    float* stat = red + NW * (G + 1) * 66;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane % LPK, kslot = lane / LPK;
+    const int head = blockIdx.x, grp = blockIdx.y;
+    const int b0 = grp * G;
+    const int n = a.d_n ? *a.d_n + a.n : a.n;   // context length incl. the new key
+    const int row = n - 1;
+    const float sl2 = a.scale * kLog2eF;        // scores live in the base-2 domain
+
+#define AF_TRACE(i) do { if (a.trace && tid == 0) a.trace[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    AF_TRACE(0);
+    // ---- every load that does not depend on another load is requested up front, in the order the results are needed (vmcnt waits are in order):
+    //      x rows and ln1 gamma / beta -> first q/k/v weight rows -> bias and visibility row of this step
+    float xv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) xv[g] = tid < D ? rowsrc_at(a.x, b0 + g, tid) : 0.f;
+    const float lw = tid < D ? a.ln_w[tid] : 0.f, lb = tid < D ? a.ln_b[tid] : 0.f;
+
+    // q/k/v projection: wave w owns rows j = 12 w .. 12 w + 11 of the head's 192 (q | k | v) x 64 rows, fetched RB rows at a time into two register
+    // buffers.  The 16 workgroups of a head (one per sequence, same XCD) read the same rows through that XCD's L2: each starts at a different batch
+    // so that at any moment they pull on different lines / channels instead of queueing on one.
+    constexpr int RB = G == 1 ? 3 : 2, NB = 12 / RB;
+    const int rot = grp % NB;
+    auto wrow = [&](int bi, int r) { return wave * 12 + ((bi + rot) % NB) * RB + r; };
+    auto wptr = [&](int j) { return a.wqkv + ((long)(j >> 6) * D + head * 64 + (j & 63)) * D; };
+    float4 wb[2][RB][4];
+    auto load_batch = [&](int bi, float4 (&w)[RB][4]) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float* p = wptr(wrow(bi, r));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int col = c * 256 + lane * 4;
+                w[r][c] = col < D ? *reinterpret_cast<const float4*>(p + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    load_batch(0, wb[0]);
+
+    // bias row of this step with the visibility mask folded in (shared by every sequence and head of the step): through registers, stored after ln1
+    constexpr int BR = 3;
+    const uint8_t* keep_row = a.keep ? a.keep + (long)head * a.keep_head_stride + (long)row * a.ldkeep : nullptr;
+    const float* bias_row = a.bias ? a.bias + (long)row * a.ldbias : nullptr;
+    float bstage[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int k = tid + 1024 * j;
+        bstage[j] = kNegBig;
+        if (k < n) {
+            const bool vis = !keep_row || keep_row[k];
+            bstage[j] = vis ? (bias_row ? bias_row[k] * sl2 : 0.f) : kNegBig;
+        }
+    }
+
+    // ---- ln1, thread = column
+    {
+        float s[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[g] = wave_sum_dpp(xv[g]);
+        if (lane == 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
+        }
+        __syncthreads();
+        float mean[G], var[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += stat[w * G + g];
+            mean[g] = t / (float)D;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float d = tid < D ? xv[g] - mean[g] : 0.f;
+            s[g] = wave_sum_dpp(d * d);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += stat[w * G + g];
+            var[g] = t / (float)D;
+        }
+        if (tid < D) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) xn_s[g * D + tid] = (xv[g] - mean[g]) * rsqrtf(var[g] + a.eps) * lw + lb;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            if (tid + 1024 * j < n) bias_s[tid + 1024 * j] = bstage[j];
+        for (int k = tid + 1024 * BR; k < n; k += 1024) {   // sequences longer than 3072: the remainder the plain way
+            const bool vis = !keep_row || keep_row[k];
+            bias_s[k] = vis ? (bias_row ? bias_row[k] * sl2 : 0.f) : kNegBig;
+        }
+        __syncthreads();
+    }
+
+    AF_TRACE(1);
+    // ---- q/k/v projection of this head
+    {
+        auto dot_batch = [&](int bi, const float4 (&w)[RB][4]) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                float accp[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) accp[g] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = c * 256 + lane * 4;
+                    if (col < D) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const float4 x4 = *reinterpret_cast<const float4*>(xn_s + g * D + col);
+                            accp[g] = fmaf(w[r][c].x, x4.x, accp[g]);
+                            accp[g] = fmaf(w[r][c].y, x4.y, accp[g]);
+                            accp[g] = fmaf(w[r][c].z, x4.z, accp[g]);
+                            accp[g] = fmaf(w[r][c].w, x4.w, accp[g]);
+                        }
+                    }
+                }
+                const int j = wrow(bi, r);
+                const float bj = a.bqkv[(long)(j >> 6) * D + head * 64 + (j & 63)];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float t = wave_sum_dpp(accp[g]);
+                    if (lane == 0) qkv_s[g * 192 + j] = t + bj;
+                }
+            }
+        };
+#pragma unroll
+        for (int bi = 0; bi < NB; bi += 2) {
+            load_batch(bi + 1, wb[1]);
+            dot_batch(bi, wb[0]);
+            if (bi + 2 < NB) load_batch(bi + 2, wb[0]);
+            dot_batch(bi + 1, wb[1]);
+        }
+    }
+    __syncthreads();
+    AF_TRACE(2);
+
+    // ---- append this step's k / v rows to the cache (row n-1 of every sequence of the group); read back through the normal path below
+    if (tid < 128 * G) {
+        const int g = tid >> 7, is_v = (tid >> 6) & 1, d = tid & 63;
+        const float val = qkv_s[g * 192 + 64 + is_v * 64 + d];
+        void* cache = is_v ? a.vcache : a.kcache;
+        const long idx = ((((long)(b0 + g)) * a.H + head) * a.Lmax + row) * 64 + d;
+        if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
+        else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)val;
+    }
+    __syncthreads();
+
+    AF_TRACE(3);
+    // ---- attention
+    float* my_red = red + wave * (G + 1) * 66;
+    if (G == 1) {
+        float q[1][DPL], m[1] = {kNegBig}, l[1] = {0.f}, acc[1][DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[sub * DPL + i] * sl2; acc[0][i] = 0.f; }
+        const long row0 = ((long)b0 * a.H + head) * a.Lmax;
+        Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, 0, n, wave * KPI + kslot, NW * KPI, sub, bias_s, q, m, l, acc);
+        wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
+        if (kslot == 0) {
+            if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) my_red[2 + sub * DPL + i] = acc[0][i];
+        }
+    } else {
+        // shared prefix [0, prefix): rows of the group's first sequence, every key row scored against the G queries
+        {
+            float q[G][DPL], m[G], l[G], acc[G][DPL];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                m[g] = kNegBig; l[g] = 0.f;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) { q[g][i] = qkv_s[g * 192 + sub * DPL + i] * sl2; acc[g][i] = 0.f; }
+            }
+            const long row0 = ((long)b0 * a.H + head) * a.Lmax;
+            Attend<DT, G, UP>::run(a.kcache, a.vcache, row0, 0, min(a.prefix, n), wave * KPI + kslot, NW * KPI, sub, bias_s, q, m, l, acc);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                wave_merge<LPK, DPL>(m[g], l[g], acc[g]);
+                if (kslot == 0) {
+                    if (sub == 0) { my_red[g * 66] = m[g]; my_red[g * 66 + 1] = l[g]; }
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) my_red[g * 66 + 2 + sub * DPL + i] = acc[g][i];
+                }
+            }
+        }
+        // private suffix [prefix, n): team of TW waves per sequence
+        {
+            const int g_own = wave / TW, wt = wave % TW;
+            float q[1][DPL], m[1] = {kNegBig}, l[1] = {0.f}, acc[1][DPL];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[g_own * 192 + sub * DPL + i] * sl2; acc[0][i] = 0.f; }
+            const long row0 = ((long)(b0 + g_own) * a.H + head) * a.Lmax;
+            Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, min(a.prefix, n), n, wt * KPI + kslot, TW * KPI, sub, bias_s, q, m, l, acc);
+            wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
+            if (kslot == 0) {
+                if (sub == 0) { my_red[G * 66] = m[0]; my_red[G * 66 + 1] = l[0]; }
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) my_red[G * 66 + 2 + sub * DPL + i] = acc[0][i];
+            }
+        }
+    }
+    __syncthreads();
+    AF_TRACE(4);
+
+    // ---- merge the waves (fixed order), normalise, add the ln1(x) residual (Block.forward: the residual is the NORMALISED row)
+    if (tid < 64 * G) {
+        const int g = tid >> 6, d = tid & 63;
+        float mm = kNegBig;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, red[(w * (G + 1) + g) * 66]);
+        if (G > 1) {
+#pragma unroll
+            for (int w = 0; w < TW; ++w) mm = fmaxf(mm, red[((g * TW + w) * (G + 1) + G) * 66]);
+        }
+        float l = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float* e = red + (w * (G + 1) + g) * 66;
+            const float f = __builtin_amdgcn_exp2f(e[0] - mm);
+            l += e[1] * f;
+            o += e[2 + d] * f;
+        }
+        if (G > 1) {
+#pragma unroll
+            for (int w = 0; w < TW; ++w) {
+                const float* e = red + ((g * TW + w) * (G + 1) + G) * 66;
+                const float f = __builtin_amdgcn_exp2f(e[0] - mm);
+                l += e[1] * f;
+                o += e[2 + d] * f;
+            }
+        }
+        a.out[(long)(b0 + g) * a.ldo + head * 64 + d] = o / l + xn_s[g * D + head * 64 + d];
+    }
+    AF_TRACE(5);
+#undef AF_TRACE
+}
+
+size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) { return ((size_t)Lpad + (size_t)G * D + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66 + (size_t)AF_WAVES * G) * sizeof(float); }
+
+bool ar_attn_fused_supported(int B, int G, int D, int H) { return D == H * 64 && D % 4 == 0 && D <= 1024 && (G == 1 || G == 2 || G == 4) && B % G == 0; }
+
+void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
+    ArAttnFusedArgs a = a0;
+    BG_REQUIRE(ar_attn_fused_supported(a.B, a.G, a.D, a.H), "fused decode attention: unsupported shape B=%d G=%d D=%d H=%d", a.B, a.G, a.D, a.H);
+    BG_REQUIRE(a.G == 1 || a.prefix > 0, "fused decode attention: group size %d needs a shared prefix length", a.G);
+    a.Lpad = (int)round_up(a.Lmax, 4);
+    const size_t lds = ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
+    BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
+    dim3 grid(a.H, a.B / a.G);
+    // algorithmic bytes of one launch: K and V rows of the context, once each; the shared prefix once per group
+    const double n_host = a.d_n ? a.n + a.n_hint : a.n;
+    const double eb = a.kv_dtype == 0 ? 4 : 2;
+    const double pre = a.G > 1 ? (double)a.prefix : 0.0;
+    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pre) + (double)(a.B / a.G) * pre), s);
+#define AF_LAUNCH(DT, GG) hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG>), grid, dim3(1024), lds, s, a)
+    if (a.kv_dtype == 0) {
+        if (a.G == 1) AF_LAUNCH(0, 1); else if (a.G == 2) AF_LAUNCH(0, 2); else AF_LAUNCH(0, 4);
+    } else {
+        if (a.G == 1) AF_LAUNCH(1, 1); else if (a.G == 2) AF_LAUNCH(1, 2); else AF_LAUNCH(1, 4);
+    }
+#undef AF_LAUNCH
+    LAUNCH_CHECK();
+}
+
+// ----------------------------------------------------------------------------------------------------------------- (ln +) skinny GEMM
+// C[M, N] = act(LN?(A)[M, K] W[N, K]^T + bias), M <= 64.  One workgroup = 16 output columns x one K slice of <= 1024; 8 waves split the slice.
+// The weight slice (64 KB per workgroup) goes straight from HBM into registers with non-temporal 16-byte loads issued first; while it is in
+// flight the workgroup builds its A tile in LDS: rows are fetched through the row source (split-K partials + bias + residual, fixed order),
+// optionally LayerNorm-ed (two-pass statistics, 32 values per lane, lanes -> waves through LDS), and stored k-chunk-major
+// ([k/4][16 rows][4]) so that both the staging stores and the MFMA operand reads are contiguous 1 KiB per wave (conflict free).
+// v_mfma_f32_16x16x4_f32 (exact fp32): the four k-slots of one MFMA are the four 16-lane quarters, quarter q owns k = 16c + 4q .. +3.
+constexpr int SF_WAVES = 8;
+
+__device__ __forceinline__ float4 ldg_nt4(const float* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <bool LN>
+__global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFusedArgs g) {
+    __shared__ float4 As[256 * 16];
+    __shared__ float red[SF_WAVES - 1][4][64];
+    __shared__ float stat[2][SF_WAVES][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16, split = blockIdx.y;
+    const int kw = g.K / g.ksplit, kbase = split * kw, kper = kw / SF_WAVES;   // kper: multiple of 16, <= 128
+    const int nch = kw >> 2;
+
+#define SF_TRACE(i) do { if (g.trace && tid == 0) g.trace[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    SF_TRACE(0);
+    // Loads are requested in the order their results are needed (vmcnt waits are in order): the first A row chunk and the LayerNorm parameters,
+    // THEN the weight slice, so that the statistics are computed while the 64 KB of weights are still in flight.
+    auto load_a = [&](int mc, float4 (&v)[8]) {
+        const int m = mc * 16 + r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = q + 4 * wave + 32 * j;
+            v[j] = (c < nch && m < g.M) ? rowsrc_at4(g.a, m, kbase + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    float4 v[8];
+    load_a(0, v);
+    float4 gm[LN ? 8 : 1], bt[LN ? 8 : 1];
+    if (LN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = q + 4 * wave + 32 * j;
+            gm[j] = c < nch ? *reinterpret_cast<const float4*>(g.ln_w + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bt[j] = (c < nch && g.ln_b) ? *reinterpret_cast<const float4*>(g.ln_b + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 wv[8];
+    {
+        const int n = min(n0 + r, g.N - 1);
+        const float* wp = g.W + (long)n * g.ldw + kbase + wave * kper + 4 * q;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = 16 * u < kper ? ldg_nt4(wp + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    for (int mc = 0; mc * 16 < g.M; ++mc) {
+        if (mc > 0) load_a(mc, v);
+        if (LN) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            s += __shfl_xor(s, 16, 64);
+            s += xor32(s);
+            if (q == 0) stat[0][wave][r] = s;
+            __syncthreads();
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < SF_WAVES; ++w) t += stat[0][w][r];
+            const float mean = t / (float)g.K;
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (q + 4 * wave + 32 * j < nch) {
+                    const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                    qq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+            qq += __shfl_xor(qq, 16, 64);
+            qq += xor32(qq);
+            if (q == 0) stat[1][wave][r] = qq;
+            __syncthreads();
+            t = 0.f;
+#pragma unroll
+            for (int w = 0; w < SF_WAVES; ++w) t += stat[1][w][r];
+            const float rstd = rsqrtf(t / (float)g.K + g.eps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = make_float4((v[j].x - mean) * rstd * gm[j].x + bt[j].x, (v[j].y - mean) * rstd * gm[j].y + bt[j].y,
+                                   (v[j].z - mean) * rstd * gm[j].z + bt[j].z, (v[j].w - mean) * rstd * gm[j].w + bt[j].w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = q + 4 * wave + 32 * j;
+            if (c < nch) As[c * 16 + r] = v[j];
+        }
+        __syncthreads();
+        SF_TRACE(1);
+
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (16 * u < kper) {
+                const float4 a4 = As[(((wave * kper + 16 * u) >> 2) + q) * 16 + r];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv[u].w, acc, 0, 0, 0);
+            }
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[wave - 1][j][lane] = acc[j];
+        }
+        __syncthreads();
+        SF_TRACE(2);
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < SF_WAVES - 1; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += red[w][j][lane];
+            // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+            const int col = n0 + r;
+            if (col < g.N) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int mo = mc * 16 + 4 * q + j;
+                    if (mo >= g.M) continue;
+                    if (g.ksplit > 1) {
+                        g.C[((long)split * g.M + mo) * g.N + col] = acc[j];
+                    } else {
+                        float o = acc[j] + (g.bias ? g.bias[col] : 0.f);
+                        if (g.act == ACT_GELU) o = gelu_erf(o);
+                        g.C[(long)mo * g.ldc + col] = o;
+                    }
+                }
+            }
+        }
+        if ((mc + 1) * 16 < g.M) __syncthreads();   // As / red are rewritten by the next row chunk
+    }
+    SF_TRACE(3);
+#undef SF_TRACE
+}
+
+int skinny_fused_ksplit(int N, int K) {
+    // the K slice of one workgroup is at most 1024 (A tile in LDS, W slice in registers); beyond that, split until the grid covers the chip
+    int s = 1;
+    while (K / s > 1024 || (cdiv(N, 16) * s < 192 && (K / (s * 2)) % (SF_WAVES * 16) == 0 && K / (s * 2) >= 256)) s *= 2;
+    return s;
+}
+
+bool skinny_fused_supported(int M, int N, int K, bool ln) {
+    if (M < 1 || M > 64 || K % 4 != 0) return false;
+    const int s = ln ? 1 : skinny_fused_ksplit(N, K);
+    if (K % s != 0) return false;
+    const int kw = K / s;
+    return kw <= 1024 && kw % (SF_WAVES * 16) == 0;
+}
+
+void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
+    SkinnyFusedArgs g = g0;
+    const bool ln = g.ln_w != nullptr;
+    if (g.ksplit <= 0) g.ksplit = ln ? 1 : skinny_fused_ksplit(g.N, g.K);
+    BG_REQUIRE(skinny_fused_supported(g.M, g.N, g.K, ln) && g.K % g.ksplit == 0 && (g.K / g.ksplit) <= 1024 && (g.K / g.ksplit) % (SF_WAVES * 16) == 0,
+               "skinny_fused: unsupported shape M=%d N=%d K=%d ksplit=%d", g.M, g.N, g.K, g.ksplit);
+    BG_REQUIRE(!ln || g.ksplit == 1, "skinny_fused: LayerNorm needs the whole row in one workgroup");
+    BG_REQUIRE(g.ldw % 4 == 0 && g.a.ld % 4 == 0, "skinny_fused: strides must be multiples of 4");
+    dim3 grid(cdiv(g.N, 16), g.ksplit);
+    ProfScope prof(PROF_GEMM_SKINNY, ((double)g.N * g.K + (double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);
+    if (ln) hipLaunchKernelGGL(skinny_fused_kernel<true>, grid, dim3(SF_WAVES * 64), 0, s, g);
+    else hipLaunchKernelGGL(skinny_fused_kernel<false>, grid, dim3(SF_WAVES * 64), 0, s, g);
+    LAUNCH_CHECK();
+}
+
+}  // namespace bevgen

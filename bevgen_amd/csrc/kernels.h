@@ -147,6 +147,49 @@ size_t decode_attention_ws_bytes(int B, int H, int S);
 void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipStream_t s);
 void launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------- decode_fused.hip (Route A decode step, three launches per layer)
+// A [M, D] fp32 matrix that may still be "in flight" as split-K partial sums: element (m, c) = base[m*ld + c] + bias[c] + sum_k partial[k*pstride + m*pld + c]
+// (partials added in index order: deterministic).  ns = 0 / partial = bias = null -> the plain matrix `base`.
+struct RowSrc {
+    const float* base = nullptr; int ld = 0;
+    const float* partial = nullptr; int ns = 0; long pstride = 0; int pld = 0;
+    const float* bias = nullptr;
+};
+void launch_rowsrc_materialize(const RowSrc& r, float* out, int M, int D, int* counter /* or null: incremented by one */, hipStream_t s);
+
+struct ArAttnFusedArgs {
+    RowSrc x;                          // rows entering the layer (before ln1), [B, D]
+    const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;
+    const float* wqkv = nullptr;       // fused [3D, D] (q | k | v), bqkv [3D]
+    const float* bqkv = nullptr;
+    void* kcache = nullptr;            // this layer's [B, H, Lmax, 64]
+    void* vcache = nullptr;
+    int kv_dtype = 0;                  // 0 fp32, 1 fp16 storage
+    const float* bias = nullptr; int ldbias = 0;                               // camera-bias matrix [L, ldbias] (unscaled) or null
+    const uint8_t* keep = nullptr; long keep_head_stride = 0; int ldkeep = 0;  // visibility [H or 1][L][ldkeep]
+    float* out = nullptr; int ldo = 0; // x2 [B, D] = ln1(x) + attention
+    int B = 0, G = 1, H = 0, D = 0, Lmax = 0, Lpad = 0;
+    int n = 0; const int* d_n = nullptr; int n_hint = 0;                        // context length incl. the new key = n (+ *d_n)
+    int prefix = 0;                    // G > 1: leading keys shared by the G sequences of a group (read from the group's first cache slot)
+    float scale = 0.125f;
+    long long* trace = nullptr;        // diagnostics: [workgroup][8] device timestamps (100 MHz) at the phase boundaries, or null
+};
+bool ar_attn_fused_supported(int B, int G, int D, int H);
+void launch_ar_attn_fused(const ArAttnFusedArgs& a, hipStream_t s);
+
+struct SkinnyFusedArgs {
+    RowSrc a;                          // [M, K]
+    const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;   // ln_w != null: LayerNorm over K fused in front of the product
+    const float* W = nullptr; int ldw = 0;   // [N, K]
+    const float* bias = nullptr;       // [N] (ksplit == 1 only)
+    float* C = nullptr; int ldc = 0;   // [M, N], or the partial sums [ksplit][M][N] when ksplit > 1
+    int M = 0, N = 0, K = 0, ksplit = 0 /* 0 = skinny_fused_ksplit(N, K) */, act = 0;
+    long long* trace = nullptr;        // diagnostics, as above
+};
+int skinny_fused_ksplit(int N, int K);
+bool skinny_fused_supported(int M, int N, int K, bool ln);
+void launch_skinny_fused(const SkinnyFusedArgs& g, hipStream_t s);
+
 // ---------------------------------------------------------------- embed.hip
 // Geometric camera embeddings (gpt:336-349 / muse_net:314-327)
 //   c_embed[b,c,:] = Wcam[D,4] * E_inv[b,c,:,3];  img[b,c,t,:] = normalize(Wimg * (E_inv [I_inv pix_t; 1]) - c_embed) (+1e-7)

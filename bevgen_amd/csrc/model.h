@@ -83,6 +83,7 @@ struct Ctx {
     // per-batch decode state (lives in `persist`)
     struct ArState {
         int B = 0, step = 0;        // step = number of image tokens already fed
+        int G = 1;                  // sequences per layout group sharing the condition prefix rows of the group's first cache slot (fused decode path)
         float *img_embed = nullptr, *c_embed = nullptr;  // [B,C,T,D], [B,C,D]
         void *kcache = nullptr, *vcache = nullptr;       // [layers][B,H,L,64]
         float* hidden = nullptr;                         // [B,D] newest row after the last layer
@@ -117,6 +118,7 @@ struct Ctx {
     hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
     std::vector<std::pair<hipGraphExec_t, hipGraph_t>> retired_graphs;
     bool disable_graphs = false;
+    long long* trace = nullptr;   // diagnostics (bevgen_set_trace_buffer): phase timestamps of the fused decode kernels, [3 kinds][4096 workgroups][8]
     void retire_graph(hipGraphExec_t e, hipGraph_t g);  // destroyed once the stream has drained (next call or destroy)
 
     ~Ctx();

@@ -52,7 +52,7 @@ class Context:
     """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
-                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32"):
+                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "fused"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bevgen_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product")
@@ -72,6 +72,9 @@ class Context:
         # Route A KV-cache storage: 'f32' (bit-exact tokens) or 'f16' (fp16 storage / fp32 accumulate, BASELINE config 4: half the decode traffic)
         c.kv_cache_dtype = {"f32": _lib.KV_F32, "f16": _lib.KV_F16}[kv_cache]
         self.kv_cache = kv_cache
+        # Route A decode step: 'fused' (three launches per layer) or 'per_op' (one kernel per operator, the A/B reference)
+        c.decode_path = {"fused": _lib.DECODE_FUSED, "per_op": _lib.DECODE_PER_OP}[decode_path]
+        self.decode_path = decode_path
         if cfg is not None:
             c.num_layers, c.num_heads, c.dim = cfg.num_layers, cfg.num_heads, cfg.num_embed
             c.vocab_size, c.cond_vocab_size = cfg.vocab_size, cfg.cond_vocab_size
@@ -286,6 +289,16 @@ class Context:
         buf = (C.c_double * (3 * len(self.PROFILE_KINDS)))()
         self._check(self.lib.bevgen_profile_end(self._h, buf))
         return {k: {"launches": buf[3 * i], "ms": buf[3 * i + 1], "work": buf[3 * i + 2]} for i, k in enumerate(self.PROFILE_KINDS)}
+
+    def trace_begin(self):
+        """Diagnostics: phase timestamps of the fused decode kernels (last launch of each kind)."""
+        self._trace = torch.zeros((3, 4096, 8), dtype=torch.int64, device=self.device)
+        self._check(self.lib.bevgen_set_trace_buffer(self._h, _ptr(self._trace)))
+
+    def trace_end(self):
+        torch.cuda.synchronize()
+        self._check(self.lib.bevgen_set_trace_buffer(self._h, None))
+        return self._trace.cpu()
 
     # ------------------------------------------------------------------------------------------ operator level (tests / roofline)
     def op_gemm(self, a, w, bias=None, residual=None, gelu=False, skinny=False):

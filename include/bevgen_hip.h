@@ -35,6 +35,7 @@ enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
  *         fp32 accumulation, up to 5x the fp32 MFMA rate.  Everything else (attention, norms, samplers, decode-step GEMMs) stays fp32. */
 enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 /* reserved */, BEVGEN_PRECISION_F16X3 = 2 };
 enum { BEVGEN_KV_F32 = 0, BEVGEN_KV_F16 = 1 };
+enum { BEVGEN_DECODE_FUSED = 0, BEVGEN_DECODE_PER_OP = 1 };
 enum { BEVGEN_DTYPE_F32 = 0, BEVGEN_DTYPE_I64 = 1, BEVGEN_DTYPE_U8 = 2, BEVGEN_DTYPE_F64 = 3 };
 
 enum {
@@ -67,7 +68,9 @@ typedef struct bevgen_cfg {
     int32_t vq_in_channels;                            /* encoder input channels (3 images / 7 Argoverse BEV classes); 0 = decoder only */
     int32_t kv_cache_dtype;                            /* Route A KV-cache storage: BEVGEN_KV_F32 (default, bit-exact tokens) or BEVGEN_KV_F16 (fp16 storage,
                                                           fp32 accumulate: half the decode-attention HBM traffic; tokens no longer guaranteed identical) */
-    int32_t reserved[14];
+    int32_t decode_path;                               /* Route A decode step: BEVGEN_DECODE_FUSED (default: three launches per layer, decode_fused.hip) or
+                                                          BEVGEN_DECODE_PER_OP (one kernel per operator: the round-1 path, kept as the A/B reference) */
+    int32_t reserved[13];
 } bevgen_cfg;
 
 typedef struct bevgen_ctx bevgen_ctx;
@@ -202,6 +205,10 @@ int bevgen_decode_attention_splits(int B, int H, int n);
 #define BEVGEN_PROFILE_KINDS 5
 int bevgen_profile_begin(bevgen_ctx* ctx);
 int bevgen_profile_end(bevgen_ctx* ctx, double* out);
+
+/* Diagnostics: phase timestamps of the fused Route A decode kernels.  d_buf = device buffer of 3 * 4096 * 8 int64 (kinds: 0 ln1+qkv+attention,
+ * 1 ln2+MLP-up, 2 MLP-down; [workgroup][8] 100 MHz device timestamps at the phase boundaries of the most recent launch), NULL = off. */
+int bevgen_set_trace_buffer(bevgen_ctx* ctx, void* d_buf);
 
 #ifdef __cplusplus
 }

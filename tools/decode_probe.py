@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Route A decode probe for rocprofv3 kernel traces: config4 (L=2368, 24 layers), B sequences, `steps` greedy steps (hipGraph path)."""
+"""Route A decode probe: BASELINE config 4 (L=2368, 24 layers), B sequences, `steps` greedy steps through the hipGraph path.
+usage: decode_probe.py [B] [steps] [paths=fused,per_op] [kv=f32,f16] [samples_per_layout=1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,15 +10,29 @@ from bevgen_amd.weights import gpt_state_dict
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+paths = (sys.argv[3] if len(sys.argv) > 3 else "fused,per_op").split(",")
+kvs = (sys.argv[4] if len(sys.argv) > 4 else "f32,f16").split(",")
+S = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 cfg = presets.config4()
-ctx = Context(cfg, route="ar", max_batch=B)
-ctx.load_state_dict(gpt_state_dict(cfg, 1234))
-ctx.set_tables()
-ctx.finalize()
-bt = {k: v.cuda() for k, v in synthetic.make_batch(cfg, B, seed=0).items()}
-ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=8)
-torch.cuda.synchronize()
-t0 = time.time()
-ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=steps)
-torch.cuda.synchronize()
-print(f"B={B} steps={steps} wall {time.time()-t0:.3f}s -> {(time.time()-t0)*1e3/steps:.3f} ms/step")
+sd = gpt_state_dict(cfg, 1234)
+layouts = B // S
+bt = {k: v.repeat_interleave(S, dim=0).cuda() for k, v in synthetic.make_batch(cfg, layouts, seed=0).items()}
+ref = None
+for kv in kvs:
+    for path in paths:
+        ctx = Context(cfg, route="ar", max_batch=B, kv_cache=kv, decode_path=path)
+        ctx.load_state_dict(sd)
+        ctx.set_tables()
+        ctx.finalize()
+        ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=8, samples_per_layout=S)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        x = ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=steps, samples_per_layout=S)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        x = x.cpu()
+        same = "" if ref is None else f" tokens equal to first run: {bool(torch.equal(x, ref))} ({(x != ref).sum().item()} differ)"
+        if ref is None:
+            ref = x
+        print(f"B={B} S={S} steps={steps} kv={kv} path={path}: wall {dt:.3f}s -> {dt * 1e3 / steps:.3f} ms/step (incl. prefill){same}", flush=True)
+        ctx.close()
