@@ -67,6 +67,7 @@ SIGNATURES = {
     "bevgen_vq_decode_latents": (_i, [_p, _p, _i, _i, _p, _p]),
     "bevgen_vq_encode": (_i, [_p, _p, _i, _p, _p]),
     "bevgen_op_gemm": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "bevgen_op_ln_gemm": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _p]),
     "bevgen_op_layernorm": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "bevgen_op_geglu_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "bevgen_op_attention": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),

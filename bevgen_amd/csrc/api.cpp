@@ -218,6 +218,25 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float*
     });
 }
 
+int bevgen_op_ln_gemm(bevgen_ctx* ctx, const float* a, const float* ln_w, const float* ln_b, float eps, const float* w, const float* bias, float* c, int M, int N, int K,
+                      int act_gelu, int ksplit, int* ksplit_out, void* stream) {
+    return guarded(ctx, [&] {
+        BG_REQUIRE(skinny_fused_supported(M, N, K, ln_w != nullptr), "op_ln_gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
+        SkinnyFusedArgs g;
+        g.A = a; g.lda = K; g.ln_w = ln_w; g.ln_b = ln_b; g.eps = eps;
+        ctx->arena.reserve(skinny_packed_floats(N, K) * sizeof(float) + 4096);
+        ctx->arena.reset();
+        float* wp = ctx->arena.get<float>(skinny_packed_floats(N, K));
+        launch_pack_skinny_weight(w, wp, N, K, (hipStream_t)stream);
+        g.Wp = wp; g.bias = bias; g.C = c; g.ldc = N;
+        g.M = M; g.N = N; g.K = K; g.act = act_gelu ? ACT_GELU : ACT_NONE;
+        g.ksplit = ksplit > 0 ? ksplit : (ln_w ? 1 : skinny_fused_ksplit(N, K));
+        if (ksplit_out) *ksplit_out = g.ksplit;
+        g.trace = ctx->trace ? ctx->trace + 4096 * 8 : nullptr;
+        launch_skinny_fused(g, (hipStream_t)stream);
+    });
+}
+
 int bevgen_op_layernorm(bevgen_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, void* stream) {
     return guarded(ctx, [&] { launch_layernorm(x, D, gamma, beta, y, D, rows, D, eps, (hipStream_t)stream); });
 }

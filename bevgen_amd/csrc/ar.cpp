@@ -239,9 +239,9 @@ static void head_logits(Ctx& c, StepWs& w, int B, float* logits, hipStream_t s) 
     auto& st = c.ars;
     if (fused_path(c, B, st.G)) {
         SkinnyFusedArgs g;
-        g.a.base = st.hidden; g.a.ld = c.D;
+        g.A = st.hidden; g.lda = c.D;
         g.ln_w = c.pf("ln_f.weight"); g.ln_b = c.pf("ln_f.bias"); g.eps = 1e-5f;
-        g.W = c.pf("head.weight"); g.ldw = c.D;
+        g.Wp = c.head_wp;
         g.C = logits; g.ldc = c.V;
         g.M = B; g.N = c.V; g.K = c.D; g.ksplit = 1;
         launch_skinny_fused(g, s);
@@ -289,16 +289,16 @@ static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipS
         a.trace = c.trace;
         launch_ar_attn_fused(a, s);
         SkinnyFusedArgs up;
-        up.a.base = x2; up.a.ld = D;
+        up.A = x2; up.lda = D;
         up.ln_w = l.ln2_w; up.ln_b = l.ln2_b; up.eps = 1e-5f;
-        up.W = l.mlp0_w; up.ldw = D; up.bias = l.mlp0_b;
+        up.Wp = l.mlp0_wp; up.bias = l.mlp0_b;
         up.C = w.m1; up.ldc = 4 * D;
         up.M = B; up.N = 4 * D; up.K = D; up.ksplit = 1; up.act = ACT_GELU;
         up.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
         launch_skinny_fused(up, s);
         SkinnyFusedArgs dn;
-        dn.a.base = w.m1; dn.a.ld = 4 * D;
-        dn.W = l.mlp2_w; dn.ldw = 4 * D;
+        dn.A = w.m1; dn.lda = 4 * D;
+        dn.Wp = l.mlp2_wp;
         dn.M = B; dn.N = D; dn.K = 4 * D; dn.ksplit = ks;
         dn.trace = c.trace ? c.trace + 2 * 4096 * 8 : nullptr;
         if (ks > 1) {

@@ -222,9 +222,19 @@ static void finalize_ar(Ctx& c) {
         l.bqkv = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
         launch_fuse_qkv(c.pf(q + "attention.query.weight"), c.pf(q + "attention.key.weight"), c.pf(q + "attention.value.weight"),
                         c.pf(q + "attention.query.bias"), c.pf(q + "attention.key.bias"), c.pf(q + "attention.value.bias"), l.wqkv, l.bqkv, D, 0);
+        if (c.cfg.decode_path == BEVGEN_DECODE_FUSED) {
+            l.mlp0_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(4 * D, D) * sizeof(float)));
+            l.mlp2_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(D, 4 * D) * sizeof(float)));
+            launch_pack_skinny_weight(l.mlp0_w, l.mlp0_wp, 4 * D, D, 0);
+            launch_pack_skinny_weight(l.mlp2_w, l.mlp2_wp, D, 4 * D, 0);
+        }
         c.split_weight(l.wqkv, 3L * D * D);      // used by the prefill GEMMs (the per-token decode GEMMs stream the fp32 weights)
         c.split_weight(l.mlp0_w, 4L * D * D);
         c.split_weight(l.mlp2_w, 4L * D * D);
+    }
+    if (c.cfg.decode_path == BEVGEN_DECODE_FUSED) {
+        c.head_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(g.vocab_size, D) * sizeof(float)));
+        launch_pack_skinny_weight(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);
     }
     // visibility mask: allowed AND layout block present.  Heads with identical layouts share one plane.
     const int blk = g.sparse_block_size, nb = c.L / blk;

@@ -24,33 +24,37 @@
 namespace bevgen {
 
 // ----------------------------------------------------------------------------------------------------------------- row source
+// Every load of an element is requested before the first one is used, and UNCONDITIONALLY: a predicated load (`k < ns ? p[k] : 0`) becomes a
+// divergent branch whose join point waits for the load, i.e. one serialised memory round trip per partial.  The launchers therefore make every
+// pointer valid (rowsrc_fix: absent partials / bias alias `base`) and the kernel only selects which values count.
+constexpr int ROWSRC_MAX_SPLITS = 4;
+inline RowSrc rowsrc_fix(RowSrc r) {
+    if (!r.partial || r.ns == 0) { r.partial = r.base; r.ns = 0; r.pstride = 0; r.pld = r.ld; }
+    r.has_bias = r.bias != nullptr;
+    if (!r.bias) r.bias = r.base;
+    return r;
+}
 __device__ __forceinline__ float rowsrc_at(const RowSrc& r, int m, int c) {
+    float p[ROWSRC_MAX_SPLITS];
+#pragma unroll
+    for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) p[k] = r.partial[(long)(k < r.ns ? k : 0) * r.pstride + (long)m * r.pld + c];
+    const float b = r.bias[r.has_bias ? c : 0];
+    const float x = r.base[(long)m * r.ld + c];
     float s = 0.f;
-    for (int k = 0; k < r.ns; ++k) s += r.partial[(long)k * r.pstride + (long)m * r.pld + c];
-    if (r.bias) s += r.bias[c];
-    return s + r.base[(long)m * r.ld + c];
+#pragma unroll
+    for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) s += k < r.ns ? p[k] : 0.f;
+    return (s + (r.has_bias ? b : 0.f)) + x;
 }
-__device__ __forceinline__ float4 rowsrc_at4(const RowSrc& r, int m, int c) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < r.ns; ++k) {
-        const float4 p = *reinterpret_cast<const float4*>(r.partial + (long)k * r.pstride + (long)m * r.pld + c);
-        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-    }
-    if (r.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(r.bias + c);
-        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-    }
-    const float4 x = *reinterpret_cast<const float4*>(r.base + (long)m * r.ld + c);
-    return make_float4(s.x + x.x, s.y + x.y, s.z + x.z, s.w + x.w);
-}
-
 __global__ __launch_bounds__(256) void rowsrc_materialize_kernel(RowSrc r, float* __restrict__ out, int M, int D, int* counter) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long)M * D) out[i] = rowsrc_at(r, (int)(i / D), (int)(i % D));
+    const long ic = i < (long)M * D ? i : 0;
+    const float v = rowsrc_at(r, (int)(ic / D), (int)(ic % D));
+    if (i < (long)M * D) out[i] = v;
     if (counter && i == 0) *counter += 1;   // the step counter: no kernel of this launch reads it
 }
 
-void launch_rowsrc_materialize(const RowSrc& r, float* out, int M, int D, int* counter, hipStream_t s) {
+void launch_rowsrc_materialize(const RowSrc& r0, float* out, int M, int D, int* counter, hipStream_t s) {
+    const RowSrc r = rowsrc_fix(r0);
     hipLaunchKernelGGL(rowsrc_materialize_kernel, dim3(cdiv((long)M * D, 256)), dim3(256), 0, s, r, out, M, D, counter);
     LAUNCH_CHECK();
 }
@@ -212,10 +216,11 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     AF_TRACE(0);
     // ---- every load that does not depend on another load is requested up front, in the order the results are needed (vmcnt waits are in order):
     //      x rows and ln1 gamma / beta -> first q/k/v weight rows -> bias and visibility row of this step
+    const int tcol = min(tid, D - 1);   // threads beyond D load a valid element and ignore it (no predicated loads, see rowsrc_at)
     float xv[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) xv[g] = tid < D ? rowsrc_at(a.x, b0 + g, tid) : 0.f;
-    const float lw = tid < D ? a.ln_w[tid] : 0.f, lb = tid < D ? a.ln_b[tid] : 0.f;
+    for (int g = 0; g < G; ++g) xv[g] = rowsrc_at(a.x, b0 + g, tcol);
+    const float lw = a.ln_w[tcol], lb = a.ln_b[tcol];
 
     // q/k/v projection: wave w owns rows j = 12 w .. 12 w + 11 of the head's 192 (q | k | v) x 64 rows, fetched RB rows at a time into two register
     // buffers.  The 16 workgroups of a head (one per sequence, same XCD) read the same rows through that XCD's L2: each starts at a different batch
@@ -230,39 +235,37 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         for (int r = 0; r < RB; ++r) {
             const float* p = wptr(wrow(bi, r));
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int col = c * 256 + lane * 4;
-                w[r][c] = col < D ? *reinterpret_cast<const float4*>(p + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int c = 0; c < 4; ++c) w[r][c] = *reinterpret_cast<const float4*>(p + min(c * 256 + lane * 4, D - 4));   // columns >= D: ignored by dot_batch
         }
     };
-    load_batch(0, wb[0]);
-
     // bias row of this step with the visibility mask folded in (shared by every sequence and head of the step): through registers, stored after ln1
     constexpr int BR = 3;
-    const uint8_t* keep_row = a.keep ? a.keep + (long)head * a.keep_head_stride + (long)row * a.ldkeep : nullptr;
-    const float* bias_row = a.bias ? a.bias + (long)row * a.ldbias : nullptr;
-    float bstage[BR];
+    // (the launcher points absent tables at valid memory: has_keep / has_bias say whether the values count)
+    const uint8_t* keep_row = a.keep + (long)head * a.keep_head_stride + (long)row * a.ldkeep;
+    const float* bias_row = a.bias + (long)row * a.ldbias;
+    float braw[BR];
+    uint8_t kraw[BR];
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        const int k = tid + 1024 * j;
-        bstage[j] = kNegBig;
-        if (k < n) {
-            const bool vis = !keep_row || keep_row[k];
-            bstage[j] = vis ? (bias_row ? bias_row[k] * sl2 : 0.f) : kNegBig;
-        }
+    for (int j = 0; j < BR; ++j) {   // raw values, clamped addresses: nothing below touches them before the statistics are done (a use would wait for the loads)
+        const int k = min(tid + 1024 * j, n - 1);
+        braw[j] = bias_row[k];
+        kraw[j] = keep_row[k];
     }
 
     // ---- ln1, thread = column
     {
         float s[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) s[g] = wave_sum_dpp(xv[g]);
+        for (int g = 0; g < G; ++g) s[g] = wave_sum_dpp(tid < D ? xv[g] : 0.f);
         if (lane == 0) {
 #pragma unroll
             for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
         }
         __syncthreads();
+        AF_TRACE(6);
+        // the x rows have arrived: only now request the first weight batch (issued earlier, the 50 MB the 256 workgroups ask their L2s for at
+        // once would queue in front of the later workgroups' x rows)
+        load_batch(0, wb[0]);
         float mean[G], var[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -289,17 +292,16 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
             for (int w = 0; w < NW; ++w) t += stat[w * G + g];
             var[g] = t / (float)D;
         }
+        AF_TRACE(7);
         if (tid < D) {
 #pragma unroll
             for (int g = 0; g < G; ++g) xn_s[g * D + tid] = (xv[g] - mean[g]) * rsqrtf(var[g] + a.eps) * lw + lb;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            if (tid + 1024 * j < n) bias_s[tid + 1024 * j] = bstage[j];
-        for (int k = tid + 1024 * BR; k < n; k += 1024) {   // sequences longer than 3072: the remainder the plain way
-            const bool vis = !keep_row || keep_row[k];
-            bias_s[k] = vis ? (bias_row ? bias_row[k] * sl2 : 0.f) : kNegBig;
-        }
+            if (tid + 1024 * j < n) bias_s[tid + 1024 * j] = (kraw[j] || !a.has_keep) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
+        for (int k = tid + 1024 * BR; k < n; k += 1024)   // sequences longer than 3072: the remainder the plain way
+            bias_s[k] = (keep_row[k] || !a.has_keep) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
         __syncthreads();
     }
 
@@ -453,8 +455,13 @@ bool ar_attn_fused_supported(int B, int G, int D, int H) { return D == H * 64 &&
 void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     ArAttnFusedArgs a = a0;
     BG_REQUIRE(ar_attn_fused_supported(a.B, a.G, a.D, a.H), "fused decode attention: unsupported shape B=%d G=%d D=%d H=%d", a.B, a.G, a.D, a.H);
-    BG_REQUIRE(a.G == 1 || a.prefix > 0, "fused decode attention: group size %d needs a shared prefix length", a.G);
+    BG_REQUIRE(a.x.ns <= ROWSRC_MAX_SPLITS, "fused decode attention: at most %d partial sums per row", ROWSRC_MAX_SPLITS);
     a.Lpad = (int)round_up(a.Lmax, 4);
+    a.x = rowsrc_fix(a.x);
+    a.has_keep = a.keep != nullptr; a.has_bias = a.bias != nullptr;
+    if (!a.keep) { a.keep = reinterpret_cast<const uint8_t*>(a.x.base); a.keep_head_stride = 0; a.ldkeep = 0; }   // any readable memory of >= Lmax bytes
+    if (!a.bias) { a.bias = a.x.base; a.ldbias = 0; }
+    BG_REQUIRE(a.D >= 4 && (a.has_keep || a.D * (int)sizeof(float) >= 0), "fused decode attention: bad width");
     const size_t lds = ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
     dim3 grid(a.H, a.B / a.G);
@@ -476,7 +483,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
 // ----------------------------------------------------------------------------------------------------------------- (ln +) skinny GEMM
 // C[M, N] = act(LN?(A)[M, K] W[N, K]^T + bias), M <= 64.  One workgroup = 16 output columns x one K slice of <= 1024; 8 waves split the slice.
 // The weight slice (64 KB per workgroup) goes straight from HBM into registers with non-temporal 16-byte loads issued first; while it is in
-// flight the workgroup builds its A tile in LDS: rows are fetched through the row source (split-K partials + bias + residual, fixed order),
+// flight the workgroup builds its A tile in LDS: rows are fetched,
 // optionally LayerNorm-ed (two-pass statistics, 32 values per lane, lanes -> waves through LDS), and stored k-chunk-major
 // ([k/4][16 rows][4]) so that both the staging stores and the MFMA operand reads are contiguous 1 KiB per wave (conflict free).
 // v_mfma_f32_16x16x4_f32 (exact fp32): the four k-slots of one MFMA are the four 16-lane quarters, quarter q owns k = 16c + 4q .. +3.
@@ -490,7 +497,7 @@ __device__ __forceinline__ float4 ldg_nt4(const float* p) {
 template <bool LN>
 __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFusedArgs g) {
     __shared__ float4 As[256 * 16];
-    __shared__ float red[SF_WAVES - 1][4][64];
+    __shared__ float red[SF_WAVES][4][64];
     __shared__ float stat[2][SF_WAVES][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -500,14 +507,14 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 
 #define SF_TRACE(i) do { if (g.trace && tid == 0) g.trace[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     SF_TRACE(0);
-    // Loads are requested in the order their results are needed (vmcnt waits are in order): the first A row chunk and the LayerNorm parameters,
-    // THEN the weight slice, so that the statistics are computed while the 64 KB of weights are still in flight.
+    // Loads are requested in the order their results are needed: the first A row chunk and the LayerNorm parameters, THEN the weight slice, so that
+    // the statistics are computed while the 64 KB of weights are still in flight (vmcnt waits are in order per wave).
     auto load_a = [&](int mc, float4 (&v)[8]) {
         const int m = mc * 16 + r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = q + 4 * wave + 32 * j;
-            v[j] = (c < nch && m < g.M) ? rowsrc_at4(g.a, m, kbase + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = min(q + 4 * wave + 32 * j, nch - 1);   // clamped, never predicated (see rowsrc_at); surplus chunks / rows are ignored below
+            v[j] = *reinterpret_cast<const float4*>(g.A + (long)min(m, g.M - 1) * g.lda + kbase + 4 * c);
         }
     };
     float4 v[8];
@@ -516,17 +523,17 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
     if (LN) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = q + 4 * wave + 32 * j;
-            gm[j] = c < nch ? *reinterpret_cast<const float4*>(g.ln_w + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bt[j] = (c < nch && g.ln_b) ? *reinterpret_cast<const float4*>(g.ln_b + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int c = min(q + 4 * wave + 32 * j, nch - 1);
+            gm[j] = *reinterpret_cast<const float4*>(g.ln_w + 4 * c);
+            bt[j] = *reinterpret_cast<const float4*>(g.ln_b + 4 * c);   // launcher: a missing beta aliases gamma, has_ln_b = 0
         }
     }
     float4 wv[8];
     {
-        const int n = min(n0 + r, g.N - 1);
-        const float* wp = g.W + (long)n * g.ldw + kbase + wave * kper + 4 * q;
+        // packed layout (launch_pack_skinny_weight): one wave load = 1 KiB contiguous, the 8 loads of a wave 8 KiB, the workgroup's slice 64 KiB
+        const float* wp = g.Wp + (((long)blockIdx.x * (g.K >> 4) + ((kbase + wave * kper) >> 4)) * 64 + lane) * 4;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = 16 * u < kper ? ldg_nt4(wp + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 8; ++u) wv[u] = ldg_nt4(wp + (long)min(u, (kper >> 4) - 1) * 256);   // u >= kper / 16: a repeat, not used
     }
 
     for (int mc = 0; mc * 16 < g.M; ++mc) {
@@ -534,7 +541,8 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
         if (LN) {
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            for (int j = 0; j < 8; ++j)
+                if (q + 4 * wave + 32 * j < nch) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
             s += __shfl_xor(s, 16, 64);
             s += xor32(s);
             if (q == 0) stat[0][wave][r] = s;
@@ -561,8 +569,9 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
             const float rstd = rsqrtf(t / (float)g.K + g.eps);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                v[j] = make_float4((v[j].x - mean) * rstd * gm[j].x + bt[j].x, (v[j].y - mean) * rstd * gm[j].y + bt[j].y,
-                                   (v[j].z - mean) * rstd * gm[j].z + bt[j].z, (v[j].w - mean) * rstd * gm[j].w + bt[j].w);
+                const float fb = g.has_ln_b ? 1.f : 0.f;
+                v[j] = make_float4(fmaf(bt[j].x, fb, (v[j].x - mean) * rstd * gm[j].x), fmaf(bt[j].y, fb, (v[j].y - mean) * rstd * gm[j].y),
+                                   fmaf(bt[j].z, fb, (v[j].z - mean) * rstd * gm[j].z), fmaf(bt[j].w, fb, (v[j].w - mean) * rstd * gm[j].w));
             }
         }
 #pragma unroll
@@ -584,31 +593,24 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv[u].w, acc, 0, 0, 0);
             }
         }
-        if (wave > 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) red[wave - 1][j][lane] = acc[j];
-        }
+        for (int j = 0; j < 4; ++j) red[wave][j][lane] = acc[j];
         __syncthreads();
         SF_TRACE(2);
-        if (wave == 0) {
+        if (tid < 256) {   // one output element per thread: the 8 waves' partial sums in wave order, then the epilogue
+            // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg; thread t finishes (reg j = t >> 6, lane t & 63)
+            const int j = tid >> 6, ln = tid & 63;
+            float o = 0.f;
 #pragma unroll
-            for (int w = 0; w < SF_WAVES - 1; ++w)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += red[w][j][lane];
-            // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
-            const int col = n0 + r;
-            if (col < g.N) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int mo = mc * 16 + 4 * q + j;
-                    if (mo >= g.M) continue;
-                    if (g.ksplit > 1) {
-                        g.C[((long)split * g.M + mo) * g.N + col] = acc[j];
-                    } else {
-                        float o = acc[j] + (g.bias ? g.bias[col] : 0.f);
-                        if (g.act == ACT_GELU) o = gelu_erf(o);
-                        g.C[(long)mo * g.ldc + col] = o;
-                    }
+            for (int w = 0; w < SF_WAVES; ++w) o += red[w][j][ln];
+            const int col = n0 + (ln & 15), mo = mc * 16 + 4 * (ln >> 4) + j;
+            if (col < g.N && mo < g.M) {
+                if (g.ksplit > 1) {
+                    g.C[((long)split * g.M + mo) * g.N + col] = o;
+                } else {
+                    o += g.bias ? g.bias[col] : 0.f;
+                    if (g.act == ACT_GELU) o = gelu_erf(o);
+                    g.C[(long)mo * g.ldc + col] = o;
                 }
             }
         }
@@ -618,17 +620,40 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 #undef SF_TRACE
 }
 
+// W [N, K] row-major -> tile-major operand image: [N/16 column tiles][K/16 k-chunks][64 lanes][4]; lane l = r + 16 q holds W[16 tile + r][16 chunk + 4 q .. + 3],
+// i.e. exactly the float4 that lane feeds to the four MFMAs of the chunk.  Rows beyond N are zero.
+__global__ __launch_bounds__(256) void pack_skinny_weight_kernel(const float* __restrict__ W, float* __restrict__ Wp, int N, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of the packed image
+    const long total = (long)((N + 15) / 16) * (K >> 4) * 64;
+    if (i >= total) return;
+    const int l = (int)(i & 63);
+    const long ck = i >> 6;
+    const int kc = (int)(ck % (K >> 4));
+    const int tile = (int)(ck / (K >> 4));
+    const int n = tile * 16 + (l & 15), k = kc * 16 + 4 * (l >> 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) v = *reinterpret_cast<const float4*>(W + (long)n * K + k);
+    reinterpret_cast<float4*>(Wp)[i] = v;
+}
+size_t skinny_packed_floats(int N, int K) { return (size_t)cdiv(N, 16) * 16 * K; }
+void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStream_t s) {
+    BG_REQUIRE(K % 16 == 0, "pack_skinny_weight: K=%d must be a multiple of 16", K);
+    const long total = (long)cdiv(N, 16) * (K >> 4) * 64;
+    hipLaunchKernelGGL(pack_skinny_weight_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, W, Wp, N, K);
+    LAUNCH_CHECK();
+}
+
 int skinny_fused_ksplit(int N, int K) {
     // the K slice of one workgroup is at most 1024 (A tile in LDS, W slice in registers); beyond that, split until the grid covers the chip
     int s = 1;
-    while (K / s > 1024 || (cdiv(N, 16) * s < 192 && (K / (s * 2)) % (SF_WAVES * 16) == 0 && K / (s * 2) >= 256)) s *= 2;
+    while (K / s > 1024 || (s < ROWSRC_MAX_SPLITS && cdiv(N, 16) * s < 192 && (K / (s * 2)) % (SF_WAVES * 16) == 0 && K / (s * 2) >= 256)) s *= 2;
     return s;
 }
 
 bool skinny_fused_supported(int M, int N, int K, bool ln) {
     if (M < 1 || M > 64 || K % 4 != 0) return false;
     const int s = ln ? 1 : skinny_fused_ksplit(N, K);
-    if (K % s != 0) return false;
+    if (K % s != 0 || s > ROWSRC_MAX_SPLITS) return false;   // the consumer's row source adds at most ROWSRC_MAX_SPLITS partials
     const int kw = K / s;
     return kw <= 1024 && kw % (SF_WAVES * 16) == 0;
 }
@@ -637,10 +662,13 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     SkinnyFusedArgs g = g0;
     const bool ln = g.ln_w != nullptr;
     if (g.ksplit <= 0) g.ksplit = ln ? 1 : skinny_fused_ksplit(g.N, g.K);
+    g.has_ln_b = g.ln_b != nullptr;
+    if (ln && !g.ln_b) g.ln_b = g.ln_w;
     BG_REQUIRE(skinny_fused_supported(g.M, g.N, g.K, ln) && g.K % g.ksplit == 0 && (g.K / g.ksplit) <= 1024 && (g.K / g.ksplit) % (SF_WAVES * 16) == 0,
                "skinny_fused: unsupported shape M=%d N=%d K=%d ksplit=%d", g.M, g.N, g.K, g.ksplit);
     BG_REQUIRE(!ln || g.ksplit == 1, "skinny_fused: LayerNorm needs the whole row in one workgroup");
-    BG_REQUIRE(g.ldw % 4 == 0 && g.a.ld % 4 == 0, "skinny_fused: strides must be multiples of 4");
+    BG_REQUIRE(g.ksplit <= ROWSRC_MAX_SPLITS, "skinny_fused: at most %d K splits", ROWSRC_MAX_SPLITS);
+    BG_REQUIRE(g.lda % 4 == 0 && g.Wp, "skinny_fused: A stride must be a multiple of 4, weights packed");
     dim3 grid(cdiv(g.N, 16), g.ksplit);
     ProfScope prof(PROF_GEMM_SKINNY, ((double)g.N * g.K + (double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);
     if (ln) hipLaunchKernelGGL(skinny_fused_kernel<true>, grid, dim3(SF_WAVES * 64), 0, s, g);

@@ -154,6 +154,7 @@ struct RowSrc {
     const float* base = nullptr; int ld = 0;
     const float* partial = nullptr; int ns = 0; long pstride = 0; int pld = 0;
     const float* bias = nullptr;
+    int has_bias = 0;                  // filled in by the launchers (absent tables alias `base` so that kernels can load unconditionally)
 };
 void launch_rowsrc_materialize(const RowSrc& r, float* out, int M, int D, int* counter /* or null: incremented by one */, hipStream_t s);
 
@@ -173,19 +174,23 @@ struct ArAttnFusedArgs {
     int prefix = 0;                    // G > 1: leading keys shared by the G sequences of a group (read from the group's first cache slot)
     float scale = 0.125f;
     long long* trace = nullptr;        // diagnostics: [workgroup][8] device timestamps (100 MHz) at the phase boundaries, or null
+    int has_keep = 0, has_bias = 0;    // filled in by the launcher
 };
 bool ar_attn_fused_supported(int B, int G, int D, int H);
 void launch_ar_attn_fused(const ArAttnFusedArgs& a, hipStream_t s);
 
 struct SkinnyFusedArgs {
-    RowSrc a;                          // [M, K]
+    const float* A = nullptr; int lda = 0;   // [M, K]
     const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;   // ln_w != null: LayerNorm over K fused in front of the product
-    const float* W = nullptr; int ldw = 0;   // [N, K]
+    const float* Wp = nullptr;               // [N, K] weights in the packed operand layout (launch_pack_skinny_weight)
     const float* bias = nullptr;       // [N] (ksplit == 1 only)
     float* C = nullptr; int ldc = 0;   // [M, N], or the partial sums [ksplit][M][N] when ksplit > 1
     int M = 0, N = 0, K = 0, ksplit = 0 /* 0 = skinny_fused_ksplit(N, K) */, act = 0;
     long long* trace = nullptr;        // diagnostics, as above
+    int has_ln_b = 0;                  // filled in by the launcher
 };
+size_t skinny_packed_floats(int N, int K);
+void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStream_t s);
 int skinny_fused_ksplit(int N, int K);
 bool skinny_fused_supported(int M, int N, int K, bool ln);
 void launch_skinny_fused(const SkinnyFusedArgs& g, hipStream_t s);

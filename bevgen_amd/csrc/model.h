@@ -43,6 +43,7 @@ struct ArLayer {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     float *wqkv, *bqkv;  // fused [3D, D], [3D], owned
     const float *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
+    float *mlp0_wp = nullptr, *mlp2_wp = nullptr;   // decode-step operand images of the MLP weights (owned; fused decode path)
 };
 
 struct ConvW { float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };  // w re-laid [Cout][kh][kw][Cin] (owned)
@@ -76,6 +77,7 @@ struct Ctx {
 
     // ---- Route A
     std::vector<ArLayer> ar;
+    float* head_wp = nullptr;      // packed head.weight (fused decode path)
     uint8_t* keep = nullptr;       // [Hk, L, L]
     int keep_heads = 1;
     float* prefill_bias = nullptr; // [Hk, K, Kpad]

@@ -308,6 +308,17 @@ class Context:
         self._check(self.lib.bevgen_op_gemm(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(c), M, N, K, int(gelu), int(skinny), _stream()))
         return c
 
+    def op_ln_gemm(self, a, w, ln_w=None, ln_b=None, bias=None, gelu=False, ksplit=0, eps=1e-5):
+        """Decode-step projection kernel: act(LN?(a) w^T + bias); with K split over workgroups the partial sums are added here (the model path folds
+        that sum into the consumer's row fetch)."""
+        M, K = a.shape
+        N = w.shape[0]
+        ks = C.c_int(0)
+        out = torch.empty((4, M, N), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_op_ln_gemm(self._h, _ptr(a), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(w), _ptr(bias), _ptr(out), M, N, K, int(gelu), int(ksplit),
+                                               C.byref(ks), _stream()))
+        return out[0] if ks.value == 1 else out[:ks.value].sum(0)
+
     def op_layernorm(self, x, gamma, beta=None, eps=1e-5):
         y = torch.empty_like(x)
         self._check(self.lib.bevgen_op_layernorm(self._h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), x.shape[0], x.shape[1], float(eps), _stream()))

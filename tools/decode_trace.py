@@ -34,6 +34,8 @@ for k, (name, pts) in enumerate(names):
         continue
     t0 = t[:, 0].min()
     print(f"{name}: {t.shape[0]} workgroups; first start -> last end {float(t[:, len(pts) - 1].max() - t0):.2f} us; start skew {float(t[:, 0].max() - t0):.2f} us")
+    if k == 0:
+        print(f"    x rows arrived + first barrier at mean {float((t[:, 6] - t0).mean()):.2f} us; statistics done at mean {float((t[:, 7] - t0).mean()):.2f} us")
     for i in range(1, len(pts)):
         d = t[:, i] - t[:, i - 1]
         print(f"    {pts[i - 1]:>16} -> {pts[i]:<16} mean {float(d.mean()):6.2f}  min {float(d.min()):6.2f}  max {float(d.max()):6.2f} us   (done at mean {float((t[:, i] - t0).mean()):6.2f})")

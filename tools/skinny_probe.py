@@ -1,22 +1,18 @@
 #!/usr/bin/env python
-"""Decode-step projection shapes through the skinny GEMM (HIP-event time per launch): usage skinny_probe.py [M]"""
+"""Decode-step projection through the fused skinny kernel, for rocprofv3 kernel traces: `cold` = 24 different weight matrices (every launch
+streams from HBM), `warm` = one matrix re-used (L2 / Infinity-Cache resident).  usage: skinny_probe.py M cold|warm N K ln"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bevgen_amd.runtime import Context
 
-M = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+M, mode, N, K, ln = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 ctx = Context(None)
-for (N, K) in [(3072, 1024), (4096, 1024), (1024, 4096), (1024, 1024)]:
-    a = torch.randn(M, K, device="cuda")
-    ws = [torch.randn(N, K, device="cuda") * 0.03 for _ in range(24)]   # 24 different weight matrices: every launch streams from HBM
-    for w in ws[:2]:
-        ctx.op_gemm(a, w, skinny=True)
-    torch.cuda.synchronize()
-    ctx.profile_begin()
-    for w in ws:
-        ctx.op_gemm(a, w, skinny=True)
-    torch.cuda.synchronize()
-    p = ctx.profile_end()["gemm_skinny"]
-    us = p["ms"] * 1e3 / p["launches"]
-    print(f"M={M} N={N} K={K}: {us:.2f} us per launch, {N * K * 4 / us / 1e6:.2f} TB/s of weights")
+a = torch.randn(M, K, device="cuda")
+g, b = torch.randn(K, device="cuda"), torch.randn(K, device="cuda")
+ws = [torch.randn(N, K, device="cuda") * 0.03 for _ in range(24)]
+seq = ws if mode == "cold" else [ws[0]] * 24
+for rep in range(10):
+    for w in seq:
+        ctx.op_ln_gemm(a, w, ln_w=g if ln else None, ln_b=b if ln else None)
+torch.cuda.synchronize()
