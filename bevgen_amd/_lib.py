@@ -13,11 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVGEN_LIB_PATH") or os.path.join(_HERE, "csrc", "libbevgen_hip.so")   # override: A/B runs of two builds on one GPU box
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevgen_hip.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
 DECODE_FUSED, DECODE_PER_OP = 0, 1
+VQ_OUT_RAW, VQ_OUT_DENORM, VQ_OUT_U8 = 0, 1, 2
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_F64 = 0, 1, 2, 3
 
 
@@ -63,9 +64,9 @@ SIGNATURES = {
     "bevgen_ar_decode_step": (_i, [_p, _p, _p]),
     "bevgen_ar_sample": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _p, _p]),
     "bevgen_ar_sample_forced": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _i, _p, _p, _p, _p]),
-    "bevgen_vq_decode": (_i, [_p, _p, _i, _i, _p, _p]),
-    "bevgen_vq_decode_latents": (_i, [_p, _p, _i, _i, _p, _p]),
-    "bevgen_vq_encode": (_i, [_p, _p, _i, _p, _p]),
+    "bevgen_vq_decode": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "bevgen_vq_decode_latents": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "bevgen_vq_encode": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "bevgen_op_gemm": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "bevgen_op_ln_gemm": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _p]),
     "bevgen_op_layernorm": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),

@@ -167,31 +167,37 @@ int bevgen_ar_sample_forced(bevgen_ctx* ctx, const int64_t* cond, const float* I
     });
 }
 
-int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* ids, int n, int denormalize, float* out, void* stream) {
+static void vq_default_grid(const bevgen_ctx* ctx, int& h, int& w) {   // 0 x 0 = the square grid of ddconfig.resolution
+    if (h <= 0 || w <= 0) h = w = ctx->cfg.vq_resolution >> (ctx->cfg.vq_num_levels - 1);
+}
+
+int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* ids, int n, int lat_h, int lat_w, int out_mode, void* out, void* stream) {
     return guarded(ctx, [&] {
         need_final(ctx);
-        BG_REQUIRE(ids && out && n >= 1, "vq_decode: bad arguments");
-        vq_decode(*ctx, ids, nullptr, n, denormalize, out, (hipStream_t)stream);
+        BG_REQUIRE(ids && out && n >= 1 && out_mode >= 0 && out_mode <= 2, "vq_decode: bad arguments");
+        vq_default_grid(ctx, lat_h, lat_w);
+        vq_decode(*ctx, ids, nullptr, n, lat_h, lat_w, out_mode, out, (hipStream_t)stream);
     });
 }
 
-int bevgen_vq_encode(bevgen_ctx* ctx, const float* x, int n, int64_t* ids, void* stream) {
+int bevgen_vq_encode(bevgen_ctx* ctx, const float* x, int n, int H, int W, int64_t* ids, void* stream) {
     return guarded(ctx, [&] {
         need_final(ctx);
         BG_REQUIRE(x && ids && n >= 1, "vq_encode: bad arguments");
-        vq_encode(*ctx, x, n, ids, (hipStream_t)stream);
+        if (H <= 0 || W <= 0) H = W = ctx->cfg.vq_resolution;
+        vq_encode(*ctx, x, n, H, W, ids, (hipStream_t)stream);
     });
 }
 
-int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* zq, int n, int denormalize, float* out, void* stream) {
+int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* zq, int n, int lat_h, int lat_w, int out_mode, void* out, void* stream) {
     return guarded(ctx, [&] {
         need_final(ctx);
-        BG_REQUIRE(zq && out && n >= 1, "vq_decode_latents: bad arguments");
-        vq_decode(*ctx, nullptr, zq, n, denormalize, out, (hipStream_t)stream);
+        BG_REQUIRE(zq && out && n >= 1 && out_mode >= 0 && out_mode <= 2, "vq_decode_latents: bad arguments");
+        vq_default_grid(ctx, lat_h, lat_w);
+        vq_decode(*ctx, nullptr, zq, n, lat_h, lat_w, out_mode, out, (hipStream_t)stream);
     });
 }
 
-// ------------------------------------------------------------------------------------------------ operator-level entry points
 int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float* bias, const float* residual, float* c, int M, int N, int K, int act_gelu, int skinny,
                    void* stream) {
     return guarded(ctx, [&] {

@@ -200,7 +200,7 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
         launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, G, H, K, 0, Lk, s);   // cache slots [0, G) for now
         if (kvd) launch_ar_qkv_scatter(qkv, nullptr, kcb, vcb, kvd, G, H, K, 0, L, s);   // the fp16 image the decode steps read
         AttnArgs a{};
-        a.Q = Q; a.K = kc; a.V = vc; a.bias = c.prefill_bias; a.R = xn; a.O = x2;
+        a.Q = Q; a.K = kc; a.V = vc; a.bias = c.prefill_bias + (c.keep_layers > 1 ? (size_t)i * c.keep_heads * K * c.Kpad : 0); a.R = xn; a.O = x2;
         a.B = G; a.H = H; a.Nq = K; a.Nk_pad = c.Kpad;
         a.q_bstride = (long)H * K * 64; a.q_hstride = (long)K * 64;
         a.kv_bstride = (long)H * Lk * 64; a.kv_hstride = (long)Lk * 64;
@@ -281,7 +281,7 @@ static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipS
         a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes;
         a.kv_dtype = cache_dtype(c);
         a.bias = c.attn_bias; a.ldbias = L;
-        a.keep = c.keep; a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
+        a.keep = c.keep + (c.keep_layers > 1 ? (size_t)i * c.keep_heads * L * L : 0); a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
         a.out = x2; a.ldo = D;
         a.B = B; a.G = st.G; a.H = H; a.D = D; a.Lmax = L;
         a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step;
@@ -338,7 +338,7 @@ static void decode_step_launch(Ctx& c, StepWs& w, const int64_t* tok, hipStream_
         a.append_k = w.qkv + D; a.append_v = w.qkv + 2 * D;  // the new row (sequence position K + step) is appended inside the attention kernel
         a.kcache = kc; a.vcache = vc;
         a.bias = c.attn_bias; a.ldbias = L;
-        a.keep = c.keep; a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
+        a.keep = c.keep + (c.keep_layers > 1 ? (size_t)i * c.keep_heads * L * L : 0); a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
         a.R = w.xn; a.ldr = D; a.O = w.x2; a.ldo = D;
         a.B = B; a.H = H; a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step; a.Lmax = L;
         a.scale = 0.125f; a.kv_dtype = cache_dtype(c);

@@ -236,22 +236,40 @@ static void finalize_ar(Ctx& c) {
         c.head_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(g.vocab_size, D) * sizeof(float)));
         launch_pack_skinny_weight(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);
     }
-    // visibility mask: allowed AND layout block present.  Heads with identical layouts share one plane.
+    // visibility mask: allowed AND layout block present.  The reference keeps one layout buffer PER LAYER in the checkpoint
+    // (blocks.{i}.attention.sparse_self_attention.master_layout, drawn at construction when density < 1: mingpt_sparse.py:176, mask_generator.py:217-228);
+    // a layer without one uses table.layout.  Identical layers / heads share one plane.
     const int blk = g.sparse_block_size, nb = c.L / blk;
-    const DevTensor& lay = c.need("table.layout");
-    BG_REQUIRE(lay.dtype == BEVGEN_DTYPE_I64 && lay.numel() == (long)c.H * nb * nb, "table.layout must be int64 [H=%d, %d, %d]", c.H, nb, nb);
+    const size_t lay_n = (size_t)c.H * nb * nb;
     expect_shape(c, "table.attention_mask", {c.L, c.L});
-    std::vector<int64_t> hl(lay.numel());
-    HIP_CHECK(hipMemcpy(hl.data(), lay.ptr, lay.bytes, hipMemcpyDeviceToHost));
-    bool same = true;
-    for (int h = 1; h < c.H && same; ++h) same = std::memcmp(hl.data(), hl.data() + (size_t)h * nb * nb, (size_t)nb * nb * sizeof(int64_t)) == 0;
-    c.keep_heads = same ? 1 : c.H;
-    c.keep = reinterpret_cast<uint8_t*>(c.own((size_t)c.keep_heads * c.L * c.L));
-    launch_build_keep(c.pf("table.attention_mask"), reinterpret_cast<const int64_t*>(lay.ptr), c.keep, c.keep_heads, c.L, blk, 0);
+    std::vector<const DevTensor*> lays(g.num_layers);
+    std::vector<std::vector<int64_t>> hl(g.num_layers);
+    for (int i = 0; i < g.num_layers; ++i) {
+        const DevTensor* t = c.find("blocks." + std::to_string(i) + ".attention.sparse_self_attention.master_layout");
+        if (!t) t = &c.need("table.layout");
+        BG_REQUIRE(t->dtype == BEVGEN_DTYPE_I64 && (size_t)t->numel() == lay_n, "layout of layer %d must be int64 [H=%d, %d, %d]", i, c.H, nb, nb);
+        lays[i] = t;
+        hl[i].resize(lay_n);
+        HIP_CHECK(hipMemcpy(hl[i].data(), t->ptr, t->bytes, hipMemcpyDeviceToHost));
+    }
+    bool same_layers = true, same_heads = true;
+    for (int i = 0; i < g.num_layers; ++i) {
+        if (i > 0 && hl[i] != hl[0]) same_layers = false;
+        for (int h = 1; h < c.H && same_heads; ++h)
+            same_heads = std::memcmp(hl[i].data(), hl[i].data() + (size_t)h * nb * nb, (size_t)nb * nb * sizeof(int64_t)) == 0;
+    }
+    c.keep_heads = same_heads ? 1 : c.H;
+    c.keep_layers = same_layers ? 1 : g.num_layers;
+    const size_t plane = (size_t)c.keep_heads * c.L * c.L;
+    c.keep = reinterpret_cast<uint8_t*>(c.own(plane * c.keep_layers));
     // prefill bias over the condition rows: scale*(bias) where visible, -1e30 elsewhere
     c.Kpad = (int)round_up(c.K, 32);
-    c.prefill_bias = reinterpret_cast<float*>(c.own((size_t)c.keep_heads * c.K * c.Kpad * sizeof(float)));
-    launch_build_masked_bias(c.attn_bias, c.keep, (long)c.L * c.L, c.L, c.prefill_bias, c.keep_heads, c.K, c.K, c.Kpad, c.L, 0.125f, 0);
+    const size_t pb = (size_t)c.keep_heads * c.K * c.Kpad;
+    c.prefill_bias = reinterpret_cast<float*>(c.own(pb * c.keep_layers * sizeof(float)));
+    for (int i = 0; i < c.keep_layers; ++i) {
+        launch_build_keep(c.pf("table.attention_mask"), reinterpret_cast<const int64_t*>(lays[i]->ptr), c.keep + i * plane, c.keep_heads, c.L, blk, 0);
+        launch_build_masked_bias(c.attn_bias, c.keep + i * plane, (long)c.L * c.L, c.L, c.prefill_bias + i * pb, c.keep_heads, c.K, c.K, c.Kpad, c.L, 0.125f, 0);
+    }
 }
 
 void ctx_finalize(Ctx& c) {

@@ -236,9 +236,10 @@ void launch_ar_pick(const float* logits, int ldl, const float* u /*[steps, rows]
 // ---------------------------------------------------------------- vq.hip
 void launch_codebook_gather(const int64_t* ids, const float* codebook, float* out, int rows, int dim, int n_embed, hipStream_t s);
 // NHWC [n,hw,C] -> NCHW [n,C,hw] with optional per-channel x*std+mean and clamp to [0,1] (bev_utils/util.py:97-118)
-void launch_nhwc_to_nchw(const float* x, float* y, int n, int hw, int C, int ldc, const float* mean, const float* stdv, int clamp01, hipStream_t s);
+void launch_nhwc_to_nchw(const float* x, float* y, int n, int hw, int C, int ldc, const float* mean, const float* stdv, int clamp01, hipStream_t s,
+                         uint8_t* y8 = nullptr /* non-null: write round(v*255) as uint8 here instead of fp32 y */);
 void launch_nchw_to_nhwc(const float* x, float* y, int n, int hw, int C, hipStream_t s);
-void launch_row_softmax(float* x, int rows, int cols, float scale, hipStream_t s);
+void launch_row_softmax(float* x, int rows, int cols, float scale, hipStream_t s, int ld = 0 /* row stride (0 = cols); columns [cols, ld) are zero-filled */);
 
 // misc
 void launch_fill(float* p, long n, float v, hipStream_t s);

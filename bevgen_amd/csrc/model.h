@@ -78,9 +78,9 @@ struct Ctx {
     // ---- Route A
     std::vector<ArLayer> ar;
     float* head_wp = nullptr;      // packed head.weight (fused decode path)
-    uint8_t* keep = nullptr;       // [Hk, L, L]
-    int keep_heads = 1;
-    float* prefill_bias = nullptr; // [Hk, K, Kpad]
+    uint8_t* keep = nullptr;       // [keep_layers, Hk, L, L]
+    int keep_heads = 1, keep_layers = 1;   // planes per layer (1 = shared by all heads) / layers with their own planes (1 = shared)
+    float* prefill_bias = nullptr; // [keep_layers, Hk, K, Kpad]
     int Kpad = 0;
     // per-batch decode state (lives in `persist`)
     struct ArState {
@@ -147,8 +147,8 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
                const float* noise_u, int samples_per_layout, const int64_t* forced, int64_t* out, float* step_logits, hipStream_t s);
 // vqdec.cpp
 void vq_finalize(Ctx& c);
-void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n, int denorm, float* out, hipStream_t s);
-void vq_encode(Ctx& c, const float* x_nchw, int n, int64_t* ids, hipStream_t s);
+void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n, int lat_h, int lat_w, int out_mode, void* out, hipStream_t s);
+void vq_encode(Ctx& c, const float* x_nchw, int n, int RH, int RW, int64_t* ids, hipStream_t s);
 // vqenc_kernels.hip
 void launch_nchw_to_nhwc_pad(const float* x, float* y, int n, int hw, int C, int Cpad, hipStream_t s);
 void launch_relayout_conv_weight_pad(const float* w, float* o, int cout, int cin, int cin_pad, int kh, int kw, hipStream_t s);

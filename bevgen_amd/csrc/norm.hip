@@ -339,11 +339,11 @@ void launch_groupnorm_apply_planes(const float* x, const float* stats, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ row softmax (VQGAN AttnBlock, s1model:179-181)
-__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x, int rows, int cols, float scale) {
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x, int rows, int cols, float scale, int ld) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float* xr = x + row * cols;
+    float* xr = x + row * ld;
     float mx = kNegBig;
     for (int i = lane; i < cols; i += 64) mx = fmaxf(mx, xr[i] * scale);
     mx = wave_max(mx);
@@ -352,10 +352,11 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x,
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
     for (int i = lane; i < cols; i += 64) xr[i] = expf(xr[i] * scale - mx) * inv;
+    for (int i = cols + lane; i < ld; i += 64) xr[i] = 0.f;
 }
 
-void launch_row_softmax(float* x, int rows, int cols, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(row_softmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, cols, scale);
+void launch_row_softmax(float* x, int rows, int cols, float scale, hipStream_t s, int ld) {
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, cols, scale, ld > 0 ? ld : cols);
     LAUNCH_CHECK();
 }
 

@@ -25,7 +25,7 @@ void launch_codebook_gather(const int64_t* ids, const float* codebook, float* ou
 
 // x [n, hw, ldc] (first C channels used) -> y [n, C, hw]
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int hw, int C, int ldc,
-                                                           const float* __restrict__ mean, const float* __restrict__ stdv, int clamp01) {
+                                                           const float* __restrict__ mean, const float* __restrict__ stdv, int clamp01, uint8_t* __restrict__ y8) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int p = (int)(i % hw);
         const long nc = i / hw;
@@ -34,13 +34,14 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
         float v = x[(n * hw + p) * ldc + c];
         if (mean) v = v * stdv[c] + mean[c];
         if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-        y[i] = v;
+        if (y8) y8[i] = (uint8_t)fminf(fmaxf(rintf(v * 255.0f), 0.f), 255.f);   // round(x*255) (half to even, like torch.round), the storage format of the images
+        else y[i] = v;
     }
 }
 
-void launch_nhwc_to_nchw(const float* x, float* y, int n, int hw, int C, int ldc, const float* mean, const float* stdv, int clamp01, hipStream_t s) {
+void launch_nhwc_to_nchw(const float* x, float* y, int n, int hw, int C, int ldc, const float* mean, const float* stdv, int clamp01, hipStream_t s, uint8_t* y8) {
     const long total = (long)n * C * hw;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, y, total, hw, C, ldc, mean, stdv, clamp01);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, y, total, hw, C, ldc, mean, stdv, clamp01, y8);
     LAUNCH_CHECK();
 }
 

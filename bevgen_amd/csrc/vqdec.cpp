@@ -109,31 +109,33 @@ void resblock(const ResBlockW& r, Act& x, float* y, float* scratch, DecWs& ws, h
 
 void attnblock(const AttnBlockW& a, Act& x, float* y, DecWs& ws, hipStream_t s) {
     const int hw = x.h * x.w, C = a.c, n = x.n;
+    const int hwp = (int)round_up(hw, 32);   // key dimension padded to the GEMM's k granularity (non-square latents: 14 x 25 = 350 -> 352); pad keys carry P = 0, v = 0
     const long rows = (long)n * hw;
     Act t{ws.t, n, x.h, x.w, C};
     gn(x, a.nw, a.nb, ws.t, 0, ws, s);
     conv1(ws.t, rows, a.q, ws.q, nullptr, s);
     conv1(ws.t, rows, a.k, ws.k, nullptr, s);
+    if (hwp != hw) HIP_CHECK(hipMemsetAsync(ws.vT, 0, (size_t)n * C * hwp * sizeof(float), s));
     {   // vT[img] [C, hw] = Wv [C,C] * h_img^T + bias (per row)
         GemmArgs g;
         g.A = a.v.w; g.B = ws.t; g.C = ws.vT; g.bias_m = a.v.b;
-        g.M = C; g.N = hw; g.K = C; g.lda = C; g.ldb = C; g.ldc = hw;
-        g.batch = n; g.strideA = 0; g.strideB = (long)hw * C; g.strideC = (long)C * hw;
+        g.M = C; g.N = hw; g.K = C; g.lda = C; g.ldb = C; g.ldc = hwp;
+        g.batch = n; g.strideA = 0; g.strideB = (long)hw * C; g.strideC = (long)C * hwp;
         launch_gemm(g, s);
     }
     {   // S[img] [hw, hw] = q k^T
         GemmArgs g;
         g.A = ws.q; g.B = ws.k; g.C = ws.S;
-        g.M = hw; g.N = hw; g.K = C; g.lda = C; g.ldb = C; g.ldc = hw;
-        g.batch = n; g.strideA = (long)hw * C; g.strideB = (long)hw * C; g.strideC = (long)hw * hw;
+        g.M = hw; g.N = hw; g.K = C; g.lda = C; g.ldb = C; g.ldc = hwp;
+        g.batch = n; g.strideA = (long)hw * C; g.strideB = (long)hw * C; g.strideC = (long)hw * hwp;
         launch_gemm(g, s);
     }
-    launch_row_softmax(ws.S, (int)rows, hw, 1.0f / sqrtf((float)C), s);  // w_ * int(c)**-0.5, softmax over keys
+    launch_row_softmax(ws.S, (int)rows, hw, 1.0f / sqrtf((float)C), s, hwp);  // w_ * int(c)**-0.5, softmax over keys
     {   // O[img] [hw, C] = P [hw,hw] * v [hw, C]  (B operand = vT [C, hw])
         GemmArgs g;
         g.A = ws.S; g.B = ws.vT; g.C = ws.q;  // reuse q as the output buffer
-        g.M = hw; g.N = C; g.K = hw; g.lda = hw; g.ldb = hw; g.ldc = C;
-        g.batch = n; g.strideA = (long)hw * hw; g.strideB = (long)C * hw; g.strideC = (long)hw * C;
+        g.M = hw; g.N = C; g.K = hwp; g.lda = hwp; g.ldb = hwp; g.ldc = C;
+        g.batch = n; g.strideA = (long)hw * hwp; g.strideB = (long)C * hwp; g.strideC = (long)hw * C;
         launch_gemm(g, s);
     }
     conv1(ws.q, rows, a.proj, y, x.p, s);  // x + proj_out(h)
@@ -186,34 +188,40 @@ void vq_finalize(Ctx& c) {
     HIP_CHECK(hipMemcpy(c.denorm_std, stdv, sizeof stdv, hipMemcpyHostToDevice));
 }
 
-void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_total, int denorm, float* out, hipStream_t s) {
+// The decoder is fully convolutional (stage1/model.py:506-537): the latent grid is lat_h x lat_w (cam_latent_res, e.g. 16 x 16 or nuScenes' 14 x 25), the output
+// (lat_h << (levels-1)) x (lat_w << (levels-1)); which levels carry AttnBlocks is decided by ddconfig.resolution alone (curr_res == attn_resolutions, :466-480).
+// out_mode: 0 = raw fp32, 1 = denormalised fp32 in [0,1], 2 = denormalised uint8 round(x*255) (`out` then points to uint8).
+void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_total, int lat_h, int lat_w, int out_mode, void* out, hipStream_t s) {
     BG_REQUIRE(c.has_vq, "this context holds no VQGAN decoder weights (decoder.* tensors were not loaded)");
     const auto& g = c.cfg;
     const bool planes = g.precision == BEVGEN_PRECISION_F16X3;   // split-precision mode: GroupNorm writes (hi, lo) planes, convolutions read them by LDS-DMA
-    const int lat = g.vq_resolution >> (g.vq_num_levels - 1);
-    const int R = g.vq_resolution;
+    BG_REQUIRE(lat_h >= 1 && lat_w >= 1, "vq_decode: latent grid %d x %d", lat_h, lat_w);
+    const int denorm = out_mode != 0;
+    const long lat_hw = (long)lat_h * lat_w;
+    const int RH = lat_h << (g.vq_num_levels - 1), RW = lat_w << (g.vq_num_levels - 1);
     BG_REQUIRE(!denorm || g.vq_out_ch == 3, "denormalize needs 3 output channels");
-    // widest activation per image: max over levels of res^2 * channels
-    long per_img = 0;
+    // widest activation per image: max over levels of h*w * channels; most attention tokens over the levels that carry AttnBlocks
+    long per_img = 0, attn_hw = lat_hw;
     int max_c = 0;
     {
-        int res = lat;
+        long hw = lat_hw;
         for (int lvl = g.vq_num_levels - 1; lvl >= 0; --lvl) {
             const int ch = g.vq_ch * g.vq_ch_mult[lvl];
             const int ch_in = lvl == g.vq_num_levels - 1 ? ch : g.vq_ch * g.vq_ch_mult[lvl + 1];
-            per_img = std::max<long>(per_img, (long)res * res * std::max(ch, ch_in));
+            per_img = std::max<long>(per_img, hw * std::max(ch, ch_in));
             max_c = std::max(max_c, std::max(ch, ch_in));
-            if (lvl != 0) res *= 2;
+            if (!c.up[lvl].attns.empty()) attn_hw = std::max(attn_hw, hw);
+            if (lvl != 0) hw *= 4;
         }
     }
+    const long attn_hwp = round_up(attn_hw, 32);
     const int chunk_max = 16;
     const int attn_c = max_c;
-    const long attn_hw = std::max<long>((long)g.vq_attn_resolution * g.vq_attn_resolution, (long)lat * lat);
     const int chunk = std::min(n_total, chunk_max);
     const size_t act_b = (size_t)per_img * chunk * sizeof(float);
-    const size_t need = 4 * act_b + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, R * R) +
-                        (size_t)chunk * attn_hw * (3 * attn_c + attn_hw) * sizeof(float) + (size_t)chunk * lat * lat * g.vq_embed_dim * sizeof(float) +
-                        (size_t)chunk * R * R * 4 * sizeof(float) + 32 * 256;
+    const size_t need = 4 * act_b + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, RH * RW) +
+                        (size_t)chunk * attn_hwp * (3 * attn_c + attn_hwp) * sizeof(float) + (size_t)chunk * lat_hw * g.vq_embed_dim * sizeof(float) +
+                        (size_t)chunk * RH * RW * 4 * sizeof(float) + 32 * 256;
     c.arena.reserve(need);
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
         const int n = std::min(chunk, n_total - i0);
@@ -223,21 +231,21 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
         ws.b = c.arena.get<float>((size_t)per_img * n);
         ws.t = c.arena.get<float>((size_t)per_img * n);
         ws.stats = c.arena.get<float>((size_t)n * 64);
-        ws.gn_ws = c.arena.alloc(groupnorm_ws_bytes(n, R * R));
-        ws.q = c.arena.get<float>((size_t)n * attn_hw * attn_c);
-        ws.k = c.arena.get<float>((size_t)n * attn_hw * attn_c);
-        ws.vT = c.arena.get<float>((size_t)n * attn_hw * attn_c);
-        ws.S = c.arena.get<float>((size_t)n * attn_hw * attn_hw);
-        float* zq = c.arena.get<float>((size_t)n * lat * lat * g.vq_embed_dim);
-        float* img = c.arena.get<float>((size_t)n * R * R * 4);
+        ws.gn_ws = c.arena.alloc(groupnorm_ws_bytes(n, RH * RW));
+        ws.q = c.arena.get<float>((size_t)n * attn_hwp * attn_c);
+        ws.k = c.arena.get<float>((size_t)n * attn_hwp * attn_c);
+        ws.vT = c.arena.get<float>((size_t)n * attn_hwp * attn_c);
+        ws.S = c.arena.get<float>((size_t)n * attn_hwp * attn_hwp);
+        float* zq = c.arena.get<float>((size_t)n * lat_hw * g.vq_embed_dim);
+        float* img = c.arena.get<float>((size_t)n * RH * RW * 4);
 
-        const long lrows = (long)n * lat * lat;
-        if (ids) launch_codebook_gather(ids + (long)i0 * lat * lat, c.codebook, zq, (int)lrows, g.vq_embed_dim, g.vq_n_embed, s);
-        else launch_nchw_to_nhwc(latents_nchw + (long)i0 * g.vq_embed_dim * lat * lat, zq, n, lat * lat, g.vq_embed_dim, s);
+        const long lrows = (long)n * lat_hw;
+        if (ids) launch_codebook_gather(ids + (long)i0 * lat_hw, c.codebook, zq, (int)lrows, g.vq_embed_dim, g.vq_n_embed, s);
+        else launch_nchw_to_nhwc(latents_nchw + (long)i0 * g.vq_embed_dim * lat_hw, zq, n, (int)lat_hw, g.vq_embed_dim, s);
         conv1(zq, lrows, c.post_quant, ws.t, nullptr, s);                       // post_quant_conv
-        Act x{ws.t, n, lat, lat, g.vq_z_channels};
+        Act x{ws.t, n, lat_h, lat_w, g.vq_z_channels};
         conv3(x, c.conv_in, ws.a, nullptr, 0, s);                               // conv_in
-        x = Act{ws.a, n, lat, lat, c.conv_in.cout};
+        x = Act{ws.a, n, lat_h, lat_w, c.conv_in.cout};
         // three rotating activation buffers (input / scratch / output of a block) + ws.t for the normalised tensor
         float* o = c.arena.get<float>((size_t)per_img * n);
         auto res_step = [&](const ResBlockW& r) {
@@ -272,9 +280,10 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
         }
         gn(x, c.norm_out_w, c.norm_out_b, ws.t, 1, ws, s, planes);
         Act t{ws.t, x.n, x.h, x.w, x.c};
-        conv3(t, c.conv_out, img, nullptr, 0, s, planes);  // [n, R*R, out_ch]
-        launch_nhwc_to_nchw(img, out + (long)i0 * g.vq_out_ch * R * R, n, R * R, g.vq_out_ch, g.vq_out_ch, denorm ? c.denorm_mean : nullptr,
-                            denorm ? c.denorm_std : nullptr, denorm ? 1 : 0, s);
+        conv3(t, c.conv_out, img, nullptr, 0, s, planes);  // [n, RH*RW, out_ch]
+        const long o_off = (long)i0 * g.vq_out_ch * RH * RW;
+        launch_nhwc_to_nchw(img, out_mode == 2 ? nullptr : reinterpret_cast<float*>(out) + o_off, n, RH * RW, g.vq_out_ch, g.vq_out_ch, denorm ? c.denorm_mean : nullptr,
+                            denorm ? c.denorm_std : nullptr, denorm ? 1 : 0, s, out_mode == 2 ? reinterpret_cast<uint8_t*>(out) + o_off : nullptr);
     }
 }
 
@@ -331,28 +340,32 @@ static void vq_enc_finalize(Ctx& c) {
     launch_row_sqnorm(c.codebook, c.codebook_sqnorm, g.vq_n_embed, g.vq_embed_dim, 0);
 }
 
-void vq_encode(Ctx& c, const float* x_nchw, int n_total, int64_t* ids, hipStream_t s) {
+// x [n, in_channels, RH, RW] with RH, RW multiples of 2^(levels-1) (fully convolutional: 256 x 256 or nuScenes' 224 x 400) -> ids [n, (RH >> (levels-1)) * (RW >> (levels-1))]
+void vq_encode(Ctx& c, const float* x_nchw, int n_total, int RH, int RW, int64_t* ids, hipStream_t s) {
     BG_REQUIRE(c.has_vq_enc, "this context holds no VQGAN encoder weights (encoder.* tensors were not loaded)");
     const auto& g = c.cfg;
     const bool planes = g.precision == BEVGEN_PRECISION_F16X3;   // split-precision mode: GroupNorm writes (hi, lo) planes, convolutions read them by LDS-DMA
-    const int R = g.vq_resolution;
-    const int lat = R >> (g.vq_num_levels - 1);
-    long per_img = (long)R * R * std::max(c.enc_cin_pad, g.vq_ch);
+    const int f = 1 << (g.vq_num_levels - 1);
+    BG_REQUIRE(RH >= f && RW >= f && RH % f == 0 && RW % f == 0, "vq_encode: image %d x %d is not a multiple of the downsampling factor %d", RH, RW, f);
+    const int lat_h = RH / f, lat_w = RW / f;
+    const long lat_hw = (long)lat_h * lat_w;
+    long per_img = (long)RH * RW * std::max(c.enc_cin_pad, g.vq_ch), attn_hw = lat_hw;
     int max_c = g.vq_ch;
     {
-        int res = R;
+        long hw = (long)RH * RW;
         for (int lvl = 0; lvl < g.vq_num_levels; ++lvl) {
             const int ch = g.vq_ch * g.vq_ch_mult[lvl];
-            per_img = std::max<long>(per_img, (long)res * res * ch);
+            per_img = std::max<long>(per_img, hw * ch);
             max_c = std::max(max_c, ch);
-            if (lvl != g.vq_num_levels - 1) res /= 2;
+            if (!c.down[lvl].attns.empty()) attn_hw = std::max(attn_hw, hw);
+            if (lvl != g.vq_num_levels - 1) hw /= 4;
         }
     }
     const int chunk = std::min(n_total, 16);
-    const long attn_hw = std::max<long>((long)g.vq_attn_resolution * g.vq_attn_resolution, (long)lat * lat);
+    const long attn_hwp = round_up(attn_hw, 32);
     const size_t act_b = (size_t)per_img * chunk * sizeof(float);
-    const size_t need = 4 * act_b + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, R * R) +
-                        (size_t)chunk * attn_hw * (3 * max_c + attn_hw) * sizeof(float) + (size_t)chunk * lat * lat * (g.vq_n_embed + g.vq_embed_dim + 1) * sizeof(float) + 32 * 256;
+    const size_t need = 4 * act_b + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, RH * RW) +
+                        (size_t)chunk * attn_hwp * (3 * max_c + attn_hwp) * sizeof(float) + (size_t)chunk * lat_hw * (g.vq_n_embed + g.vq_embed_dim + 1) * sizeof(float) + 32 * 256;
     c.arena.reserve(need);
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
         const int n = std::min(chunk, n_total - i0);
@@ -363,20 +376,20 @@ void vq_encode(Ctx& c, const float* x_nchw, int n_total, int64_t* ids, hipStream
         ws.t = c.arena.get<float>((size_t)per_img * n);
         float* o = c.arena.get<float>((size_t)per_img * n);
         ws.stats = c.arena.get<float>((size_t)n * 64);
-        ws.gn_ws = c.arena.alloc(groupnorm_ws_bytes(n, R * R));
-        ws.q = c.arena.get<float>((size_t)n * attn_hw * max_c);
-        ws.k = c.arena.get<float>((size_t)n * attn_hw * max_c);
-        ws.vT = c.arena.get<float>((size_t)n * attn_hw * max_c);
-        ws.S = c.arena.get<float>((size_t)n * attn_hw * attn_hw);
-        const long lrows = (long)n * lat * lat;
+        ws.gn_ws = c.arena.alloc(groupnorm_ws_bytes(n, RH * RW));
+        ws.q = c.arena.get<float>((size_t)n * attn_hwp * max_c);
+        ws.k = c.arena.get<float>((size_t)n * attn_hwp * max_c);
+        ws.vT = c.arena.get<float>((size_t)n * attn_hwp * max_c);
+        ws.S = c.arena.get<float>((size_t)n * attn_hwp * attn_hwp);
+        const long lrows = (long)n * lat_hw;
         float* dots = c.arena.get<float>((size_t)lrows * g.vq_n_embed);
         float* zq = c.arena.get<float>((size_t)lrows * g.vq_embed_dim);
         float* zz = c.arena.get<float>((size_t)lrows);
 
-        launch_nchw_to_nhwc_pad(x_nchw + (long)i0 * g.vq_in_channels * R * R, ws.t, n, R * R, g.vq_in_channels, c.enc_cin_pad, s);
-        Act x{ws.t, n, R, R, c.enc_cin_pad};
+        launch_nchw_to_nhwc_pad(x_nchw + (long)i0 * g.vq_in_channels * RH * RW, ws.t, n, RH * RW, g.vq_in_channels, c.enc_cin_pad, s);
+        Act x{ws.t, n, RH, RW, c.enc_cin_pad};
         conv3(x, c.enc_conv_in, ws.a, nullptr, 0, s);
-        x = Act{ws.a, n, R, R, c.enc_conv_in.cout};
+        x = Act{ws.a, n, RH, RW, c.enc_conv_in.cout};
         auto pick2 = [&](float*& scratch, float*& y) {
             float* bufs[3] = {ws.a, ws.b, o};
             scratch = nullptr; y = nullptr;
@@ -417,7 +430,7 @@ void vq_encode(Ctx& c, const float* x_nchw, int n_total, int64_t* ids, hipStream
         gd.A = zq; gd.B = c.codebook; gd.C = dots;
         gd.M = (int)lrows; gd.N = g.vq_n_embed; gd.K = g.vq_embed_dim; gd.lda = g.vq_embed_dim; gd.ldb = g.vq_embed_dim; gd.ldc = g.vq_n_embed;
         launch_gemm(gd, s);
-        launch_vq_argmin(dots, zz, c.codebook_sqnorm, ids + (long)i0 * lat * lat, lrows, g.vq_n_embed, s);
+        launch_vq_argmin(dots, zz, c.codebook_sqnorm, ids + (long)i0 * lat_hw, lrows, g.vq_n_embed, s);
     }
 }
 

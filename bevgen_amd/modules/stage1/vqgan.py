@@ -48,6 +48,9 @@ class VQModel(nn.Module):
         self.ddconfig["ch_mult"] = list(self.ddconfig["ch_mult"])
         self.ddconfig["attn_resolutions"] = list(self.ddconfig["attn_resolutions"])
         self.n_embed, self.embed_dim = n_embed, embed_dim
+        # the networks are fully convolutional: cam_res / cam_latent_res only fix the default latent grid of decode_ids (nuScenes: 224 x 400 -> 14 x 25)
+        self.cam_res = tuple(cam_res) if cam_res is not None else None
+        self.cam_latent_res = tuple(cam_latent_res) if cam_latent_res is not None else None
         self.image_key = image_key
         self.denormalize = denormalize
         self.quantize = VectorQuantizer2(n_embed, embed_dim, beta=0.25, remap=remap, sane_index_shape=sane_index_shape, legacy=legacy)
@@ -95,24 +98,24 @@ class VQModel(nn.Module):
         return self.context().vq_decode_latents(quant, denormalize=False)
 
     @torch.no_grad()
-    def decode_ids(self, ids, denormalize=False):
-        """Fused get_codebook_entry + decode (+ util.denormalize_tensor): ids [n, h*w] -> pixels."""
-        return self.context().vq_decode(ids, denormalize=denormalize)
+    def decode_ids(self, ids, denormalize=False, latent_hw=None):
+        """Fused get_codebook_entry + decode (+ util.denormalize_tensor): ids [n, h*w] -> pixels; latent grid = latent_hw, else cam_latent_res, else square."""
+        return self.context().vq_decode(ids, denormalize=denormalize, latent_hw=latent_hw or self.cam_latent_res)
 
     def decode_code(self, code_b):
         return self.decode_ids(code_b.reshape(code_b.shape[0], -1))
 
     @torch.no_grad()
     def encode_ids(self, x):
-        """Encoder -> quant_conv -> arg-min over the codebook: x [n, in_channels, R, R] -> ids [n, h*w]."""
+        """Encoder -> quant_conv -> arg-min over the codebook: x [n, in_channels, H, W] -> ids [n, h*w]."""
         return self.context().vq_encode(x)
 
     @torch.no_grad()
     def encode(self, x, batch=None):
         """vqgan:84-116 (geometric_embedding=False) -> (quant [n, e, h, w], emb_loss=None, (None, None, indices [n*h*w]))."""
         ids = self.encode_ids(x)
-        lat = self.ddconfig["resolution"] // 2 ** (len(self.ddconfig["ch_mult"]) - 1)
-        quant = self.quantize.get_codebook_entry(ids.reshape(-1), (x.shape[0], lat, lat, self.embed_dim))
+        f = 2 ** (len(self.ddconfig["ch_mult"]) - 1)
+        quant = self.quantize.get_codebook_entry(ids.reshape(-1), (x.shape[0], x.shape[-2] // f, x.shape[-1] // f, self.embed_dim))
         return quant, None, (None, None, ids.reshape(-1))
 
     def forward(self, input, batch=None):

@@ -79,24 +79,86 @@ class Net2NetTransformer(_Base):
         assert out.max() < cfg.vocab_size
         return out
 
-    @torch.no_grad()
-    def decode_to_img(self, index, zshape=None, denormalize=False):
-        return self.first_stage_model.decode_ids(index.reshape(index.shape[0], -1), denormalize=denormalize)
+    # ---- helpers shared with the reference's get_input / encode_to_* (ar_lm:229-292)
+    def expand_all_images(self, arr):
+        return arr.reshape(-1, self.cfg.num_cams, *arr.shape[1:])
+
+    def combine_all_images(self, arr):
+        return arr.reshape(-1, *arr.shape[2:])
+
+    def get_input(self, key, batch):
+        """ar_lm:276-287: channel-last batch tensors -> channel-first; images [B, C, H, W, 3] -> [(B C), 3, H, W]."""
+        x = batch[key]
+        if x.dtype in (torch.double, torch.uint8):
+            x = x.float()
+        x = x.movedim(-1, -3)
+        if key == self.first_stage_key:
+            if x.dim() == 4:
+                x = x[None]
+            x = self.combine_all_images(x)
+        return x.contiguous()
 
     @torch.no_grad()
-    def log_images(self, batch, temperature=None, top_k=None, callback=None, lr_interface=False, generate_only=False, **kwargs):
-        """ar_lm:479-561 reduced to the generate path: {'gen': [B,C,3,H,W], 'rec': None, 'gt': ...}."""
+    def encode_to_c(self, c, batch):
+        """ar_lm:253-264: BEV segmentation -> condition token ids [B, K] (precomputed batch['cond_ids'] short-circuits)."""
+        if "cond_ids" in batch:
+            return None, batch["cond_ids"]
+        quant_c, _, info = self.cond_stage_model.encode(c, batch)
+        return quant_c, info[2].view(c.shape[0], -1)
+
+    @torch.no_grad()
+    def encode_to_z(self, x, batch):
+        """ar_lm:229-242: images [(B C), 3, H, W] -> z ids [(B C), T]."""
+        quant_z, _, info = self.first_stage_model.encode(x, batch)
+        return quant_z, info[2].view(x.shape[0], -1)
+
+    @torch.no_grad()
+    def decode_to_img(self, index, zshape=None, denormalize=False):
+        """ar_lm:244-251 with zshape = cam_latent_res (the decoder is fully convolutional: 14 x 25 latents for nuScenes)."""
+        return self.first_stage_model.decode_ids(index.reshape(index.shape[0], -1), denormalize=denormalize, latent_hw=(self.cfg.cam_latent_h, self.cfg.cam_latent_w))
+
+    def _partial_decoding_idx(self):
+        """ar_lm:501-514."""
+        if not self.partial_decoding:
+            return None
+        C = self.cfg.num_cams
+        if self.partial_decoding == 2:
+            return torch.randint(C, (torch.randint(1, 3, ()).item(),))
+        if self.partial_decoding == 3:
+            return torch.tensor([0]) if torch.rand(()).item() > 0.5 else torch.tensor([0, 2])
+        if self.partial_decoding == 4:
+            return torch.tensor([3, 0, 2])
+        return torch.randint(C, (1,))
+
+    @torch.no_grad()
+    def log_images(self, batch, temperature=None, top_k=None, callback=None, lr_interface=False, generate_only=False, noise_u=None, sample=True, **kwargs):
+        """ar_lm:479-561 reduced to what the generate path returns: {'gen', 'rec', 'gt'} each [B, C, 3, H, W] in [0,1] ('rec' / 'gt' None when the
+        ground-truth images are absent).  Draws with top-k 100 like the reference unless told otherwise; `partial_decoding` picks the fixed cameras
+        exactly as ar_lm:501-514 does and feeds their encoded ground-truth tokens to `sample`."""
         dev = next(self.transformer.parameters()).device
-        c = batch["cond_ids"].to(dev) if "cond_ids" in batch else self.cond_stage_model.encode(batch[self.cond_stage_key], batch)
-        b2 = dict(batch, intrinsics_inv=batch["intrinsics_inv"].to(dev), extrinsics_inv=batch["extrinsics_inv"].to(dev))
-        x = self.sample(None, c, b2, temperature=temperature if temperature is not None else 1.0, sample=True, top_k=top_k if top_k is not None else 100)
-        gen = self.decode_to_img(x.reshape(-1, cfg_T(self.cfg)), denormalize=True)
-        gen = gen.reshape(c.shape[0], self.cfg.num_cams, *gen.shape[1:])
-        gt = None
-        if self.first_stage_key in batch:
-            img = batch[self.first_stage_key].to(dev).float().movedim(-1, -3)
-            gt = denormalize_tensor(img.reshape(-1, *img.shape[-3:])).reshape(img.shape)
-        return {"gen": gen, "rec": None, "gt": gt}
+        batch = dict(batch)
+        _, c = self.encode_to_c(None if "cond_ids" in batch else self.get_input(self.cond_stage_key, batch).to(dev), batch)
+        c = c.to(dev)
+        B = c.shape[0]
+        batch["intrinsics_inv"] = batch["intrinsics_inv"].to(dev)
+        batch["extrinsics_inv"] = batch["extrinsics_inv"].to(dev)
+        x_img = self.get_input(self.first_stage_key, batch).to(dev) if self.first_stage_key in batch else None
+        z = None
+        if "z_ids" in batch:
+            z = batch["z_ids"].to(dev).reshape(B * self.cfg.num_cams, -1)
+        elif x_img is not None:
+            _, z = self.encode_to_z(x_img, batch)
+        pidx = self._partial_decoding_idx()
+        if pidx is not None:
+            if z is None:
+                raise ValueError("partial_decoding needs the ground-truth images (batch['image']) or their token ids (batch['z_ids'])")
+            batch["z_ids"] = z.reshape(B, self.cfg.num_cams, -1)
+        x = self.sample(None, c, batch, temperature=temperature if temperature is not None else 1.0, sample=sample, top_k=top_k if top_k is not None else 100,
+                        partial_decoding_idx=pidx, noise_u=noise_u)
+        gen = self.expand_all_images(self.decode_to_img(self.combine_all_images(x), denormalize=True))
+        rec = self.expand_all_images(self.decode_to_img(z, denormalize=True)) if z is not None else None
+        gt = self.expand_all_images(denormalize_tensor(x_img)) if x_img is not None else None
+        return {"gen": gen, "rec": rec, "gt": gt}
 
     def test_step(self, batch, batch_idx):
         return self.log_images(batch, generate_only=True, top_k=self.top_k)
@@ -104,6 +166,3 @@ class Net2NetTransformer(_Base):
     def forward(self, batch):
         return self.log_images(batch, generate_only=True, top_k=self.top_k)
 
-
-def cfg_T(cfg):
-    return cfg.num_cam_tokens

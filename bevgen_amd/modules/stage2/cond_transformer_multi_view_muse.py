@@ -101,7 +101,7 @@ class Net2NetTransformer(_Base):
     @torch.no_grad()
     def decode_to_img(self, index, zshape=None, denormalize=False):
         """muse_lm:157-164 (+ denormalize_tensor when asked): ids [(B*C), T or h,w] -> [(B*C), 3, H, W]."""
-        return self.first_stage_model.decode_ids(index.reshape(index.shape[0], -1), denormalize=denormalize)
+        return self.first_stage_model.decode_ids(index.reshape(index.shape[0], -1), denormalize=denormalize, latent_hw=(self.cfg.cam_latent_h, self.cfg.cam_latent_w))
 
     @torch.no_grad()
     def encode_to_c(self, c, batch):

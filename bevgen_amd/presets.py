@@ -77,9 +77,9 @@ def config2(num_cams: int = 6) -> GPTConfig:
     return route_m(num_cams)
 
 
-def config4() -> GPTConfig:
-    """BASELINE config 4: Route A, nuScenes 6-view 224x400 (N=2100, L=2368, pad 12)."""
-    return route_a(6)
+def config4(density: float = 1.0) -> GPTConfig:
+    """BASELINE config 4: Route A, nuScenes 6-view 224x400 (N=2100, L=2368, pad 12); density < 1 = the random per-head layout variant."""
+    return route_a(6, density=density)
 
 
 def tiny_route_m(num_cams: int = 3, legacy: bool = True, latent=(4, 4), bev=(4, 4)) -> GPTConfig:
@@ -87,6 +87,6 @@ def tiny_route_m(num_cams: int = 3, legacy: bool = True, latent=(4, 4), bev=(4, 
                    bev_latent_res=bev, legacy_prob_matrix=legacy)
 
 
-def tiny_route_a(num_cams: int = 3, block: int = 16) -> GPTConfig:
+def tiny_route_a(num_cams: int = 3, block: int = 16, density: float = 1.0) -> GPTConfig:
     return route_a(num_cams, num_layers=2, dim=128, heads=2, vocab=64, cam_res=(64, 64), cam_latent_res=(4, 5),
-                   bev_latent_res=(4, 4), block=block, window_len=8)
+                   bev_latent_res=(4, 4), block=block, window_len=8, density=density)

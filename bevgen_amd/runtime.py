@@ -249,33 +249,52 @@ class Context:
         return (out, logits) if return_logits else out
 
     # ------------------------------------------------------------------------------------------ stage 1
-    def vq_decode(self, ids, denormalize=True):
+    def _vq_levels(self):
+        return len(self.vq_ddconfig["ch_mult"]) - 1
+
+    def _latent_grid(self, latent_hw, tokens=None):
+        """(lat_h, lat_w): explicit, else the square grid of ddconfig.resolution.  The decoder is fully convolutional: nuScenes uses 14 x 25."""
+        if latent_hw is None:
+            lat = self.vq_ddconfig["resolution"] >> self._vq_levels()
+            latent_hw = (lat, lat)
+        lh, lw = int(latent_hw[0]), int(latent_hw[1])
+        if tokens is not None and tokens != lh * lw:
+            raise ValueError(f"{tokens} token ids per image do not fill the {lh} x {lw} latent grid: pass latent_hw=cam_latent_res")
+        return lh, lw
+
+    def vq_decode(self, ids, denormalize=True, latent_hw=None, uint8=False):
+        """ids [n, lat_h*lat_w] -> [n, out_ch, H, W] fp32 (raw or denormalised to [0,1]) or, with uint8=True, the round(255 x) storage format."""
         dd = self.vq_ddconfig
         ids = _req(ids, torch.int64, self.device, "ids")
         n = ids.shape[0]
-        R = dd["resolution"]
-        out = torch.empty((n, dd["out_ch"], R, R), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids.reshape(n, -1)), n, int(bool(denormalize)), _ptr(out), _stream()))
+        ids = ids.reshape(n, -1)
+        lh, lw = self._latent_grid(latent_hw, ids.shape[1])
+        f = 1 << self._vq_levels()
+        mode = _lib.VQ_OUT_U8 if uint8 else (_lib.VQ_OUT_DENORM if denormalize else _lib.VQ_OUT_RAW)
+        out = torch.empty((n, dd["out_ch"], lh * f, lw * f), dtype=torch.uint8 if uint8 else torch.float32, device=self.device)
+        self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids), n, lh, lw, mode, _ptr(out), _stream()))
         return out
 
     def vq_encode(self, x):
-        """VQModel.encode -> token ids: x [n, in_channels, R, R] fp32 (NCHW) -> ids [n, h*w] int64."""
+        """VQModel.encode -> token ids: x [n, in_channels, H, W] fp32 (NCHW; H, W multiples of 2^(levels-1)) -> ids [n, h*w] int64."""
         dd = self.vq_ddconfig
         x = _req(x, torch.float32, self.device, "x")
-        n = x.shape[0]
-        lat = dd["resolution"] // 2 ** (len(dd["ch_mult"]) - 1)
-        assert tuple(x.shape[1:]) == (dd["in_channels"], dd["resolution"], dd["resolution"]), x.shape
-        ids = torch.empty((n, lat * lat), dtype=torch.int64, device=self.device)
-        self._check(self.lib.bevgen_vq_encode(self._h, _ptr(x), n, _ptr(ids), _stream()))
+        n, ch, H, W = x.shape
+        f = 1 << self._vq_levels()
+        if ch != dd["in_channels"] or H % f or W % f:
+            raise ValueError(f"vq_encode: input {tuple(x.shape)} needs {dd['in_channels']} channels and sides divisible by {f}")
+        ids = torch.empty((n, (H // f) * (W // f)), dtype=torch.int64, device=self.device)
+        self._check(self.lib.bevgen_vq_encode(self._h, _ptr(x), n, H, W, _ptr(ids), _stream()))
         return ids
 
     def vq_decode_latents(self, zq, denormalize=False):
         """VQModel.decode(quant): zq [n, embed_dim, h, w] fp32."""
         dd = self.vq_ddconfig
         zq = _req(zq, torch.float32, self.device, "zq")
-        n, R = zq.shape[0], dd["resolution"]
-        out = torch.empty((n, dd["out_ch"], R, R), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_vq_decode_latents(self._h, _ptr(zq), n, int(bool(denormalize)), _ptr(out), _stream()))
+        n, _, lh, lw = zq.shape
+        f = 1 << self._vq_levels()
+        out = torch.empty((n, dd["out_ch"], lh * f, lw * f), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_vq_decode_latents(self._h, _ptr(zq), n, lh, lw, _lib.VQ_OUT_DENORM if denormalize else _lib.VQ_OUT_RAW, _ptr(out), _stream()))
         return out
 
     # ------------------------------------------------------------------------------------------ per-kernel HIP-event timing

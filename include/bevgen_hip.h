@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BEVGEN_ABI_VERSION 1
+#define BEVGEN_ABI_VERSION 2
 
 enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
 /* FP32  : every product and accumulation in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32) - bit-exact greedy tokens vs the CPU reference.
@@ -167,17 +167,24 @@ int bevgen_ar_sample_forced(bevgen_ctx* ctx, const int64_t* d_cond_ids, const fl
  * stage-1 VQGAN decode                                                                                            */
 
 /* decode_to_img (stage2/cond_transformer_multi_view_muse.py:157-164): get_codebook_entry (stage1/quantize.py:314-329) ->
- * post_quant_conv + Decoder (stage1/vqgan.py:118-121, stage1/model.py:506-537) [-> util.denormalize_tensor,
- * bev_utils/util.py:97-118 when denormalize != 0].   d_ids [n, h*w] -> d_out [n, out_ch, H, W] fp32. */
-int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* d_ids, int n, int denormalize, float* d_out, void* stream);
+ * post_quant_conv + Decoder (stage1/vqgan.py:118-121, stage1/model.py:506-537) [-> util.denormalize_tensor, bev_utils/util.py:97-118].
+ * The decoder is fully convolutional: the latent grid is lat_h x lat_w = cam_latent_res (16 x 16 for 256 x 256 images, 14 x 25 for nuScenes 224 x 400;
+ * 0, 0 = the square grid of ddconfig.resolution), the image (lat_h << (levels-1)) x (lat_w << (levels-1)).
+ *   out_mode BEVGEN_VQ_OUT_RAW      d_out fp32 [n, out_ch, H, W], the decoder output
+ *            BEVGEN_VQ_OUT_DENORM   d_out fp32 [n, 3, H, W] in [0,1]  (x*std + mean, clamped)
+ *            BEVGEN_VQ_OUT_U8       d_out uint8 [n, 3, H, W] = round(255 * denormalised): the storage / wire format of the generated images
+ *   d_ids [n, lat_h*lat_w]. */
+enum { BEVGEN_VQ_OUT_RAW = 0, BEVGEN_VQ_OUT_DENORM = 1, BEVGEN_VQ_OUT_U8 = 2 };
+int bevgen_vq_decode(bevgen_ctx* ctx, const int64_t* d_ids, int n, int lat_h, int lat_w, int out_mode, void* d_out, void* stream);
 
 /* VQModel.encode (stage1/vqgan.py:84-116 with geometric_embedding=False): Encoder (stage1/model.py:405-433) -> quant_conv ->
- * VectorQuantizer2.forward arg-min (stage1/quantize.py:271-312).  d_x [n, in_channels, R, R] fp32 (NCHW, as get_input produces it,
- * muse_lm:166-179) -> d_ids [n, h*w] int64.  This is encode_to_c (BEV segmentation -> condition tokens) and encode_to_z (muse_lm:142-155). */
-int bevgen_vq_encode(bevgen_ctx* ctx, const float* d_x, int n, int64_t* d_ids, void* stream);
+ * VectorQuantizer2.forward arg-min (stage1/quantize.py:271-312).  d_x [n, in_channels, H, W] fp32 (NCHW, as get_input produces it,
+ * muse_lm:166-179; H, W multiples of 2^(levels-1); 0, 0 = ddconfig.resolution squared) -> d_ids [n, (H >> (levels-1)) * (W >> (levels-1))] int64.
+ * This is encode_to_c (BEV segmentation -> condition tokens) and encode_to_z (muse_lm:142-155). */
+int bevgen_vq_encode(bevgen_ctx* ctx, const float* d_x, int n, int H, int W, int64_t* d_ids, void* stream);
 
-/* VQModel.decode(quant) (stage1/vqgan.py:118-121) for already looked-up latents: d_zq [n, embed_dim, h, w] (NCHW, like the reference). */
-int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* d_zq, int n, int denormalize, float* d_out, void* stream);
+/* VQModel.decode(quant) (stage1/vqgan.py:118-121) for already looked-up latents: d_zq [n, embed_dim, lat_h, lat_w] (NCHW, like the reference). */
+int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* d_zq, int n, int lat_h, int lat_w, int out_mode, void* d_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Operator-level entry points (parity tests and roofline measurements call the kernels through these)             */

@@ -117,58 +117,136 @@ def golden_route_m(case: cases.Case, full: bool):
 
 
 # ------------------------------------------------------------------------------------------------ Route A
+class _RefSampler:
+    """Drives the reference's OWN sampling loop, `Net2NetTransformer.sample` (ar_lm:154-227: mask-id initialisation, decode order from a fresh
+    CustomPermuter, temperature, `top_k_logits` ar_lm:138-142, softmax, topk(1) / multinomial), as an unbound method on a minimal stand-in object:
+    the LightningModule constructor would instantiate both VQGANs through Hydra, which the loop does not need.  The stand-in supplies exactly the
+    attributes the loop reads (cfg, transformer, skip_sampling, debug_viz, top_k_logits, and for partial decoding get_input / encode_to_z /
+    expand_all_images returning the given ground-truth ids).  `steps`: the loop has no step limit, so for the full-size head cases the module's
+    tqdm is replaced by a truncating iterator; the final `x.max() < vocab_size` assert then fires and the partially filled x is read back from the
+    tensor the loop handed to the transformer.  Stochastic sampling: torch.multinomial is replaced by the inverse-CDF draw on explicit uniforms
+    (the definition this repo uses: first index whose cumulative probability exceeds u * total)."""
+
+    def __init__(self, gpt, rcfg):
+        import types
+
+        self.ns = stubs.import_reference()
+        self.N2N = self.ns.ar_lm.Net2NetTransformer
+        outer = self
+
+        class Transformer:
+            training = False
+
+            def __call__(self, x, cond, batch, sampling=True):
+                outer.x_seen = x
+                out = gpt(x, cond, batch, sampling=sampling)
+                if outer.step_logits is not None:
+                    outer.step_logits.append(out)
+                return out
+
+        class Shim:
+            pass
+
+        o = Shim()
+        o.cfg, o.transformer, o.skip_sampling, o.debug_viz, o.first_stage_key = rcfg, Transformer(), False, False, "image"
+        o.top_k_logits = types.MethodType(self.N2N.top_k_logits, o)
+        o.get_input = lambda key, batch: None
+        o.expand_all_images = lambda z: z
+        self.o = o
+        self.x_seen = None
+        self.step_logits = None
+
+    def run(self, B, cond, batch, *, steps=0, temperature=1.0, top_k=None, noise_u=None, partial_idx=None, z=None, record=None):
+        import itertools
+
+        mod = self.ns.ar_lm
+        self.step_logits = record
+        self.o.encode_to_z = lambda x, batch: (None, z)
+        old_tqdm, old_mn = mod.tqdm, torch.multinomial
+        state = {"s": 0}
+
+        def multinomial(probs, num_samples=1, **kw):
+            u = noise_u[state["s"]]
+            state["s"] += 1
+            cdf = probs.cumsum(dim=-1)
+            return (cdf <= u[:, None] * cdf[:, -1:]).sum(dim=-1).clamp(max=probs.shape[-1] - 1)[:, None]
+
+        mod.tqdm = (lambda it: itertools.islice(it, steps)) if steps else (lambda it: it)
+        if noise_u is not None:
+            torch.multinomial = multinomial
+        try:
+            x0 = torch.zeros((B, 1), dtype=torch.long)
+            try:
+                return self.N2N.sample(self.o, x0, cond, batch, temperature=temperature, sample=noise_u is not None, top_k=top_k, partial_decoding_idx=partial_idx)
+            except AssertionError:
+                assert steps, "the reference loop failed its own assertions"
+                return self.x_seen.clone()   # truncated run: unfilled positions still hold the mask id
+        finally:
+            mod.tqdm, torch.multinomial = old_tqdm, old_mn
+
+
 def golden_route_a(case: cases.Case, full: bool):
     cfg = case.make_cfg()
     sd = cases.gpt_state_dict(cfg, case.weight_seed)
-    gpt, _ = RM.build_ref_gpt(cfg, sd)
     bt = cases.inputs(case, cfg)
     batch = {"intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
     B, C, T, N = case.batch, cfg.num_cams, cfg.num_cam_tokens, cfg.num_img_tokens
     g = torch.Generator().manual_seed(case.input_seed)
     ids = torch.randint(0, cfg.vocab_size, (B, C, T), generator=g)
-    with torch.no_grad():
-        lr = gpt(ids.clone(), bt["cond_ids"], batch, sampling=True)
+    layout_seed = case.layout_seed
+    while True:
+        # density < 1: sd receives the layouts the reference draws, layer by layer.  A draw can leave a condition row without any visible block in some
+        # head (nothing forces the cond x cond blocks in); the reference then fails its own finite-logits assert (gpt:388): take the next seed.
+        gpt, rcfg = RM.build_ref_gpt(cfg, sd, layout_seed=layout_seed)
+        try:
+            with torch.no_grad():
+                lr = gpt(ids.clone(), bt["cond_ids"], batch, sampling=True)
+            break
+        except AssertionError:
+            assert layout_seed and layout_seed < case.layout_seed + 64, "reference forward is not finite"
+            print(f"  layout seed {layout_seed}: a row without visible keys, trying the next seed")
+            layout_seed += 1
     lo = R.gpt_forward(sd, cfg, ids, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"])
     assert rel(lo, lr) < 2e-5, rel(lo, lr)
-    # greedy sampling with the reference's own loop structure (one full forward per token), driven through the reference GPT
-    x = torch.full((B, C, T), cfg.vocab_size, dtype=torch.long)
-    step_logits = []
-    t0 = time.time()
+    # greedy sampling by the reference's own loop (one full forward per token)
+    sampler = _RefSampler(gpt, rcfg)
     n_steps = case.steps or N
-    with torch.no_grad():
-        for s in range(n_steps):
-            j = int(cfg.forward_shuffle_idx[s])
-            logits = gpt(x, bt["cond_ids"], batch, sampling=True)[:, j]
-            step_logits.append(logits.clone())
-            x[:, j // T, j % T] = logits.softmax(-1).topk(1).indices[:, 0]
+    rec = []
+    t0 = time.time()
+    x = sampler.run(B, bt["cond_ids"], batch, steps=case.steps, record=rec)
     t_ref = time.time() - t0
+    order = [int(cfg.forward_shuffle_idx[s]) for s in range(n_steps)]
+    step_logits = [rec[s][:, order[s]].clone() for s in range(n_steps)]
+    del rec
     lc = []
     xc = R.ar_sample_cached(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], logits_out=lc, steps=n_steps)
-    assert torch.equal(x, xc), "KV-cache oracle != reference full-recompute sampling (greedy)"
+    assert torch.equal(x, xc), "KV-cache oracle != reference Net2NetTransformer.sample (greedy)"
     err = max(rel(a, b) for a, b in zip(lc, step_logits))
     assert err < 5e-5, err
     sl = torch.stack(step_logits)  # [N,B,V]
     out = dict(ids_in=ids.to(torch.int16), cond_ids=bt["cond_ids"].to(torch.int16), I_inv=bt["intrinsics_inv"], E_inv=bt["extrinsics_inv"],
                sample_greedy=x.to(torch.int16), min_margin_greedy=np.array(top2_margin(sl)), ref_sample_seconds=np.array(t_ref))
+    if case.layout_seed:
+        lay = torch.stack([sd[f"blocks.{i}.attention.sparse_self_attention.master_layout"] for i in range(cfg.num_layers)])
+        assert any(not torch.equal(lay[0], lay[i]) for i in range(1, cfg.num_layers)), "the layers were expected to draw different layouts"
+        out.update(layer_layout_bits=np.packbits(lay.numpy().astype(np.uint8)), layer_layout_shape=np.array(lay.shape), layout_seed=np.array(layout_seed),
+                   layout_fill=np.array(float(lay.float().mean())))
     if not full:
         noise_u = synthetic.uniform_noise((N, B), 11, 2)
-        xs = R.ar_sample_full_recompute(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], temperature=0.9, top_k=8, noise_u=noise_u)
+        xs = sampler.run(B, bt["cond_ids"], batch, temperature=0.9, top_k=8, noise_u=noise_u)   # reference loop incl. its top_k_logits
+        xs1 = R.ar_sample_full_recompute(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], temperature=0.9, top_k=8, noise_u=noise_u)
         xs2 = R.ar_sample_cached(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], temperature=0.9, top_k=8, noise_u=noise_u)
-        assert torch.equal(xs, xs2)
-        out.update(logits_full=lr, step_logits=sl, sample_topk8=xs.to(torch.int16))
-        # partial decoding (ar_lm:161-165, 181-182) with the reference's loop structure driven through the reference GPT: the fixed cameras start from
-        # "ground-truth" ids (encode_to_z output in the reference; seeded random ids here) and their positions are skipped
+        assert torch.equal(xs, xs1) and torch.equal(xs, xs2), "oracle top-k sampling != reference loop"
+        # top_k_logits tie behaviour (ar_lm:138-142: values equal to the k-th largest are kept), straight from the reference method
+        tl = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0, 0.5], [0.0, -1.0, 0.0, 0.0, -2.0, 5.0]])
+        tk = sampler.o.top_k_logits(tl, 2)
+        assert torch.equal(tk, R.top_k_logits(tl, 2)), "oracle top_k_logits != reference"
+        out.update(logits_full=lr, step_logits=sl, sample_topk8=xs.to(torch.int16), topk_tie_in=tl, topk_tie_out=tk)
+        # partial decoding (ar_lm:161-165, 181-182) by the reference loop: the fixed cameras start from "ground-truth" ids (encode_to_z output in
+        # the reference; seeded random ids here) and their positions are skipped
         partial_idx = [1] if C < 6 else [0, 2]
         z = torch.randint(0, cfg.vocab_size, (B, C, T), generator=g)
-        xp = torch.full((B, C, T), cfg.vocab_size, dtype=torch.long)
-        xp[:, partial_idx, :] = z[:, partial_idx]
-        with torch.no_grad():
-            for s in range(N):
-                j = int(cfg.forward_shuffle_idx[s])
-                if j // T in partial_idx:
-                    continue
-                logits = gpt(xp, bt["cond_ids"], batch, sampling=True)[:, j]
-                xp[:, j // T, j % T] = logits.softmax(-1).topk(1).indices[:, 0]
+        xp = sampler.run(B, bt["cond_ids"], batch, partial_idx=partial_idx, z=z)
         xp_or = R.ar_sample_full_recompute(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], partial_decoding_idx=partial_idx, z_indices=z)
         xp_kv = R.ar_sample_cached(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], forced_ids=R.partial_forced_ids(cfg, partial_idx, z))
         assert torch.equal(xp, xp_or), "oracle partial decoding != reference loop"
@@ -178,6 +256,25 @@ def golden_route_a(case: cases.Case, full: bool):
         keep = sorted({0, 1, 17, N // 2, N - 1}) if n_steps == N else list(range(n_steps))
         out.update(step_logits_idx=np.array(keep), step_logits=sl[keep])
     save("route_a_" + case.name, **out)
+
+
+def golden_tables_density():
+    """S4 with density < 1 (maskgen:217-251, perm:125-143): the reference's multi_outward_pattern under a fixed torch seed, and this repo's
+    tables.head_layouts under the same seed (same primitive, same call order) - asserted equal here, re-checked by tests/test_tables.py."""
+    from bevgen_amd import tables
+
+    for name, mk in (("nusc6_224x400_d035", lambda: presets.config4(density=0.35)), ("tiny_a_blk4_d035", lambda: presets.tiny_route_a(3, block=4, density=0.35))):
+        cfg = mk()
+        ref = RM.ref_gpt_config(cfg)
+        seed = 4242
+        torch.manual_seed(seed)
+        lay_ref, _ = ref.get_mask()
+        torch.manual_seed(seed)
+        lay = tables.head_layouts(cfg, cfg._patterns)
+        assert torch.equal(lay_ref.to(torch.int64), lay), "tables.head_layouts != reference multi_outward_pattern under the same seed"
+        assert not torch.equal(lay[0], lay[1]), "heads were expected to differ"
+        save("tables_" + name, seed=np.array(seed), layout_bits=np.packbits(lay_ref.numpy().astype(np.uint8)), layout_shape=np.array(lay_ref.shape),
+             layout_fill=np.array(float(lay_ref.float().mean())), density=np.array(cfg.density))
 
 
 # ------------------------------------------------------------------------------------------------ VQGAN decode
@@ -244,6 +341,70 @@ def golden_vq():
     save("vq_tiny", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd, **enc)
 
 
+def golden_vq_rect():
+    """Non-square latents (the reference's nuScenes experiment: cam_res [224, 400], cam_latent_res [14, 25], configs/experiment/muse_stage_two_multi_view.yaml)
+    through the fully convolutional decoder / encoder: tiny model with full tensors, and the released f16 architecture at 14 x 25 -> 224 x 400
+    (pixels as float16 of the denormalised output) plus the full-size ENCODER (s1model:342-433, quant:271-312) at 256 x 256 and 224 x 400."""
+    ns = stubs.import_reference()
+    out = {}
+    # ---- tiny: latent 3 x 5 -> 24 x 40 pixels
+    v = cases.VQ_TINY
+    dd = v["dd"]
+    f = 2 ** (len(dd["ch_mult"]) - 1)
+    sd = cases.vq_state_dict(dd, v["n_embed"], v["embed_dim"], v["seed"], with_encoder=True)
+    lh, lw = 3, 5
+    vq = RM.build_ref_vqmodel(dd, v["n_embed"], v["embed_dim"], sd, (lh * f, lw * f), (lh, lw))
+    g = torch.Generator().manual_seed(23)
+    ids = torch.randint(0, v["n_embed"], (2, lh * lw), generator=g)
+    with torch.no_grad():
+        zq = vq.quantize.get_codebook_entry(ids.reshape(-1), shape=(2, lh, lw, v["embed_dim"]))
+        xr = vq.decode(zq)
+        xd = ns.util.denormalize_tensor(xr, keep_tensor=True)
+        xin = torch.randn(2, dd["in_channels"], lh * f, lw * f, generator=g)
+        _, _, info = vq.encode(xin, None)
+    xo = R.vq_decode_ids(sd, dd, ids, (lh, lw), denorm=False)
+    assert rel(xo, xr) < 1e-5, rel(xo, xr)
+    ids_enc = info[2].view(2, -1)
+    ids_or, dist = R.vq_encode_ids(sd, dd, xin, return_distances=True)
+    assert torch.equal(ids_enc, ids_or)
+    top2 = dist.topk(2, dim=1, largest=False).values
+    out.update(tiny_latent=np.array([lh, lw]), tiny_ids=ids.to(torch.int16), tiny_pixels_raw=xr, tiny_pixels_denorm=xd, tiny_enc_x=xin, tiny_enc_ids=ids_enc.to(torch.int16),
+               tiny_enc_min_margin=np.array(float((top2[:, 1] - top2[:, 0]).min())))
+    # ---- full size f16: decode 14 x 25 -> 224 x 400, encode 224 x 400 and 256 x 256 (inputs regenerated from their seeds by the tests)
+    v = cases.VQ_FULL
+    dd = v["dd"]
+    sd = cases.vq_state_dict(dd, v["n_embed"], v["embed_dim"], v["seed"], with_encoder=True)
+    lh, lw = 14, 25
+    vq = RM.build_ref_vqmodel(dd, v["n_embed"], v["embed_dim"], sd, (224, 400), (lh, lw))
+    g = torch.Generator().manual_seed(29)
+    ids = torch.randint(0, v["n_embed"], (1, lh * lw), generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        zq = vq.quantize.get_codebook_entry(ids.reshape(-1), shape=(1, lh, lw, v["embed_dim"]))
+        xr = vq.decode(zq)
+        xd = ns.util.denormalize_tensor(xr, keep_tensor=True)
+    t_dec = time.time() - t0
+    xo = R.vq_decode_ids(sd, dd, ids, (lh, lw), denorm=False)
+    assert rel(xo, xr) < 2e-5, rel(xo, xr)
+    out.update(full_latent=np.array([lh, lw]), full_ids=ids.to(torch.int16), full_pixels_denorm_f16=xd.to(torch.float16), full_raw_rows=xr[:, :, ::56, :].clone(),
+               full_raw_absmax=np.array(float(xr.abs().max())), full_decode_seconds=np.array(t_dec))
+    for tag, (H, W), seed in (("enc256", (256, 256), 31), ("enc224x400", (224, 400), 37)):
+        gx = torch.Generator().manual_seed(seed)
+        xin = torch.randn(1, 3, H, W, generator=gx)
+        t0 = time.time()
+        with torch.no_grad():
+            _, _, info = vq.encode(xin, None)
+        t_enc = time.time() - t0
+        ids_ref = info[2].view(1, -1)
+        ids_or, dist = R.vq_encode_ids(sd, dd, xin, return_distances=True)
+        assert torch.equal(ids_ref, ids_or), "oracle encode ids != reference (full size)"
+        top2 = dist.topk(2, dim=1, largest=False).values
+        out.update({f"{tag}_seed": np.array(seed), f"{tag}_hw": np.array([H, W]), f"{tag}_ids": ids_ref.to(torch.int16), f"{tag}_x_sha256": np.array(sha(xin)),
+                    f"{tag}_min_margin": np.array(float((top2[:, 1] - top2[:, 0]).min())), f"{tag}_dist_scale": np.array(float(dist.abs().mean())),
+                    f"{tag}_seconds": np.array(t_enc)})
+    save("vq_rect", **out)
+
+
 def golden_keys():
     """state_dict key -> shape of the reference modules (tiny sizes), as instantiated by the reference's own constructors."""
     import json
@@ -275,9 +436,15 @@ def main():
     if want("tables"):
         print("tables")
         golden_tables()
+    if want("tables_density"):
+        print("tables_density")
+        golden_tables_density()
     if want("vq"):
         print("vq")
         golden_vq()
+    if want("vq_rect"):
+        print("vq_rect")
+        golden_vq_rect()
     if want("keys"):
         print("keys")
         golden_keys()
@@ -285,7 +452,7 @@ def main():
         print("vq_full")
         golden_vq_full()
     for name, case in cases.CASES.items():
-        full = name in ("a_config1", "m_full_3cam", "m_full_6cam", "a_config4_head")
+        full = name in ("a_config1", "m_full_3cam", "m_full_6cam", "a_config4_head", "a_config4_d035_head")
         if not want(name) or (full and args.skip_full):
             continue
         print(name)

@@ -68,10 +68,17 @@ def build_ref_maskgit(cfg, sd):
     return mg.eval(), rcfg
 
 
-def build_ref_gpt(cfg, sd):
+def build_ref_gpt(cfg, sd, layout_seed: int = 0):
+    """layout_seed != 0 (density < 1): the reference GPT is constructed under that torch seed and the per-layer layouts it draws
+    (one multi_outward_pattern call per attention module, gpt:176) are written into ``sd`` (in place) before loading, i.e. they survive."""
     ns = stubs.import_reference()
     rcfg = ref_gpt_config(cfg)
+    if layout_seed:
+        torch.manual_seed(layout_seed)
     gpt = ns.gpt.GPT(rcfg)
+    if layout_seed:
+        for i, blk in enumerate(gpt.blocks):
+            sd[f"blocks.{i}.attention.sparse_self_attention.master_layout"] = blk.attention.sparse_self_attention.master_layout.clone().to(torch.int64)
     gpt.load_state_dict(sd, strict=True)
 
     def dense_forward(self, query, key, value, rpe=None, key_padding_mask=None, attn_mask=None, add_mask=None):

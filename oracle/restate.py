@@ -3,8 +3,8 @@
 TEST INFRASTRUCTURE.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module; the product package ``bevgen_amd`` never does (its ops fail loudly when
 the HIP library is missing).  Parity status: PINNED - every function below is checked in the build
-container against the *imported* reference (oracle/ref_import/check_oracle.py, tests/test_oracle_vs_reference.py)
-and against the golden vectors it generated (tests/golden/*.npz, made by oracle/ref_import/make_golden.py).
+container against the *imported* reference while oracle/ref_import/make_golden.py generates the golden vectors (it asserts reference ==
+restatement on every case before writing tests/golden/*.npz), and tests/test_oracle_golden.py re-checks it against those vectors on every run.
 Route A's attention is pinned against the dense restatement of DeepSpeed's block-sparse kernels, not against
 DeepSpeed 0.7.4 itself (its Triton kernels are not in the tree and not installable here: "parity unpinned"
 at that one boundary).
@@ -270,6 +270,12 @@ def gpt_embed(sd, cfg, cam_ids: Tensor, cond_ids: Tensor, I_inv: Tensor, E_inv: 
     return seq
 
 
+def layer_layout(sd, cfg, i: int) -> Tensor:
+    """Block layout of layer i: the checkpoint's per-layer buffer (the reference draws one per attention module at construction when density < 1,
+    gpt:176, maskgen:217-228, and stores it as ``master_layout``), else the configuration's."""
+    return sd.get(f"blocks.{i}.attention.sparse_self_attention.master_layout", cfg.layout)
+
+
 def _gpt_block(sd, i: int, x: Tensor, cfg, bias: Optional[Tensor], rows: Optional[slice] = None) -> Tensor:
     """Block.forward (gpt:240-253): x = ln1(x); x = x + attn(x); x = x + mlp(ln2(x)).  The residual is taken from ln1(x) (reference quirk)."""
     p = f"blocks.{i}."
@@ -279,7 +285,7 @@ def _gpt_block(sd, i: int, x: Tensor, cfg, bias: Optional[Tensor], rows: Optiona
     q = split(F.linear(x, sd[p + "attention.query.weight"], sd[p + "attention.query.bias"]))
     k = split(F.linear(x, sd[p + "attention.key.weight"], sd[p + "attention.key.bias"]))
     v = split(F.linear(x, sd[p + "attention.value.weight"], sd[p + "attention.value.bias"]))
-    a = sparse_self_attention_dense(q, k, v, cfg.layout, cfg.sparse_block_size, cfg.attention_mask, bias)
+    a = sparse_self_attention_dense(q, k, v, layer_layout(sd, cfg, i), cfg.sparse_block_size, cfg.attention_mask, bias)
     a = a.permute(0, 2, 1, 3).reshape(x.shape)
     x = x + a  # no output projection (gpt:203-212)
     h = F.layer_norm(x, x.shape[-1:], sd[p + "ln2.weight"], sd[p + "ln2.bias"], 1e-5)
@@ -355,14 +361,14 @@ def ar_sample_full_recompute(sd, cfg, cond_ids: Tensor, I_inv: Tensor, E_inv: Te
 class ARCache:
     """Prefill + KV-cache decode: the same arithmetic as ``gpt_forward`` restricted to the one row each step needs.
     Valid because image rows are causal in decode order and cond rows only see cond columns (maskgen:148, 202-206);
-    checked bit-for-bit-in-argmax against ``ar_sample_full_recompute`` in tests/test_oracle_selfconsistency.py."""
+    checked bit-for-bit-in-argmax against ``ar_sample_full_recompute`` and the reference's own sampling loop in oracle/ref_import/make_golden.py."""
 
     def __init__(self, sd, cfg, cond_ids: Tensor, I_inv: Tensor, E_inv: Tensor):
         self.sd, self.cfg = sd, cfg
         self.B = cond_ids.shape[0]
         K, D, H = cfg.num_cond_tokens, cfg.num_embed, cfg.num_heads
         self.bias = attention_bias(sd, "", cfg) if cfg.camera_bias else None
-        self.present = torch.kron(cfg.layout.to(torch.float32), torch.ones(cfg.sparse_block_size, cfg.sparse_block_size)) > 0
+        self.present = [torch.kron(layer_layout(sd, cfg, i).to(torch.float32), torch.ones(cfg.sparse_block_size, cfg.sparse_block_size)) > 0 for i in range(cfg.num_layers)]
         self.img_embed = None
         c_embed = None
         if cfg.image_embed:
@@ -401,7 +407,7 @@ class ARCache:
         if self.bias is not None:
             s = s + self.bias[rows][:, :n][None, None]
         s = s * (float(dh) ** -0.5)
-        keep = self.present[:, rows][:, :, :n] & (cfg.attention_mask[rows][:, :n] != 0)[None]
+        keep = self.present[i][:, rows][:, :, :n] & (cfg.attention_mask[rows][:, :n] != 0)[None]
         s = s.masked_fill(~keep[None], float("-inf"))
         a = torch.einsum("bhij,bhjd->bhid", s.softmax(dim=-1), vv).permute(0, 2, 1, 3).reshape(x.shape)
         x = x + a

@@ -68,3 +68,17 @@ def test_density_below_one_needs_rng_and_is_seed_reproducible():
     assert not torch.equal(a[0], a[1])  # per-head random layouts
     full = presets.route_a(3, num_layers=1, density=1.0).layout
     assert a.sum() < full.sum()
+
+
+@pytest.mark.parametrize("name,mk", [("nusc6_224x400_d035", lambda: presets.config4(density=0.35)), ("tiny_a_blk4_d035", lambda: presets.tiny_route_a(3, block=4, density=0.35))])
+def test_random_layouts_reproduce_the_reference_draw(name, mk):
+    """S4 with density < 1: multi_outward_pattern (maskgen:217-251) = static U multinomial(prob_layout, nnz) (perm:125-143).  The golden holds the
+    layouts the imported reference drew under torch.manual_seed(seed); tables.head_layouts uses the same primitive in the same call order."""
+    g = golden("tables_" + name)
+    cfg = mk()
+    torch.manual_seed(int(g["seed"]))
+    lay = tables.head_layouts(cfg, cfg._patterns)
+    shape = tuple(g["layout_shape"])
+    want = np.unpackbits(g["layout_bits"])[: int(np.prod(shape))].reshape(shape).astype(np.int64)
+    assert np.array_equal(lay.numpy(), want)
+    assert abs(float(lay.float().mean()) - float(g["layout_fill"])) < 1e-7 and float(g["layout_fill"]) < 0.36
