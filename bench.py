@@ -2,31 +2,34 @@
 """bench.py - BEVGen stage-2 sampling path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): Route M (muse_stage_two bidirectional MaskGit decoder, released hyper-parameters: 14
-layers, D=1024, 16 heads, 18 iterations, top-k thres 0.9, self token critic), 6 views of 256x256, batch = 16 scenes per GPU,
-BEV token grid -> MaskGit generate -> VQGAN decode -> denormalised pixels.  A "step" is one batch of 16 scenes.
-Inputs (BEV token ids, camera matrices) and random-init weights of the reference architecture are synthetic and resident in
-HBM before the timed region.  N > 1: independent scenes are sharded over ranks (weak scaling, 16 scenes per GPU), no data-path
-collective; the only RCCL traffic is the final gather of the uint8 pixels to rank 0 (inside the timed region).
+N > 1: the script launches its own N ranks (one per GPU, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`)
+unless it already runs under a launcher (WORLD_SIZE set); inside, the RCCL world size must equal N or the run fails.
+
+Workload (BASELINE.json configs[1]): Route M (muse_stage_two bidirectional MaskGit decoder, released hyper-parameters: 14 layers, D=1024, 16 heads,
+18 iterations, top-k thres 0.9, self token critic), 6 views of 256x256, batch = 16 scenes per GPU: BEV token grid -> MaskGit generate -> VQGAN decode
+-> uint8 pixels.  A "step" is one batch of 16 scenes.  Inputs (BEV token ids, camera matrices) and random-init weights of the reference
+architecture are synthetic and resident in HBM before the timed region.  N > 1: independent scenes are sharded over ranks (weak scaling, 16 scenes
+per GPU), no data-path collective; the only RCCL traffic is the final gather of the uint8 pixels to rank 0 (inside the timed region); a
+`strong_scaling` leg (16 scenes in total) is added to the line.
 
 Default arithmetic mode: f16x3 (every GEMM / conv / attention product as three f16 MFMAs on hi/lo splits, fp32 accumulation: fp32-class accuracy,
 bit-identical greedy tokens on every parity fixture); the line also carries a one-step `exact_fp32_mode` leg (exact fp32 MFMA).
 
-One JSON line on rank 0 carries: the headline metric, `roofline` for the dominant kernel of the workload (the LDS-DMA split-precision GEMM),
-`roofline_decode_attention` (the HBM-bound Route A decode-attention kernel the north star names; measured on BASELINE config 4
-at N=1), `ms_per_decode_step`, and `cpu_baseline` (the CPU oracle timed on this host on a bounded sample).
+One JSON line on rank 0: the headline metric with median / p99 step times, ms per MaskGit iteration and VQGAN ms per scene, `roofline` for the
+dominant kernel of the workload (the LDS-DMA split-precision GEMM), and at N = 1: the Route A decode legs (BASELINE config 4: ms per decode step
+mean / median / p99, `roofline_decode_attention` = the HBM-bound kernel the north star names, `decode_step_roofline` = (KV + weight bytes) per step
+against HBM peak; f32 and f16 KV cache), the config 5 leg (top-k 32, 4 samples per layout, 64 sequences, shared condition prefix), the released
+3-camera shape, and `cpu_baseline` (the CPU oracle timed on this host: one full scene, plus Route A KV-cache vs full recompute).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -37,9 +40,44 @@ MFMA_FP32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32: exact fp32 at the vector r
 MFMA_F16_PEAK_TF = 2500.0   # dense f16/bf16 MFMA peak
 
 
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step")
+    ap.add_argument("--cams", type=int, default=6)
+    ap.add_argument("--timesteps", type=int, default=18)
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "none"], help="sample = one whole scene with 4 of the 18 MaskGit iterations (about 30 s of CPU work), full = all 18 (minutes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode-leg", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the config 5 / 3-camera legs")
+    ap.add_argument("--decode-batch", type=int, default=16)
+    ap.add_argument("--decode-steps", type=int, default=0, help="0 = a full decode (N image tokens)")
+    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"], help="fp32 = exact fp32 MFMA; f16x3 = split-precision products (both bit-exact on the parity fixtures)")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the additional one-step run in exact-fp32 mode")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N without a launcher: become `torch.distributed.run` with N ranks on this node."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE,
-    gfx950 correction applied), at the probe shape recorded there; None if no PMC summary covers the kernel."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950
+    correction applied) at the probe shape recorded there - a PMC pass cannot run inside this process; None if no summary covers the kernel."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")), reverse=True):
         try:
@@ -52,21 +90,9 @@ def pmc_traffic(kernel):
     return None
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="scenes per GPU per step")
-    ap.add_argument("--cams", type=int, default=6)
-    ap.add_argument("--timesteps", type=int, default=18)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-decode-leg", action="store_true")
-    ap.add_argument("--decode-batch", type=int, default=16)
-    ap.add_argument("--decode-steps", type=int, default=0, help="0 = a full decode (N image tokens)")
-    ap.add_argument("--precision", default="f16x3", choices=["fp32", "f16x3"], help="fp32 = exact fp32 MFMA; f16x3 = split-precision products (both bit-exact on the parity fixtures)")
-    ap.add_argument("--no-exact-leg", action="store_true", help="skip the additional one-step run in exact-fp32 mode")
-    return ap.parse_args()
+def pct(xs, q):
+    import numpy as np
+    return float(np.percentile(np.asarray(xs, dtype=np.float64), q)) if len(xs) else None
 
 
 def build_route_m(cams, batch, device, precision="fp32"):
@@ -85,51 +111,124 @@ def build_route_m(cams, batch, device, precision="fp32"):
     return cfg, ctx, sd
 
 
-def cpu_baseline_route_m(cams):
-    """Oracle (CPU restatement of the reference algorithm, `kind: port`) on a bounded sample of the same workload:
-    ONE scene, ONE MaskGit iteration (2 useful transformer forwards) + ONE image of VQGAN decode, extrapolated to
-    18 iterations and `cams` images per scene.  Also times the reference's own schedule (4 forwards per iteration)."""
-    from bevgen_amd import presets, synthetic
-    from oracle import cases, restate as R
+# ----------------------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
 
-    # pick the thread count that is fastest on this host for the path's dominant op (a 1536x1024 @ 1024x5460 projection):
-    # on many-core hosts "all cores" is far from the optimum for these sizes
-    a, b = torch.randn(1536, 1024), torch.randn(1024, 5460)
+
+def tune_threads(run):
+    """The torch thread count that is fastest on this host for `run` (a bounded piece of the workload itself: on many-core hosts "all cores" is far from
+    the optimum at these sizes, and a GEMM micro-benchmark does not predict the attention / normalisation parts)."""
+    import torch
+
     best_t, best = 1, float("inf")
-    for nt in [n for n in (8, 16, 32, 64, 128, 256) if n <= (os.cpu_count() or 1)] or [1]:
+    for nt in [n for n in (8, 16, 32, 64, 128) if n <= (os.cpu_count() or 1)] or [1]:
         torch.set_num_threads(nt)
-        a @ b
         t0 = time.time()
-        for _ in range(3):
-            a @ b
+        run()
         dt = time.time() - t0
         if dt < best:
             best_t, best = nt, dt
     torch.set_num_threads(best_t)
+    return best_t
+
+
+def cpu_baseline(cams, timesteps, mode):
+    """Oracle (CPU restatement of the reference algorithm, `kind: port`) on this host, on a bounded sample of the headline workload (about 30 s of CPU
+    work): ONE whole scene, measured end to end - MaskGit generate + VQGAN decode of the `cams` images - with 4 MaskGit iterations instead of 18
+    (7 transformer forwards instead of 35; the iterations are identical in cost), scaled to 18 iterations.  mode 'full' runs all 18 (minutes).
+    Beside it: the reference's own schedule (4 forwards per iteration, derived from the measured per-forward time), a 1-thread figure on a bounded
+    piece, and the Route A legs (BASELINE config 4, one sequence: prefill + 8 KV-cache steps vs one full-recompute step of the reference loop)."""
+    import torch
+    from bevgen_amd import presets, synthetic
+    from oracle import cases, restate as R
+
+    model, cores = cpu_info()
     cfg = presets.config2(cams)
     sd = cases.maskgit_state_dict(cfg, 1234)
     bt = synthetic.make_batch(cfg, 1, seed=0)
-    ids = torch.full((cams, cfg.num_cam_tokens), cfg.vocab_size, dtype=torch.long)
+    dd = presets.VQ_DDCONFIG_F16
+    sdv = cases.vq_state_dict(dd, 1024, 256, 99)
+    idm = torch.full((cams, cfg.num_cam_tokens), cfg.vocab_size, dtype=torch.long)
+
+    def two_layers():
+        with torch.no_grad():
+            R.muse_forward(sd, cfg, idm, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], depth=2, heads=cfg.num_heads)
+
+    two_layers()
+    threads = tune_threads(two_layers)
+    its = timesteps if mode == "full" else min(4, timesteps)
     with torch.no_grad():
         t0 = time.time()
-        R.muse_forward(sd, cfg, ids, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], depth=cfg.num_layers, heads=cfg.num_heads)
-        t_fwd = time.time() - t0
-        dd = presets.VQ_DDCONFIG_F16
-        sdv = cases.vq_state_dict(dd, 1024, 256, 99)
-        vid = torch.zeros((1, 256), dtype=torch.long)
+        ids = R.maskgit_generate(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], depth=cfg.num_layers, heads=cfg.num_heads, timesteps=its)
+        t_gen = time.time() - t0
         t0 = time.time()
-        R.vq_decode_ids(sdv, dd, vid, (16, 16))
-        t_img = time.time() - t0
-    scene_same_alg = 35 * t_fwd + cams * t_img          # same forward count as the HIP path (36 - skipped last critic)
-    scene_ref_alg = 72 * t_fwd + cams * t_img           # the reference's schedule (CFG null forwards + critic double forwards)
-    return {"value": 1.0 / scene_same_alg, "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 scene ({cams}x256x256): 1 transformer forward ({t_fwd:.2f}s) + 1 VQGAN image decode ({t_img:.2f}s), extrapolated to 35 forwards + {cams} images",
-            "reference_schedule_value": 1.0 / scene_ref_alg}
+        R.vq_decode_ids(sdv, dd, ids.reshape(cams, -1), (cfg.cam_latent_h, cfg.cam_latent_w))
+        t_dec = time.time() - t0
+    n_meas, n_fwd = 2 * its - 1, 2 * timesteps - 1
+    t_fwd = t_gen / n_meas
+    scene = t_fwd * n_fwd + t_dec
+    out = {"value": 1.0 / scene, "unit": "scenes/s", "cores": threads, "kind": "port",
+           "sample": (f"1 whole scene ({cams}x256x256) measured end to end: MaskGit generate with {its} iterations = {n_meas} transformer forwards ({t_gen:.1f} s) + VQGAN decode of {cams} images "
+                      f"({t_dec:.1f} s)" + ("" if its == timesteps else f"; scaled to {timesteps} iterations = {n_fwd} forwards of the same cost")),
+           "host": {"cpu_model": model, "logical_cores": cores, "threads_used": threads, "threads_note": "fastest of 8..128 torch threads on two transformer layers of this workload"},
+           "seconds_per_forward": t_fwd, "seconds_vqgan_decode_per_image": t_dec / cams,
+           "reference_schedule_value": 1.0 / (4 * timesteps * t_fwd + t_dec),
+           "reference_schedule_note": f"the reference runs {4 * timesteps} forwards per scene (CFG null + critic double forwards, muse_net:272-276, 394-396); derived from the measured per-forward time"}
+    # 1-thread figure on a bounded piece: the first 2 of the 14 layers of one six-view forward
+    torch.set_num_threads(1)
+    t0 = time.time()
+    two_layers()
+    t1 = time.time() - t0
+    out["one_thread"] = {"seconds_2_of_14_layers": t1, "scenes_per_s_extrapolated": 1.0 / (t1 * (cfg.num_layers / 2.0) * n_fwd),
+                         "note": "1 torch thread, 2 transformer layers of one six-view forward, scaled by 7 x 35 (transformer only)"}
+    torch.set_num_threads(threads)
+    # Route A: BASELINE config 4, one sequence
+    del sd
+    cfg4 = presets.config4()
+    sd4 = cases.gpt_state_dict(cfg4, 1234)
+    b4 = synthetic.make_batch(cfg4, 1, seed=0)
+    with torch.no_grad():
+        t0 = time.time()
+        cache = R.ARCache(sd4, cfg4, b4["cond_ids"], b4["intrinsics_inv"], b4["extrinsics_inv"])
+        t_pre = time.time() - t0
+        del cache
+        t0 = time.time()
+        R.ar_sample_cached(sd4, cfg4, b4["cond_ids"], b4["intrinsics_inv"], b4["extrinsics_inv"], steps=8)
+        t_c8 = time.time() - t0 - t_pre
+        t0 = time.time()
+        R.ar_sample_full_recompute(sd4, cfg4, b4["cond_ids"], b4["intrinsics_inv"], b4["extrinsics_inv"], steps=1)
+        t_full = time.time() - t0
+    out["route_a_config4"] = {"prefill_s": t_pre, "kv_cache_ms_per_step": max(t_c8, 0.0) * 1e3 / 8, "full_recompute_ms_per_step": t_full * 1e3,
+                              "sample": "1 sequence, L=2368: prefill + 8 KV-cache steps; 1 step of the reference's full L-token forward per token (ar_lm:172-219)"}
+    return out
 
 
-def decode_leg(device, batch, steps, kv_cache="f32"):
-    """Route A (BASELINE config 4: nuScenes 6-view 224x400, 24 layers, L=2368, blk 16, camera bias): greedy decode of `steps`
-    tokens for `batch` sequences; returns ms/step and the decode-attention roofline from HIP events."""
+# ----------------------------------------------------------------------------------------------------------------- Route A legs
+def route_a_bytes(cfg, B, steps, kv_bytes, G=1):
+    """Algorithmic HBM bytes of a decode run: K and V rows of the context once per (sequence, head, layer) - the shared condition prefix once
+    per group - and every weight matrix once per step."""
+    H, D, K, Lyr, V = cfg.num_heads, cfg.num_embed, cfg.num_cond_tokens, cfg.num_layers, cfg.vocab_size
+    kv = 0.0
+    for s in range(steps):
+        n = K + s + 1
+        kv += 2.0 * H * 64 * kv_bytes * Lyr * (B * (n - (K if G > 1 else 0)) + (B // G) * (K if G > 1 else 0))
+    w = steps * 4.0 * (Lyr * (3 * D * D + 8 * D * D) + V * D)
+    return kv, w
+
+
+def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic=False):
+    """Route A (BASELINE config 4: nuScenes 6-view 224x400, 24 layers, L=2368, blk 16, camera bias): decode of `steps` tokens for `batch` sequences through
+    the product path (hipGraph replay of the fused decode step).  S > 1 = BASELINE config 5: groups of S samples share their BEV layout."""
+    import torch
     from bevgen_amd import presets, synthetic
     from bevgen_amd.runtime import Context
     from bevgen_amd.weights import gpt_state_dict
@@ -139,47 +238,80 @@ def decode_leg(device, batch, steps, kv_cache="f32"):
     ctx.load_state_dict(gpt_state_dict(cfg, 1234))
     ctx.set_tables()
     ctx.finalize()
-    bt = synthetic.make_batch(cfg, batch, seed=0)
-    bt = {k: v.to(ctx.device) for k, v in bt.items()}
+    bt = synthetic.make_batch(cfg, batch // S, seed=0)
+    bt = {k: v.repeat_interleave(S, dim=0).to(ctx.device) for k, v in bt.items()}
     steps = steps or cfg.num_img_tokens
-    ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=8)  # warm-up
+    noise = synthetic.uniform_noise((steps, batch), 2025, 1).to(ctx.device) if stochastic else None
+
+    def sample(n_steps):
+        kw = dict(samples_per_layout=S)
+        if stochastic:
+            kw.update(greedy=False, top_k=top_k, temperature=1.0, noise_u=noise[:n_steps].contiguous() if n_steps != steps else noise)
+        return ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=n_steps, **kw)
+
+    sample(8)  # warm-up
     torch.cuda.synchronize()
     t0 = time.time()
     ctx.ar_prefill(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"])   # the K condition rows of every sequence through the 24 layers
     torch.cuda.synchronize()
     prefill_ms = (time.time() - t0) * 1e3
-    # pass 1: the product path (decode loop replayed as a hipGraph) -> wall time per step
+    # pass 1: the product path with one event per replayed step -> wall time, per-step distribution
+    ctx.ar_step_timing(True)
     t0 = time.time()
-    ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=steps)
+    sample(steps)
     torch.cuda.synchronize()
     wall = time.time() - t0
-    # pass 2: same work launched eagerly with a HIP-event pair around every decode-attention / skinny-GEMM launch -> per-kernel rooflines
+    st = ctx.ar_step_times(steps + 8)
+    ctx.ar_step_timing(False)
+    # pass 2: same work launched eagerly with a HIP-event pair around every fused attention / skinny-GEMM launch -> per-kernel rooflines
     ctx.profile_begin()
-    ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=steps)
+    sample(steps)
     torch.cuda.synchronize()
     prof = ctx.profile_end()
-    da = prof["decode_attention"]
-    gs = prof["gemm_skinny"]
+    # pass 3: phase timestamps of the last step's kernels (attention phase alone)
+    ctx.trace_begin()
+    sample(min(steps, 1044))
+    tr = ctx.trace_end().double()[0] / 100.0
+    tr = tr[tr[:, 0] > 0]
+    n_last = cfg.num_cond_tokens + min(steps, 1044) - 1
+    kvb = 4 if kv_cache == "f32" else 2
+    phase_us = float((tr[:, 4] - tr[:, 3]).mean()) if tr.numel() else None
+    K = cfg.num_cond_tokens
+    phase_bytes = 2.0 * cfg.num_heads * 64 * kvb * (batch * (n_last - (K if S > 1 else 0)) + (batch // S) * (K if S > 1 else 0))
     ctx.close()
+    da, gs = prof["decode_attention"], prof["gemm_skinny"]
     ach = da["work"] / (da["ms"] * 1e-3) / 1e9 if da["ms"] > 0 else 0.0
+    kv_bytes, w_bytes = route_a_bytes(cfg, batch, steps, kvb, S)
+    step_ach = (kv_bytes + w_bytes) / wall / 1e9
     out = {
-        "ms_per_decode_step": wall * 1e3 / steps,
-        "decode_prefill_ms": prefill_ms,
-        "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("decode_attention_kernel") if kv_cache == "f32" else None,
+        "ms_per_decode_step": wall * 1e3 / steps, "ms_per_decode_step_median": pct(st, 50), "ms_per_decode_step_p99": pct(st, 99), "decode_prefill_ms": prefill_ms,
+        "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                      "traffic": None, "kernel": "ar_attn_fused_kernel (ln1 + q/k/v projection + decode attention in one launch; achieved = K/V bytes / WHOLE kernel time)",
+                                      "attention_phase": {"GBs": phase_bytes / (phase_us * 1e-6) / 1e9 if phase_us else None, "frac": phase_bytes / (phase_us * 1e-6) / 1e9 / HBM_PEAK_GBS if phase_us else None,
+                                                          "us": phase_us, "context": n_last, "note": "K/V streaming phase alone, device timestamps of one launch"},
                                       "launches": int(da["launches"]), "avg_us": da["ms"] * 1e3 / max(da["launches"], 1),
-                                      "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of a full decode, {kv_cache} KV cache, L=2368"},
-        "decode_scenes_per_s": batch / wall,
+                                      "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of the decode, {kv_cache} KV cache, L=2368" + (f", {S} samples per layout (shared prefix read once per group)" if S > 1 else "")},
+        "decode_step_roofline": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_ach / HBM_PEAK_GBS,
+                                 "bytes_per_step": {"kv": kv_bytes / steps, "weights": w_bytes / steps}, "note": "(K/V rows of the context + every fp32 weight matrix once) per step / wall time per step"},
+        "decode_sequences_per_s": batch / wall, "decode_scenes_per_s": batch / wall,
         "decode_weight_stream": {"achieved_GBs": gs["work"] / (gs["ms"] * 1e-3) / 1e9 if gs["ms"] > 0 else 0.0, "launches": int(gs["launches"])},
     }
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -188,20 +320,28 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group("nccl", rank=rank, world_size=world)  # backend "nccl" is RCCL on ROCm
         dist = dist_mod
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
+    n_gpus = dist.get_world_size() if dist else 1
 
     from bevgen_amd import synthetic
     from bevgen_amd.parallel import gather_scenes
 
-    def run_route_m(precision, steps, warmup):
-        cfg, ctx, _ = build_route_m(args.cams, args.batch, local_rank, precision)
-        bt = synthetic.make_batch(cfg, args.batch, seed=1000 + rank)  # each rank: its own shard of scenes
+    def run_route_m(precision, steps, warmup, cams, batch):
+        cfg, ctx, _ = build_route_m(cams, batch, local_rank, precision)
+        bt = synthetic.make_batch(cfg, batch, seed=1000 + rank)  # each rank: its own shard of scenes
         bt = {k: v.to(ctx.device) for k, v in bt.items()}
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
 
-        def one_step():
+        def one_step(e=None):
+            if e: e[0].record()
             ids = ctx.maskgit_generate(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], timesteps=args.timesteps)
-            px = ctx.vq_decode(ids.reshape(args.batch * args.cams, -1), denormalize=True)      # [B*C,3,256,256] in [0,1]
-            return gather_scenes(px.reshape(args.batch, args.cams, 3, px.shape[-2], px.shape[-1]), dist)
+            if e: e[1].record()
+            px = ctx.vq_decode(ids.reshape(batch * cams, -1), latent_hw=(cfg.cam_latent_h, cfg.cam_latent_w), uint8=True)      # [B*C,3,256,256] uint8
+            if e: e[2].record()
+            out = gather_scenes(px.reshape(batch, cams, 3, px.shape[-2], px.shape[-1]), dist)
+            if e: e[3].record()
+            return out
 
         for _ in range(warmup):
             one_step()
@@ -210,8 +350,8 @@ def main():
         torch.cuda.synchronize()
         ctx.profile_begin()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step()
+        for i in range(steps):
+            one_step(ev[i])
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -220,13 +360,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        parts = {"step": [e[0].elapsed_time(e[3]) for e in ev], "generate": [e[0].elapsed_time(e[1]) for e in ev],
+                 "vq_decode": [e[1].elapsed_time(e[2]) for e in ev], "gather": [e[2].elapsed_time(e[3]) for e in ev]}
         ctx.close()
-        return float(t.item()), prof
+        return float(t.item()), prof, parts
 
-    elapsed, prof = run_route_m(args.precision, args.steps, args.warmup)
+    elapsed, prof, parts = run_route_m(args.precision, args.steps, args.warmup, args.cams, args.batch)
+    strong = None
+    if world > 1 and 16 % world == 0:
+        s_steps = max(2, min(args.steps, 5))
+        e_s, _, _ = run_route_m(args.precision, s_steps, 1, args.cams, 16 // world)   # 16 scenes in total, sharded
+        strong = {"scaling": "strong", "global_batch": 16, "scenes_per_gpu": 16 // world, "steps": s_steps, "value": 16 * s_steps / e_s, "unit": "scenes/s", "ms_per_step": e_s * 1e3 / s_steps}
     exact = None
     if world == 1 and args.precision != "fp32" and not args.no_exact_leg:
-        e2, p2 = run_route_m("fp32", 1, 1)   # the exact-fp32 parity mode on the same workload (one step)
+        e2, p2, _ = run_route_m("fp32", 1, 1, args.cams, args.batch)   # the exact-fp32 parity mode on the same workload (one step)
         exact = (e2, p2)
 
     if rank != 0:
@@ -234,7 +381,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    def roof(prof, elapsed_s, precision):
+    def roof(prof, precision):
         g = prof["gemm"]
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         if precision == "fp32":
@@ -244,30 +391,46 @@ def main():
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(kern), "kernel": kern, "note": note,
                 "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1)}
 
-    scenes = world * args.batch * args.steps
+    import numpy as np
+    scenes = n_gpus * args.batch * args.steps
     line = {
-        "metric": "multi-view scenes/sec (6x256x256)", "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "multi-view scenes/sec (6x256x256)", "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps, "ms_per_step_median": pct(parts["step"], 50), "ms_per_step_p99": pct(parts["step"], 99),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM/conv/attention products as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; everything else fp32)",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: Route M MaskGit (14 layers, D=1024, 18 iterations, self-critic) {args.cams}x256x256, batch {args.batch} scenes/GPU, + VQGAN f16 decode",
-                   "global_batch": world * args.batch, "parallelism": f"scene-parallel x{world} (RCCL gather of uint8 pixels)", "precision_mode": args.precision},
-        "roofline": roof(prof, elapsed, args.precision),
+        "config": {"workload": f"BASELINE configs[1]: Route M MaskGit (14 layers, D=1024, 18 iterations, self-critic) {args.cams}x256x256, batch {args.batch} scenes/GPU, + VQGAN f16 decode to uint8",
+                   "global_batch": n_gpus * args.batch, "parallelism": f"scene-parallel x{n_gpus} (RCCL gather of uint8 pixels)", "precision_mode": args.precision},
+        "ms_per_maskgit_iteration": float(np.mean(parts["generate"])) / args.timesteps,
+        "vqgan_decode_ms_per_scene": float(np.mean(parts["vq_decode"])) / args.batch,
+        "gather_ms_per_step": float(np.mean(parts["gather"])),
+        "roofline": roof(prof, args.precision),
         "kernel_time_share": {k: v["ms"] / (elapsed * 1e3) for k, v in prof.items() if v["launches"]},
         "kernel_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12) for k, v in prof.items() if v["launches"] and k in ("gemm", "conv3x3", "attention")},
     }
+    if strong is not None:
+        line["strong_scaling"] = strong
     if exact is not None:
         e2, p2 = exact
-        line["exact_fp32_mode"] = {"value": world * args.batch / e2, "unit": "scenes/s", "ms_per_step": e2 * 1e3, "roofline": roof(p2, e2, "fp32"),
+        line["exact_fp32_mode"] = {"value": args.batch / e2, "unit": "scenes/s", "ms_per_step": e2 * 1e3, "roofline": roof(p2, "fp32"),
                                    "note": "bit-exact-parity mode (every product in fp32 on the matrix cores), same workload, 1 step"}
+    if world == 1 and not args.no_extra_legs:
+        e3, _, p3 = run_route_m(args.precision, 2, 1, 3, args.batch)   # the shape of the released Argoverse checkpoint (3 cameras, N=768)
+        line["released_3_camera_shape"] = {"value": args.batch * 2 / e3, "unit": "scenes/s", "ms_per_step": e3 * 1e3 / 2, "ms_per_maskgit_iteration": float(np.mean(p3["generate"])) / args.timesteps,
+                                           "config": f"Route M, 3x256x256 (configs/modes/argoverse.yaml), batch {args.batch}, 2 steps"}
     if world == 1 and not args.no_decode_leg:
         line.update(decode_leg(local_rank, args.decode_batch, args.decode_steps))
-        # BASELINE config 4 names fp16 storage: the same decode with the KV cache stored as fp16 (fp32 accumulate; tokens not guaranteed bit-exact)
+        # BASELINE config 4 names fp16 storage: the same decode with the KV cache stored as fp16 (fp32 accumulate; logits within 2e-3 of the range, tests)
         f16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16")
-        line["decode_f16_kv_cache"] = {"ms_per_decode_step": f16["ms_per_decode_step"], "decode_scenes_per_s": f16["decode_scenes_per_s"],
-                                       "roofline_decode_attention": f16["roofline_decode_attention"]}
-    if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_route_m(args.cams)
+        line["decode_f16_kv_cache"] = {k: f16[k] for k in ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline")}
+        if not args.no_extra_legs:
+            c5 = decode_leg(local_rank, 64, args.decode_steps, kv_cache="f32", S=4, top_k=32, stochastic=True)
+            line["config5_topk32_4_samples_per_layout"] = {"sequences": 64, "layouts": 16, "ms_per_decode_step": c5["ms_per_decode_step"], "ms_per_decode_step_median": c5["ms_per_decode_step_median"],
+                                                           "ms_per_decode_step_p99": c5["ms_per_decode_step_p99"], "sequences_per_s": c5["decode_sequences_per_s"], "prefill_ms": c5["decode_prefill_ms"],
+                                                           "roofline_decode_attention": c5["roofline_decode_attention"], "decode_step_roofline": c5["decode_step_roofline"],
+                                                           "config": "BASELINE configs[4] on one GPU: Route A config-4 model, top-k 32, explicit uniforms (Philox seed 2025), 16 BEV layouts x 4 samples, condition prefix prefilled and read once per layout"}
+    if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "none":
+        line["cpu_baseline"] = cpu_baseline(args.cams, args.timesteps, args.cpu_baseline)
     print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

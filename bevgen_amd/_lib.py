@@ -78,6 +78,8 @@ SIGNATURES = {
     "bevgen_decode_attention_splits": (_i, [_i, _i, _i]),
     "bevgen_profile_begin": (_i, [_p]),
     "bevgen_profile_end": (_i, [_p, C.POINTER(C.c_double)]),
+    "bevgen_ar_step_timing": (_i, [_p, _i]),
+    "bevgen_ar_step_times": (_i, [_p, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "bevgen_set_trace_buffer": (_i, [_p, _p]),
 }
 

@@ -313,6 +313,17 @@ int bevgen_profile_end(bevgen_ctx* ctx, double* out) {
     });
 }
 
+int bevgen_ar_step_timing(bevgen_ctx* ctx, int enable) {
+    return guarded(ctx, [&] { ctx->time_steps = enable != 0; });
+}
+
+int bevgen_ar_step_times(bevgen_ctx* ctx, float* h_out_ms, int cap, int* count) {
+    return guarded(ctx, [&] {
+        BG_REQUIRE(h_out_ms && count && cap >= 0, "ar_step_times: bad arguments");
+        *count = ar_step_times(*ctx, h_out_ms, cap);
+    });
+}
+
 int bevgen_set_trace_buffer(bevgen_ctx* ctx, void* d_buf) {
     return guarded(ctx, [&] { ctx->trace = reinterpret_cast<long long*>(d_buf); });
 }

@@ -403,26 +403,57 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     hipStream_t q = c.graph_stream;
     HIP_CHECK(hipEventRecord(c.graph_ev_in, s));
     HIP_CHECK(hipStreamWaitEvent(q, c.graph_ev_in, 0));
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    HIP_CHECK(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
-    try {
-        head_and_pick(w.logits, q);
-        decode_step_launch(c, w, w.tok, q);
-    } catch (...) {
-        (void)hipStreamEndCapture(q, &graph);
-        if (graph) (void)hipGraphDestroy(graph);
-        throw;
+    Ctx::GraphKey key;
+    key.B = B; key.G = st.G; key.top_k = top_k; key.greedy = greedy; key.kv = cache_dtype(c); key.temperature = temperature;
+    key.noise = greedy ? nullptr : noise_u; key.forced = forced; key.out = out; key.arena = c.arena.base; key.persist = c.persist.base; key.trace = c.trace;
+    if (!c.graph_exec || !(c.graph_key == key)) {
+        if (c.graph_exec) c.retire_graph(c.graph_exec, c.graph);
+        c.graph_exec = nullptr; c.graph = nullptr;
+        hipGraph_t graph = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal));
+        try {
+            head_and_pick(w.logits, q);
+            decode_step_launch(c, w, w.tok, q);
+        } catch (...) {
+            (void)hipStreamEndCapture(q, &graph);
+            if (graph) (void)hipGraphDestroy(graph);
+            throw;
+        }
+        HIP_CHECK(hipStreamEndCapture(q, &graph));
+        HIP_CHECK(hipGraphInstantiate(&c.graph_exec, graph, nullptr, nullptr, 0));
+        c.graph = graph;
+        c.graph_key = key;
     }
-    HIP_CHECK(hipStreamEndCapture(q, &graph));
-    HIP_CHECK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    for (int step = 0; step + 1 < steps; ++step) HIP_CHECK(hipGraphLaunch(exec, q));
+    c.step_events_used = 0;
+    auto stamp = [&]() {
+        if (!c.time_steps) return;
+        if (c.step_events_used == (int)c.step_events.size()) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            c.step_events.push_back(e);
+        }
+        HIP_CHECK(hipEventRecord(c.step_events[c.step_events_used++], q));
+    };
+    stamp();
+    for (int step = 0; step + 1 < steps; ++step) {
+        HIP_CHECK(hipGraphLaunch(c.graph_exec, q));
+        stamp();
+    }
     st.step += steps - 1;
     head_and_pick(w.logits, q);
     HIP_CHECK(hipEventRecord(c.graph_ev_out, q));
     HIP_CHECK(hipStreamWaitEvent(s, c.graph_ev_out, 0));
-    // the exec object must outlive its in-flight launches: destroy it once the work has drained (deferred to the next call / destroy)
-    c.retire_graph(exec, graph);
 }
 
+}  // namespace bevgen
+
+namespace bevgen {
+// durations of the graph replays of the most recent bevgen_ar_sample (one decode step each), in milliseconds; synchronises the library stream
+int ar_step_times(Ctx& c, float* out_ms, int cap) {
+    if (c.step_events_used < 2) return 0;
+    HIP_CHECK(hipEventSynchronize(c.step_events[c.step_events_used - 1]));
+    const int n = std::min(cap, c.step_events_used - 1);
+    for (int i = 0; i < n; ++i) HIP_CHECK(hipEventElapsedTime(&out_ms[i], c.step_events[i], c.step_events[i + 1]));
+    return n;
+}
 }  // namespace bevgen

@@ -55,6 +55,8 @@ Ctx::~Ctx() {
         (void)hipGraphExecDestroy(p.first);
         (void)hipGraphDestroy(p.second);
     }
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); (void)hipGraphDestroy(graph); }
+    for (hipEvent_t e : step_events) (void)hipEventDestroy(e);
     if (graph_ev_in) (void)hipEventDestroy(graph_ev_in);
     if (graph_ev_out) (void)hipEventDestroy(graph_ev_out);
     if (graph_stream) (void)hipStreamDestroy(graph_stream);
@@ -276,6 +278,11 @@ void ctx_finalize(Ctx& c) {
     HIP_CHECK(hipSetDevice(c.device));
     const auto& g = c.cfg;
     // free previously derived buffers (re-finalize after reloading weights)
+    if (c.graph_exec) {   // the captured graph bakes in pointers to the derived buffers freed below
+        if (c.graph_stream) (void)hipStreamSynchronize(c.graph_stream);
+        (void)hipGraphExecDestroy(c.graph_exec); (void)hipGraphDestroy(c.graph);
+        c.graph_exec = nullptr; c.graph = nullptr;
+    }
     for (void* p : c.owned) (void)hipFree(p);
     c.owned.clear();
     c.split.clear();

@@ -119,6 +119,21 @@ struct Ctx {
     hipStream_t graph_stream = nullptr;
     hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
     std::vector<std::pair<hipGraphExec_t, hipGraph_t>> retired_graphs;
+    // the instantiated decode-step graph is kept and replayed by later bevgen_ar_sample calls that bake in the same pointers / parameters
+    struct GraphKey {
+        int B = 0, G = 0, top_k = 0, greedy = 0, kv = 0; float temperature = 0.f;
+        const void *noise = nullptr, *forced = nullptr, *out = nullptr, *arena = nullptr, *persist = nullptr, *trace = nullptr;
+        bool operator==(const GraphKey& o) const {
+            return B == o.B && G == o.G && top_k == o.top_k && greedy == o.greedy && kv == o.kv && temperature == o.temperature && noise == o.noise &&
+                   forced == o.forced && out == o.out && arena == o.arena && persist == o.persist && trace == o.trace;
+        }
+    } graph_key;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    // per-step timing of the graph replays (bevgen_ar_step_timing): one event after every replay
+    bool time_steps = false;
+    std::vector<hipEvent_t> step_events;
+    int step_events_used = 0;
     bool disable_graphs = false;
     long long* trace = nullptr;   // diagnostics (bevgen_set_trace_buffer): phase timestamps of the fused decode kernels, [3 kinds][4096 workgroups][8]
     void retire_graph(hipGraphExec_t e, hipGraph_t g);  // destroyed once the stream has drained (next call or destroy)
@@ -145,6 +160,7 @@ void ar_logits(Ctx& c, float* logits, hipStream_t s);
 void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s);
 void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int steps, int top_k, float temperature, int greedy,
                const float* noise_u, int samples_per_layout, const int64_t* forced, int64_t* out, float* step_logits, hipStream_t s);
+int ar_step_times(Ctx& c, float* out_ms, int cap);
 // vqdec.cpp
 void vq_finalize(Ctx& c);
 void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n, int lat_h, int lat_w, int out_mode, void* out, hipStream_t s);

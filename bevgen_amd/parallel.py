@@ -25,9 +25,10 @@ def to_uint8(px: torch.Tensor) -> torch.Tensor:
 
 
 def gather_scenes(px: torch.Tensor, dist=None, dst: int = 0) -> Optional[torch.Tensor]:
-    """Gather per-rank pixel blocks [b, C, 3, H, W] (float in [0,1]) as uint8 on rank `dst`; returns the concatenation there, None elsewhere.
-    All ranks must pass blocks of the same shape (pad the last shard if the scene count does not divide)."""
-    u8 = to_uint8(px)
+    """Gather per-rank pixel blocks [b, C, 3, H, W] (uint8 as bevgen_vq_decode's BEVGEN_VQ_OUT_U8 writes them, or float in [0,1]) as uint8 on rank
+    `dst`; returns the concatenation there, None elsewhere.  All ranks must pass blocks of the same shape (pad the last shard if the scene count
+    does not divide)."""
+    u8 = px if px.dtype == torch.uint8 else to_uint8(px)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return u8
     world, rank = dist.get_world_size(), dist.get_rank()

@@ -309,6 +309,16 @@ class Context:
         self._check(self.lib.bevgen_profile_end(self._h, buf))
         return {k: {"launches": buf[3 * i], "ms": buf[3 * i + 1], "work": buf[3 * i + 2]} for i, k in enumerate(self.PROFILE_KINDS)}
 
+    def ar_step_timing(self, enable: bool = True):
+        self._check(self.lib.bevgen_ar_step_timing(self._h, int(enable)))
+
+    def ar_step_times(self, cap: int = 4096):
+        """Durations (ms) of the decode steps of the most recent ar_sample (graph replays), as a float32 numpy array."""
+        buf = (C.c_float * cap)()
+        n = C.c_int(0)
+        self._check(self.lib.bevgen_ar_step_times(self._h, buf, cap, C.byref(n)))
+        return np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
+
     def trace_begin(self):
         """Diagnostics: phase timestamps of the fused decode kernels (last launch of each kind)."""
         self._trace = torch.zeros((3, 4096, 8), dtype=torch.int64, device=self.device)

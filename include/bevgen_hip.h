@@ -217,6 +217,11 @@ int bevgen_decode_attention_splits(int B, int H, int n);
 int bevgen_profile_begin(bevgen_ctx* ctx);
 int bevgen_profile_end(bevgen_ctx* ctx, double* out);
 
+/* Per-step latency of bevgen_ar_sample: with timing enabled the library records one HIP event after every replay of the captured decode step;
+ * bevgen_ar_step_times writes the durations (ms) of the most recent call's steps to the HOST array h_out_ms[cap] and their number to *count (synchronises). */
+int bevgen_ar_step_timing(bevgen_ctx* ctx, int enable);
+int bevgen_ar_step_times(bevgen_ctx* ctx, float* h_out_ms, int cap, int* count);
+
 /* Diagnostics: phase timestamps of the fused Route A decode kernels.  d_buf = device buffer of 3 * 4096 * 8 int64 (kinds: 0 ln1+qkv+attention,
  * 1 ln2+MLP-up, 2 MLP-down; [workgroup][8] 100 MHz device timestamps at the phase boundaries of the most recent launch), NULL = off. */
 int bevgen_set_trace_buffer(bevgen_ctx* ctx, void* d_buf);
