@@ -219,7 +219,11 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float*
             } else {
                 launch_gemm_split(g, (hipStream_t)stream);
             }
-        } else if (skinny) launch_gemm_skinny(g, (hipStream_t)stream);
+        } else if (skinny) {   // split-K workspace from this context's arena (one per context / device)
+            ctx->arena.reserve(gemm_skinny_ws_bytes(M, N, K) + 4096);
+            ctx->arena.reset();
+            launch_gemm_skinny_ws(g, reinterpret_cast<float*>(ctx->arena.alloc(gemm_skinny_ws_bytes(M, N, K))), (hipStream_t)stream);
+        }
         else launch_gemm(g, (hipStream_t)stream);
     });
 }
@@ -272,7 +276,10 @@ int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* q, const void* kc, 
         a.q = q; a.ldq = H * 64; a.kcache = kc; a.vcache = vc; a.kv_dtype = kv_dtype;
         a.bias = bias; a.ldbias = ldbias; a.keep = keep; a.ldkeep = ldkeep; a.keep_head_stride = keep_head_stride;
         a.O = out; a.ldo = H * 64; a.B = B; a.H = H; a.n = n; a.Lmax = Lmax; a.scale = scale;
-        launch_decode_attention(a, (hipStream_t)stream);
+        const int S = decode_attention_splits(a.B, a.H, a.n);
+        ctx->arena.reserve(decode_attention_ws_bytes(a.B, a.H, S) + 4096);
+        ctx->arena.reset();
+        launch_decode_attention_ws(a, reinterpret_cast<float*>(ctx->arena.alloc(decode_attention_ws_bytes(a.B, a.H, S))), S, (hipStream_t)stream);
     });
 }
 

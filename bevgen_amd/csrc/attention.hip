@@ -389,19 +389,4 @@ void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipSt
     LAUNCH_CHECK();
 }
 
-static float* g_dec_ws = nullptr;
-static size_t g_dec_ws_bytes = 0;
-
-void launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
-    // convenience entry with a library-owned workspace (op-level tests); the model path passes its own arena memory
-    const int S = decode_attention_splits(a.B, a.H, a.d_n ? a.Lmax : a.n);
-    const size_t need = decode_attention_ws_bytes(a.B, a.H, S);
-    if (need > g_dec_ws_bytes) {
-        if (g_dec_ws) HIP_CHECK(hipFree(g_dec_ws));
-        HIP_CHECK(hipMalloc(&g_dec_ws, need));
-        g_dec_ws_bytes = need;
-    }
-    launch_decode_attention_ws(a, g_dec_ws, S, s);
-}
-
 }  // namespace bevgen

@@ -153,17 +153,4 @@ void launch_gemm_skinny_ws(const GemmArgs& g, float* ws, hipStream_t stream) {
     }
 }
 
-static float* g_skinny_ws = nullptr;
-static size_t g_skinny_ws_bytes = 0;
-
-void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream) {
-    const size_t need = gemm_skinny_ws_bytes(g.M, g.N, g.K);
-    if (need > g_skinny_ws_bytes) {
-        if (g_skinny_ws) HIP_CHECK(hipFree(g_skinny_ws));
-        HIP_CHECK(hipMalloc(&g_skinny_ws, need));
-        g_skinny_ws_bytes = need;
-    }
-    launch_gemm_skinny_ws(g, g_skinny_ws, stream);
-}
-
 }  // namespace bevgen

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     if (g.tile_band > 0) xcd_tile_banded(gridDim.x, gridDim.y, g.tile_band, tx, ty);
     else xcd_tile(gridDim.x, gridDim.y, tx, ty);
     const int n0 = tx * GBN, m0 = ty * TBM;
-    const int n0l = (g.diag & 1) ? 0 : n0, m0l = (g.diag & 1) ? 0 : m0;   // diag: every block loads tile (0,0) -> all-L2-hit upper bound (results wrong)
+    const int n0l = n0, m0l = m0;
 
     const _Float16* Ap = reinterpret_cast<const _Float16*>(g.A_hi);   // interleaved planes: (row, 32-k block) = 64 halves = one 128-byte line
     const _Float16* Bp = reinterpret_cast<const _Float16*>(g.B_hi);
@@ -351,15 +351,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     if (g.epi == EPI_MUSE_Q)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");
-    static int band = -1, diag = 0, force_wm = 0;
-    if (band < 0) {
-        const char* e = getenv("BEVGEN_GLDS_BAND");
-        band = e ? atoi(e) : 4;
-        diag = getenv("BEVGEN_GLDS_DIAG") ? 1 : 0;
-        const char* w = getenv("BEVGEN_GLDS_WM");
-        force_wm = w ? atoi(w) : 0;
-    }
-    g.tile_band = band; g.diag = diag;
+    g.tile_band = 4;   // band height of the XCD-aware tile order (measured optimum for 256 x 128 tiles)
+    const int force_wm = 0;
     // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
     // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU
     const int wm = force_wm ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);

@@ -47,7 +47,7 @@ struct GemmArgs {
     int epi_rows = 0, epi_heads = 0;
     float epi_post = 1.f;             // EPI_MUSE_Q: extra factor on the prepared query (the attention kernel's score scale, folded in here)
     int a_bytes = 0;                  // MODE_CONV3: size of the activation plane image (buffer-resource bound), filled in by the launcher
-    int tile_band = 0, diag = 0;      // tile-order band height (0 = row-major) / diagnostic all-L2-hit mode; filled in by the launcher
+    int tile_band = 0;                // tile-order band height (0 = row-major); filled in by the launcher
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
 void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);
@@ -60,7 +60,6 @@ void launch_split_weight(const float* w, void* planes /* 2n halves, interleaved 
 void split_registry_set(const void* table /* const std::unordered_map<const float*, SplitPlanes>* */);
 
 // Skinny GEMM for decode steps (M <= 64 rows, weight-streaming bound): C[M,N] = A[M,K] B[N,K]^T + bias, act, residual
-void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream);               // library-owned split-K workspace (op tests)
 int gemm_skinny_ksplit(int M, int N, int K);
 size_t gemm_skinny_ws_bytes(int M, int N, int K);
 void launch_gemm_skinny_ws(const GemmArgs& g, float* ws, hipStream_t stream);  // caller-owned workspace (model path)
@@ -145,7 +144,6 @@ struct DecodeAttnArgs {
 int decode_attention_splits(int B, int H, int n_max);
 size_t decode_attention_ws_bytes(int B, int H, int S);
 void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipStream_t s);
-void launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- decode_fused.hip (Route A decode step, three launches per layer)
 // A [M, D] fp32 matrix that may still be "in flight" as split-K partial sums: element (m, c) = base[m*ld + c] + bias[c] + sum_k partial[k*pstride + m*pld + c]

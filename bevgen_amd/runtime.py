@@ -22,8 +22,8 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _req(t: torch.Tensor, dtype, device, name: str) -> torch.Tensor:
@@ -118,6 +118,10 @@ class Context:
     def _check(self, code):
         _lib.check(self._h, code)
 
+    def _s(self):
+        """The current torch stream of THIS context's device (not of whatever device is current)."""
+        return _stream(self.device)
+
     def load_tensor(self, name: str, t) -> None:
         a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
         if a.dtype == np.float32:
@@ -167,7 +171,7 @@ class Context:
         rows = B * cfg.num_cams
         logits = torch.empty((rows, cfg.num_cam_tokens, cfg.vocab_size), dtype=torch.float32, device=d) if want_logits else None
         embed = torch.empty((rows, cfg.num_cam_tokens, cfg.num_embed), dtype=torch.float32, device=d) if want_embed else None
-        self._check(self.lib.bevgen_muse_forward(self._h, _ptr(ids), _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, _ptr(logits), _ptr(embed), _stream()))
+        self._check(self.lib.bevgen_muse_forward(self._h, _ptr(ids), _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, _ptr(logits), _ptr(embed), self._s()))
         return logits, embed
 
     def maskgit_generate(self, cond_ids, I_inv, E_inv, *, timesteps=18, temperature=1.0, topk_filter_thres=0.9, critic_noise_scale=1.0,
@@ -193,7 +197,7 @@ class Context:
         out = torch.empty((rows, T), dtype=torch.int64, device=d)
         self._check(self.lib.bevgen_maskgit_generate(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, timesteps, sched_c, float(temperature),
                                                       topk_count(topk_filter_thres, cfg.vocab_size), float(critic_noise_scale), _ptr(gumbel_u), _ptr(critic_u),
-                                                      _ptr(init_ids), _ptr(out), _stream()))
+                                                      _ptr(init_ids), _ptr(out), self._s()))
         return out.reshape(rows, cfg.cam_latent_h, cfg.cam_latent_w)
 
     # ------------------------------------------------------------------------------------------ Route A
@@ -206,7 +210,7 @@ class Context:
         attn_mask = _req(attn_mask.reshape(L, L), torch.float32, d, "attn_mask")
         add = None if add_mask is None else _req(add_mask.reshape(L, L), torch.float32, d, "add_mask")
         out = torch.empty_like(q)
-        self._check(self.lib.bevgen_sparse_self_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(layout), _ptr(attn_mask), _ptr(add), B, H, L, int(block), _ptr(out), _stream()))
+        self._check(self.lib.bevgen_sparse_self_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(layout), _ptr(attn_mask), _ptr(add), B, H, L, int(block), _ptr(out), self._s()))
         return out
 
     def ar_prefill(self, cond_ids, I_inv, E_inv):
@@ -215,16 +219,16 @@ class Context:
         I_inv = _req(I_inv, torch.float32, d, "I_inv")
         E_inv = _req(E_inv, torch.float32, d, "E_inv")
         self._ar_B = cond_ids.shape[0]
-        self._check(self.lib.bevgen_ar_prefill(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), self._ar_B, _stream()))
+        self._check(self.lib.bevgen_ar_prefill(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), self._ar_B, self._s()))
 
     def ar_logits(self):
         out = torch.empty((self._ar_B, self.cfg.vocab_size), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_ar_logits(self._h, _ptr(out), _stream()))
+        self._check(self.lib.bevgen_ar_logits(self._h, _ptr(out), self._s()))
         return out
 
     def ar_decode_step(self, token):
         token = _req(token, torch.int64, self.device, "token")
-        self._check(self.lib.bevgen_ar_decode_step(self._h, _ptr(token), _stream()))
+        self._check(self.lib.bevgen_ar_decode_step(self._h, _ptr(token), self._s()))
 
     def ar_sample(self, cond_ids, I_inv, E_inv, *, steps=None, top_k=None, temperature=1.0, greedy=True, noise_u=None, samples_per_layout=1, return_logits=False,
                   forced_ids=None):
@@ -245,7 +249,7 @@ class Context:
             forced_ids = _req(forced_ids, torch.int64, d, "forced_ids")
             assert tuple(forced_ids.shape) == (steps, B)
         self._check(self.lib.bevgen_ar_sample_forced(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, steps, int(top_k or 0), float(temperature), int(bool(greedy)),
-                                                      _ptr(noise_u), int(samples_per_layout), _ptr(forced_ids), _ptr(out), _ptr(logits), _stream()))
+                                                      _ptr(noise_u), int(samples_per_layout), _ptr(forced_ids), _ptr(out), _ptr(logits), self._s()))
         return (out, logits) if return_logits else out
 
     # ------------------------------------------------------------------------------------------ stage 1
@@ -272,7 +276,7 @@ class Context:
         f = 1 << self._vq_levels()
         mode = _lib.VQ_OUT_U8 if uint8 else (_lib.VQ_OUT_DENORM if denormalize else _lib.VQ_OUT_RAW)
         out = torch.empty((n, dd["out_ch"], lh * f, lw * f), dtype=torch.uint8 if uint8 else torch.float32, device=self.device)
-        self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids), n, lh, lw, mode, _ptr(out), _stream()))
+        self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids), n, lh, lw, mode, _ptr(out), self._s()))
         return out
 
     def vq_encode(self, x):
@@ -284,7 +288,7 @@ class Context:
         if ch != dd["in_channels"] or H % f or W % f:
             raise ValueError(f"vq_encode: input {tuple(x.shape)} needs {dd['in_channels']} channels and sides divisible by {f}")
         ids = torch.empty((n, (H // f) * (W // f)), dtype=torch.int64, device=self.device)
-        self._check(self.lib.bevgen_vq_encode(self._h, _ptr(x), n, H, W, _ptr(ids), _stream()))
+        self._check(self.lib.bevgen_vq_encode(self._h, _ptr(x), n, H, W, _ptr(ids), self._s()))
         return ids
 
     def vq_decode_latents(self, zq, denormalize=False):
@@ -294,7 +298,7 @@ class Context:
         n, _, lh, lw = zq.shape
         f = 1 << self._vq_levels()
         out = torch.empty((n, dd["out_ch"], lh * f, lw * f), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_vq_decode_latents(self._h, _ptr(zq), n, lh, lw, _lib.VQ_OUT_DENORM if denormalize else _lib.VQ_OUT_RAW, _ptr(out), _stream()))
+        self._check(self.lib.bevgen_vq_decode_latents(self._h, _ptr(zq), n, lh, lw, _lib.VQ_OUT_DENORM if denormalize else _lib.VQ_OUT_RAW, _ptr(out), self._s()))
         return out
 
     # ------------------------------------------------------------------------------------------ per-kernel HIP-event timing
@@ -334,7 +338,7 @@ class Context:
         M, K = a.shape
         N = w.shape[0]
         c = torch.empty((M, N), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_op_gemm(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(c), M, N, K, int(gelu), int(skinny), _stream()))
+        self._check(self.lib.bevgen_op_gemm(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(c), M, N, K, int(gelu), int(skinny), self._s()))
         return c
 
     def op_ln_gemm(self, a, w, ln_w=None, ln_b=None, bias=None, gelu=False, ksplit=0, eps=1e-5):
@@ -345,12 +349,12 @@ class Context:
         ks = C.c_int(0)
         out = torch.empty((4, M, N), dtype=torch.float32, device=self.device)
         self._check(self.lib.bevgen_op_ln_gemm(self._h, _ptr(a), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(w), _ptr(bias), _ptr(out), M, N, K, int(gelu), int(ksplit),
-                                               C.byref(ks), _stream()))
+                                               C.byref(ks), self._s()))
         return out[0] if ks.value == 1 else out[:ks.value].sum(0)
 
     def op_layernorm(self, x, gamma, beta=None, eps=1e-5):
         y = torch.empty_like(x)
-        self._check(self.lib.bevgen_op_layernorm(self._h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), x.shape[0], x.shape[1], float(eps), _stream()))
+        self._check(self.lib.bevgen_op_layernorm(self._h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), x.shape[0], x.shape[1], float(eps), self._s()))
         return y
 
     def op_geglu_layernorm(self, h, gamma, ldy=None):
@@ -358,7 +362,7 @@ class Context:
         F = two_f // 2
         ldy = ldy or F
         y = torch.empty((rows, ldy), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_op_geglu_layernorm(self._h, _ptr(h), _ptr(gamma), _ptr(y), rows, F, ldy, _stream()))
+        self._check(self.lib.bevgen_op_geglu_layernorm(self._h, _ptr(h), _ptr(gamma), _ptr(y), rows, F, ldy, self._s()))
         return y
 
     def op_attention(self, q, k, v, bias, scale):
@@ -366,7 +370,7 @@ class Context:
         Nk_pad = k.shape[2]
         out = torch.empty((B, Nq, H * 64), dtype=torch.float32, device=self.device)
         ld = 0 if bias is None else bias.shape[-1]
-        self._check(self.lib.bevgen_op_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(bias), ld, B, H, Nq, Nk_pad, float(scale), _ptr(out), _stream()))
+        self._check(self.lib.bevgen_op_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(bias), ld, B, H, Nq, Nk_pad, float(scale), _ptr(out), self._s()))
         return out
 
     def op_decode_attention(self, q, kcache, vcache, n, bias=None, keep=None, scale=0.125, kv_dtype=0):
@@ -378,7 +382,7 @@ class Context:
         ldk = 0 if keep is None else keep.shape[-1]
         khs = 0 if keep is None or keep.dim() < 3 or keep.shape[0] == 1 else keep.shape[1] * keep.shape[2]
         self._check(self.lib.bevgen_op_decode_attention(self._h, _ptr(q), _ptr(kcache), _ptr(vcache), int(kv_dtype), _ptr(bias), ldb, _ptr(keep), ldk, khs,
-                                                         B, H, int(n), Lmax, float(scale), _ptr(out), _stream()))
+                                                         B, H, int(n), Lmax, float(scale), _ptr(out), self._s()))
         return out
 
     def op_conv3x3(self, x_nhwc, w_ohwi, bias, residual=None, upsample=False):
@@ -386,11 +390,11 @@ class Context:
         Cout = w_ohwi.shape[0]
         oh, ow = (2 * H, 2 * W) if upsample else (H, W)
         y = torch.empty((n, oh, ow, Cout), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_op_conv3x3(self._h, _ptr(x_nhwc), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(y), n, H, W, Cin, Cout, int(upsample), _stream()))
+        self._check(self.lib.bevgen_op_conv3x3(self._h, _ptr(x_nhwc), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(y), n, H, W, Cin, Cout, int(upsample), self._s()))
         return y
 
     def op_groupnorm(self, x_nhwc, gamma, beta, swish=True):
         n, H, W, Cc = x_nhwc.shape
         y = torch.empty_like(x_nhwc)
-        self._check(self.lib.bevgen_op_groupnorm(self._h, _ptr(x_nhwc), _ptr(gamma), _ptr(beta), _ptr(y), n, H * W, Cc, int(swish), _stream()))
+        self._check(self.lib.bevgen_op_groupnorm(self._h, _ptr(x_nhwc), _ptr(gamma), _ptr(beta), _ptr(y), n, H * W, Cc, int(swish), self._s()))
         return y
