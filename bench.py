@@ -213,7 +213,7 @@ def cpu_baseline(cams, timesteps, mode):
 
 
 # ----------------------------------------------------------------------------------------------------------------- Route A legs
-def route_a_bytes(cfg, B, steps, kv_bytes, G=1):
+def route_a_bytes(cfg, B, steps, kv_bytes, G=1, w_bytes_per=4):
     """Algorithmic HBM bytes of a decode run: K and V rows of the context once per (sequence, head, layer) - the shared condition prefix once
     per group - and every weight matrix once per step."""
     H, D, K, Lyr, V = cfg.num_heads, cfg.num_embed, cfg.num_cond_tokens, cfg.num_layers, cfg.vocab_size
@@ -221,11 +221,11 @@ def route_a_bytes(cfg, B, steps, kv_bytes, G=1):
     for s in range(steps):
         n = K + s + 1
         kv += 2.0 * H * 64 * kv_bytes * Lyr * (B * (n - (K if G > 1 else 0)) + (B // G) * (K if G > 1 else 0))
-    w = steps * 4.0 * (Lyr * (3 * D * D + 8 * D * D) + V * D)
+    w = steps * float(w_bytes_per) * (Lyr * (3 * D * D + 8 * D * D) + V * D)
     return kv, w
 
 
-def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic=False):
+def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic=False, weights="f32"):
     """Route A (BASELINE config 4: nuScenes 6-view 224x400, 24 layers, L=2368, blk 16, camera bias): decode of `steps` tokens for `batch` sequences through
     the product path (hipGraph replay of the fused decode step).  S > 1 = BASELINE config 5: groups of S samples share their BEV layout."""
     import torch
@@ -234,7 +234,7 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     from bevgen_amd.weights import gpt_state_dict
 
     cfg = presets.config4()
-    ctx = Context(cfg, route="ar", device=device, max_batch=batch, kv_cache=kv_cache)
+    ctx = Context(cfg, route="ar", device=device, max_batch=batch, kv_cache=kv_cache, decode_weights=weights)
     ctx.load_state_dict(gpt_state_dict(cfg, 1234))
     ctx.set_tables()
     ctx.finalize()
@@ -281,7 +281,7 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     ctx.close()
     da, gs = prof["decode_attention"], prof["gemm_skinny"]
     ach = da["work"] / (da["ms"] * 1e-3) / 1e9 if da["ms"] > 0 else 0.0
-    kv_bytes, w_bytes = route_a_bytes(cfg, batch, steps, kvb, S)
+    kv_bytes, w_bytes = route_a_bytes(cfg, batch, steps, kvb, S, 2 if weights == "f16" else 4)
     step_ach = (kv_bytes + w_bytes) / wall / 1e9
     out = {
         "ms_per_decode_step": wall * 1e3 / steps, "ms_per_decode_step_median": pct(st, 50), "ms_per_decode_step_p99": pct(st, 99), "decode_prefill_ms": prefill_ms,
@@ -290,9 +290,9 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
                                       "attention_phase": {"GBs": phase_bytes / (phase_us * 1e-6) / 1e9 if phase_us else None, "frac": phase_bytes / (phase_us * 1e-6) / 1e9 / HBM_PEAK_GBS if phase_us else None,
                                                           "us": phase_us, "context": n_last, "note": "K/V streaming phase alone, device timestamps of one launch"},
                                       "launches": int(da["launches"]), "avg_us": da["ms"] * 1e3 / max(da["launches"], 1),
-                                      "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of the decode, {kv_cache} KV cache, L=2368" + (f", {S} samples per layout (shared prefix read once per group)" if S > 1 else "")},
+                                      "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of the decode, {kv_cache} KV cache, {weights} projection weights, L=2368" + (f", {S} samples per layout (shared prefix read once per group)" if S > 1 else "")},
         "decode_step_roofline": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_ach / HBM_PEAK_GBS,
-                                 "bytes_per_step": {"kv": kv_bytes / steps, "weights": w_bytes / steps}, "note": "(K/V rows of the context + every fp32 weight matrix once) per step / wall time per step"},
+                                 "bytes_per_step": {"kv": kv_bytes / steps, "weights": w_bytes / steps}, "note": f"(K/V rows of the context + every {weights} weight matrix once) per step / wall time per step"},
         "decode_sequences_per_s": batch / wall, "decode_scenes_per_s": batch / wall,
         "decode_weight_stream": {"achieved_GBs": gs["work"] / (gs["ms"] * 1e-3) / 1e9 if gs["ms"] > 0 else 0.0, "launches": int(gs["launches"])},
     }
@@ -423,6 +423,9 @@ def main():
         # BASELINE config 4 names fp16 storage: the same decode with the KV cache stored as fp16 (fp32 accumulate; logits within 2e-3 of the range, tests)
         f16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16")
         line["decode_f16_kv_cache"] = {k: f16[k] for k in ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline")}
+        # ... and the all-fp16-storage model (projection weights rounded to fp16 at load, tokens bit-exact vs the oracle on the rounded weights; fp32 arithmetic)
+        h16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16")
+        line["decode_f16_kv_cache_f16_weights"] = {k: h16[k] for k in ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline")}
         if not args.no_extra_legs:
             c5 = decode_leg(local_rank, 64, args.decode_steps, kv_cache="f32", S=4, top_k=32, stochastic=True)
             line["config5_topk32_4_samples_per_layout"] = {"sequences": 64, "layouts": 16, "ms_per_decode_step": c5["ms_per_decode_step"], "ms_per_decode_step_median": c5["ms_per_decode_step_median"],

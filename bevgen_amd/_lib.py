@@ -19,6 +19,7 @@ PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
 DECODE_FUSED, DECODE_PER_OP = 0, 1
 VQ_OUT_RAW, VQ_OUT_DENORM, VQ_OUT_U8 = 0, 1, 2
+W_F32, W_F16 = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_F64 = 0, 1, 2, 3
 
 
@@ -38,7 +39,7 @@ class bevgen_cfg(C.Structure):
         ("ff_inner", C.c_int32), ("max_batch", C.c_int32),
         ("vq_ch", C.c_int32), ("vq_num_res_blocks", C.c_int32), ("vq_z_channels", C.c_int32), ("vq_embed_dim", C.c_int32),
         ("vq_n_embed", C.c_int32), ("vq_resolution", C.c_int32), ("vq_out_ch", C.c_int32), ("vq_num_levels", C.c_int32),
-        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("vq_in_channels", C.c_int32), ("kv_cache_dtype", C.c_int32), ("decode_path", C.c_int32), ("reserved", C.c_int32 * 13),
+        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("vq_in_channels", C.c_int32), ("kv_cache_dtype", C.c_int32), ("decode_path", C.c_int32), ("decode_weight_dtype", C.c_int32), ("reserved", C.c_int32 * 12),
     ]
 
 

@@ -241,7 +241,7 @@ static void head_logits(Ctx& c, StepWs& w, int B, float* logits, hipStream_t s) 
         SkinnyFusedArgs g;
         g.A = st.hidden; g.lda = c.D;
         g.ln_w = c.pf("ln_f.weight"); g.ln_b = c.pf("ln_f.bias"); g.eps = 1e-5f;
-        g.Wp = c.head_wp;
+        g.Wp = c.head_wp; g.w_f16 = c.cfg.decode_weight_dtype == BEVGEN_W_F16;
         g.C = logits; g.ldc = c.V;
         g.M = B; g.N = c.V; g.K = c.D; g.ksplit = 1;
         launch_skinny_fused(g, s);
@@ -268,6 +268,7 @@ static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipS
     launch_ar_step_embed(tok, c.pf("x_tok_emb.weight"), st.img_embed, c.pf("x_pos_emb"), c.fwd_idx, st.d_step, w.x, B, g.num_cams, c.T, D, g.vocab_size + 1, s);
     const size_t layer_bytes = (size_t)B * H * L * 64 * cache_elem_bytes(c);
     const int ks = skinny_fused_ksplit(D, 4 * D);
+    const int wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
     RowSrc src;
     src.base = w.x; src.ld = D;
     for (int i = 0; i < g.num_layers; ++i) {
@@ -276,7 +277,7 @@ static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipS
         ArAttnFusedArgs a;
         a.x = src;
         a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;
-        a.wqkv = l.wqkv; a.bqkv = l.bqkv;
+        a.wqkv = l.wqkv; a.bqkv = l.bqkv; a.wqkv_h = l.wqkv_h;
         a.kcache = reinterpret_cast<char*>(st.kcache) + i * layer_bytes;
         a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes;
         a.kv_dtype = cache_dtype(c);
@@ -291,14 +292,14 @@ static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipS
         SkinnyFusedArgs up;
         up.A = x2; up.lda = D;
         up.ln_w = l.ln2_w; up.ln_b = l.ln2_b; up.eps = 1e-5f;
-        up.Wp = l.mlp0_wp; up.bias = l.mlp0_b;
+        up.Wp = l.mlp0_wp; up.w_f16 = wf16; up.bias = l.mlp0_b;
         up.C = w.m1; up.ldc = 4 * D;
         up.M = B; up.N = 4 * D; up.K = D; up.ksplit = 1; up.act = ACT_GELU;
         up.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
         launch_skinny_fused(up, s);
         SkinnyFusedArgs dn;
         dn.A = w.m1; dn.lda = 4 * D;
-        dn.Wp = l.mlp2_wp;
+        dn.Wp = l.mlp2_wp; dn.w_f16 = wf16;
         dn.M = B; dn.N = D; dn.K = 4 * D; dn.ksplit = ks;
         dn.trace = c.trace ? c.trace + 2 * 4096 * 8 : nullptr;
         if (ks > 1) {

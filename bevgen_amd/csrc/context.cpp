@@ -209,6 +209,8 @@ static void finalize_ar(Ctx& c) {
     expect_shape(c, "x_pos_emb", {1, c.N, D});
     expect_shape(c, "cond_pos_emb", {1, c.K, D});
     expect_shape(c, "head.weight", {g.vocab_size, D});
+    const bool wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
+    BG_REQUIRE(!wf16 || (g.decode_path == BEVGEN_DECODE_FUSED && D % 256 == 0), "decode_weights = f16 needs the fused decode path and dim %% 256 == 0 (dim = %d)", D);
     c.ar.resize(g.num_layers);
     for (int i = 0; i < g.num_layers; ++i) {
         ArLayer& l = c.ar[i];
@@ -224,19 +226,33 @@ static void finalize_ar(Ctx& c) {
         l.bqkv = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
         launch_fuse_qkv(c.pf(q + "attention.query.weight"), c.pf(q + "attention.key.weight"), c.pf(q + "attention.value.weight"),
                         c.pf(q + "attention.query.bias"), c.pf(q + "attention.key.bias"), c.pf(q + "attention.value.bias"), l.wqkv, l.bqkv, D, 0);
+        if (wf16) {   // the model becomes the one whose projection weights are fp16-representable: every consumer below sees the rounded values
+            l.wqkv_h = c.own((size_t)3 * D * D * sizeof(_Float16));
+            launch_round_to_f16(l.wqkv, l.wqkv_h, 3L * D * D, 0);
+            launch_round_to_f16(const_cast<float*>(l.mlp0_w), nullptr, 4L * D * D, 0);
+            launch_round_to_f16(const_cast<float*>(l.mlp2_w), nullptr, 4L * D * D, 0);
+        }
         if (c.cfg.decode_path == BEVGEN_DECODE_FUSED) {
-            l.mlp0_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(4 * D, D) * sizeof(float)));
-            l.mlp2_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(D, 4 * D) * sizeof(float)));
-            launch_pack_skinny_weight(l.mlp0_w, l.mlp0_wp, 4 * D, D, 0);
-            launch_pack_skinny_weight(l.mlp2_w, l.mlp2_wp, D, 4 * D, 0);
+            const size_t eb = wf16 ? sizeof(_Float16) : sizeof(float);
+            l.mlp0_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(4 * D, D) * eb));
+            l.mlp2_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(D, 4 * D) * eb));
+            if (wf16) {
+                launch_pack_skinny_weight_f16(l.mlp0_w, l.mlp0_wp, 4 * D, D, 0);
+                launch_pack_skinny_weight_f16(l.mlp2_w, l.mlp2_wp, D, 4 * D, 0);
+            } else {
+                launch_pack_skinny_weight(l.mlp0_w, l.mlp0_wp, 4 * D, D, 0);
+                launch_pack_skinny_weight(l.mlp2_w, l.mlp2_wp, D, 4 * D, 0);
+            }
         }
         c.split_weight(l.wqkv, 3L * D * D);      // used by the prefill GEMMs (the per-token decode GEMMs stream the fp32 weights)
         c.split_weight(l.mlp0_w, 4L * D * D);
         c.split_weight(l.mlp2_w, 4L * D * D);
     }
+    if (wf16) launch_round_to_f16(const_cast<float*>(c.pf("head.weight")), nullptr, (long)g.vocab_size * D, 0);
     if (c.cfg.decode_path == BEVGEN_DECODE_FUSED) {
-        c.head_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(g.vocab_size, D) * sizeof(float)));
-        launch_pack_skinny_weight(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);
+        c.head_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(g.vocab_size, D) * (wf16 ? sizeof(_Float16) : sizeof(float))));
+        if (wf16) launch_pack_skinny_weight_f16(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);
+        else launch_pack_skinny_weight(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);
     }
     // visibility mask: allowed AND layout block present.  The reference keeps one layout buffer PER LAYER in the checkpoint
     // (blocks.{i}.attention.sparse_self_attention.master_layout, drawn at construction when density < 1: mingpt_sparse.py:176, mask_generator.py:217-228);

@@ -17,6 +17,8 @@
 //
 // Shared condition prefix (BASELINE config 5, several samples per BEV layout): a workgroup serves the G sequences of one layout
 // and one head; the K prefix rows are streamed ONCE and scored against the G queries, the private suffixes are split over wave teams.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 #include "profiler.h"
@@ -190,7 +192,7 @@ __device__ __forceinline__ void wave_merge(float& m, float& l, float (&acc)[DPL]
 
 // ----------------------------------------------------------------------------------------------------------------- ln1 + qkv + attention
 // grid (H, B / G), 1024 threads.  Dynamic LDS: bias row [Lpad] | xn [G][D] | qkv [G][192] | red [16][G+1][66] | stat [16][G]
-template <int DT, int G>
+template <int DT, int G, int WT>   // KV-cache storage (0 fp32, 1 fp16), sequences per workgroup, decode-weight storage (0 fp32, 1 fp16)
 __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) {
     using T = KvRow<DT>;
     constexpr int LPK = T::LPK, DPL = T::DPL, KPI = 64 / LPK, NW = AF_WAVES, TW = NW / G;
@@ -225,17 +227,24 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     // q/k/v projection: wave w owns rows j = 12 w .. 12 w + 11 of the head's 192 (q | k | v) x 64 rows, fetched RB rows at a time into two register
     // buffers.  The 16 workgroups of a head (one per sequence, same XCD) read the same rows through that XCD's L2: each starts at a different batch
     // so that at any moment they pull on different lines / channels instead of queueing on one.
-    constexpr int RB = G == 1 ? 3 : 2, NB = 12 / RB;
+    // fp16 weight storage: 8 elements per 16-byte load, twice the rows per batch for the same registers
+    constexpr int EL = WT ? 8 : 4, NCH = WT ? 2 : 4;                 // elements per lane and load; loads per row (D <= 1024)
+    constexpr int RB = (G == 1 ? 3 : 2) * (WT ? 2 : 1), NB = 12 / RB;
+    typedef typename std::conditional<WT == 1, half8_t, f32x4>::type WV;
     const int rot = grp % NB;
     auto wrow = [&](int bi, int r) { return wave * 12 + ((bi + rot) % NB) * RB + r; };
-    auto wptr = [&](int j) { return a.wqkv + ((long)(j >> 6) * D + head * 64 + (j & 63)) * D; };
-    float4 wb[2][RB][4];
-    auto load_batch = [&](int bi, float4 (&w)[RB][4]) {
+    auto wbase = [&](int j) { return ((long)(j >> 6) * D + head * 64 + (j & 63)) * D; };
+    WV wb[2][RB][NCH];
+    auto load_batch = [&](int bi, WV (&w)[RB][NCH]) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const float* p = wptr(wrow(bi, r));
+            const long o = wbase(wrow(bi, r));
 #pragma unroll
-            for (int c = 0; c < 4; ++c) w[r][c] = *reinterpret_cast<const float4*>(p + min(c * 256 + lane * 4, D - 4));   // columns >= D: ignored by dot_batch
+            for (int c = 0; c < NCH; ++c) {   // columns >= D: a clamped (valid) address, ignored by dot_batch
+                const long e = o + min(c * 64 * EL + lane * EL, D - EL);
+                if (WT) w[r][c] = *reinterpret_cast<const WV*>(reinterpret_cast<const _Float16*>(a.wqkv_h) + e);
+                else w[r][c] = *reinterpret_cast<const WV*>(a.wqkv + e);
+            }
         }
     };
     // bias row of this step with the visibility mask folded in (shared by every sequence and head of the step): through registers, stored after ln1
@@ -308,23 +317,26 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     AF_TRACE(1);
     // ---- q/k/v projection of this head
     {
-        auto dot_batch = [&](int bi, const float4 (&w)[RB][4]) {
+        auto dot_batch = [&](int bi, const WV (&w)[RB][NCH]) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 float accp[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) accp[g] = 0.f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int col = c * 256 + lane * 4;
+                for (int c = 0; c < NCH; ++c) {
+                    const int col = c * 64 * EL + lane * EL;
                     if (col < D) {
 #pragma unroll
                         for (int g = 0; g < G; ++g) {
-                            const float4 x4 = *reinterpret_cast<const float4*>(xn_s + g * D + col);
-                            accp[g] = fmaf(w[r][c].x, x4.x, accp[g]);
-                            accp[g] = fmaf(w[r][c].y, x4.y, accp[g]);
-                            accp[g] = fmaf(w[r][c].z, x4.z, accp[g]);
-                            accp[g] = fmaf(w[r][c].w, x4.w, accp[g]);
+#pragma unroll
+                            for (int e4 = 0; e4 < EL; e4 += 4) {
+                                const float4 x4 = *reinterpret_cast<const float4*>(xn_s + g * D + col + e4);
+                                accp[g] = fmaf((float)w[r][c][e4 + 0], x4.x, accp[g]);
+                                accp[g] = fmaf((float)w[r][c][e4 + 1], x4.y, accp[g]);
+                                accp[g] = fmaf((float)w[r][c][e4 + 2], x4.z, accp[g]);
+                                accp[g] = fmaf((float)w[r][c][e4 + 3], x4.w, accp[g]);
+                            }
                         }
                     }
                 }
@@ -339,10 +351,10 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         };
 #pragma unroll
         for (int bi = 0; bi < NB; bi += 2) {
-            load_batch(bi + 1, wb[1]);
+            if (bi + 1 < NB) load_batch(bi + 1, wb[1]);
             dot_batch(bi, wb[0]);
             if (bi + 2 < NB) load_batch(bi + 2, wb[0]);
-            dot_batch(bi + 1, wb[1]);
+            if (bi + 1 < NB) dot_batch(bi + 1, wb[1]);
         }
     }
     __syncthreads();
@@ -470,12 +482,15 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     const double eb = a.kv_dtype == 0 ? 4 : 2;
     const double pre = a.G > 1 ? (double)a.prefix : 0.0;
     ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pre) + (double)(a.B / a.G) * pre), s);
-#define AF_LAUNCH(DT, GG) hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG>), grid, dim3(1024), lds, s, a)
-    if (a.kv_dtype == 0) {
-        if (a.G == 1) AF_LAUNCH(0, 1); else if (a.G == 2) AF_LAUNCH(0, 2); else AF_LAUNCH(0, 4);
+#define AF_LAUNCH(DT, GG, WW) hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG, WW>), grid, dim3(1024), lds, s, a)
+#define AF_LAUNCH_G(DT, WW) do { if (a.G == 1) AF_LAUNCH(DT, 1, WW); else if (a.G == 2) AF_LAUNCH(DT, 2, WW); else AF_LAUNCH(DT, 4, WW); } while (0)
+    if (a.wqkv_h) {
+        BG_REQUIRE(a.D % 8 == 0, "fused decode attention: fp16 weights need D %% 8 == 0");
+        if (a.kv_dtype == 0) AF_LAUNCH_G(0, 1); else AF_LAUNCH_G(1, 1);
     } else {
-        if (a.G == 1) AF_LAUNCH(1, 1); else if (a.G == 2) AF_LAUNCH(1, 2); else AF_LAUNCH(1, 4);
+        if (a.kv_dtype == 0) AF_LAUNCH_G(0, 0); else AF_LAUNCH_G(1, 0);
     }
+#undef AF_LAUNCH_G
 #undef AF_LAUNCH
     LAUNCH_CHECK();
 }
@@ -494,7 +509,7 @@ __device__ __forceinline__ float4 ldg_nt4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <bool LN>
+template <bool LN, int WT>   // WT: weight storage of the packed image, 0 fp32 ([K/16][64 lanes][4]), 1 fp16 ([K/32][64 lanes][8])
 __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFusedArgs g) {
     __shared__ float4 As[256 * 16];
     __shared__ float red[SF_WAVES][4][64];
@@ -528,8 +543,14 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
             bt[j] = *reinterpret_cast<const float4*>(g.ln_b + 4 * c);   // launcher: a missing beta aliases gamma, has_ln_b = 0
         }
     }
-    float4 wv[8];
-    {
+    float4 wv[WT ? 1 : 8];
+    half8_t wh[WT ? 4 : 1];
+    if (WT) {
+        // fp16 image: one wave load = 1 KiB = a 32-wide k-chunk of the 16 columns; lane (r, q) holds W[16 tile + r][32 chunk + 8 q .. + 7]
+        const _Float16* wp = reinterpret_cast<const _Float16*>(g.Wp) + (((long)blockIdx.x * (g.K >> 5) + ((kbase + wave * kper) >> 5)) * 64 + lane) * 8;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wh[u] = __builtin_nontemporal_load(reinterpret_cast<const half8_t*>(wp + (long)min(u, (kper >> 5) - 1) * 512));
+    } else {
         // packed layout (launch_pack_skinny_weight): one wave load = 1 KiB contiguous, the 8 loads of a wave 8 KiB, the workgroup's slice 64 KiB
         const float* wp = g.Wp + (((long)blockIdx.x * (g.K >> 4) + ((kbase + wave * kper) >> 4)) * 64 + lane) * 4;
 #pragma unroll
@@ -583,14 +604,32 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
         SF_TRACE(1);
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (WT) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (16 * u < kper) {
-                const float4 a4 = As[(((wave * kper + 16 * u) >> 2) + q) * 16 + r];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv[u].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv[u].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv[u].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv[u].w, acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                if (32 * u < kper) {   // quarter q owns k = 32 c + 8 q .. + 7 of the chunk: two A float4 (chunks of 4 k), eight MFMAs
+                    const int c4 = ((wave * kper + 32 * u) >> 2) + 2 * q;
+                    const float4 a0 = As[c4 * 16 + r], a1 = As[(c4 + 1) * 16 + r];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, (float)wh[u][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, (float)wh[u][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, (float)wh[u][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, (float)wh[u][3], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, (float)wh[u][4], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, (float)wh[u][5], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, (float)wh[u][6], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, (float)wh[u][7], acc, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (16 * u < kper) {
+                    const float4 a4 = As[(((wave * kper + 16 * u) >> 2) + q) * 16 + r];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv[u].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv[u].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv[u].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv[u].w, acc, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -635,6 +674,27 @@ __global__ __launch_bounds__(256) void pack_skinny_weight_kernel(const float* __
     if (n < N) v = *reinterpret_cast<const float4*>(W + (long)n * K + k);
     reinterpret_cast<float4*>(Wp)[i] = v;
 }
+// fp16 image: [N/16 column tiles][K/32 k-chunks][64 lanes][8 halves]; lane l = r + 16 q holds W[16 tile + r][32 chunk + 8 q .. + 7] rounded to fp16
+__global__ __launch_bounds__(256) void pack_skinny_weight_f16_kernel(const float* __restrict__ W, _Float16* __restrict__ Wp, int N, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-half group of the packed image
+    const long total = (long)((N + 15) / 16) * (K >> 5) * 64;
+    if (i >= total) return;
+    const int l = (int)(i & 63);
+    const long ck = i >> 6;
+    const int kc = (int)(ck % (K >> 5));
+    const int tile = (int)(ck / (K >> 5));
+    const int n = tile * 16 + (l & 15), k = kc * 32 + 8 * (l >> 4);
+    half8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = n < N ? (_Float16)W[(long)n * K + k + e] : (_Float16)0.f;
+    reinterpret_cast<half8_t*>(Wp)[i] = v;
+}
+void launch_pack_skinny_weight_f16(const float* W, void* Wp, int N, int K, hipStream_t s) {
+    BG_REQUIRE(K % 32 == 0, "pack_skinny_weight_f16: K=%d must be a multiple of 32", K);
+    const long total = (long)cdiv(N, 16) * (K >> 5) * 64;
+    hipLaunchKernelGGL(pack_skinny_weight_f16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, W, reinterpret_cast<_Float16*>(Wp), N, K);
+    LAUNCH_CHECK();
+}
 size_t skinny_packed_floats(int N, int K) { return (size_t)cdiv(N, 16) * 16 * K; }
 void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStream_t s) {
     BG_REQUIRE(K % 16 == 0, "pack_skinny_weight: K=%d must be a multiple of 16", K);
@@ -670,9 +730,15 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     BG_REQUIRE(g.ksplit <= ROWSRC_MAX_SPLITS, "skinny_fused: at most %d K splits", ROWSRC_MAX_SPLITS);
     BG_REQUIRE(g.lda % 4 == 0 && g.Wp, "skinny_fused: A stride must be a multiple of 4, weights packed");
     dim3 grid(cdiv(g.N, 16), g.ksplit);
-    ProfScope prof(PROF_GEMM_SKINNY, ((double)g.N * g.K + (double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);
-    if (ln) hipLaunchKernelGGL(skinny_fused_kernel<true>, grid, dim3(SF_WAVES * 64), 0, s, g);
-    else hipLaunchKernelGGL(skinny_fused_kernel<false>, grid, dim3(SF_WAVES * 64), 0, s, g);
+    ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);   // work = algorithmic bytes
+    if (g.w_f16) {
+        BG_REQUIRE((g.K / g.ksplit) % (SF_WAVES * 32) == 0, "skinny_fused: fp16 weights need a K slice that is a multiple of %d (K=%d, ksplit=%d)", SF_WAVES * 32, g.K, g.ksplit);
+        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        else hipLaunchKernelGGL((skinny_fused_kernel<false, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
+    } else {
+        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        else hipLaunchKernelGGL((skinny_fused_kernel<false, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
+    }
     LAUNCH_CHECK();
 }
 

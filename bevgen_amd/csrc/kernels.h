@@ -160,6 +160,7 @@ struct ArAttnFusedArgs {
     RowSrc x;                          // rows entering the layer (before ln1), [B, D]
     const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;
     const float* wqkv = nullptr;       // fused [3D, D] (q | k | v), bqkv [3D]
+    const void* wqkv_h = nullptr;      // non-null: the same matrix stored as fp16 (decode_weights = f16), read instead of wqkv
     const float* bqkv = nullptr;
     void* kcache = nullptr;            // this layer's [B, H, Lmax, 64]
     void* vcache = nullptr;
@@ -180,7 +181,8 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a, hipStream_t s);
 struct SkinnyFusedArgs {
     const float* A = nullptr; int lda = 0;   // [M, K]
     const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;   // ln_w != null: LayerNorm over K fused in front of the product
-    const float* Wp = nullptr;               // [N, K] weights in the packed operand layout (launch_pack_skinny_weight)
+    const float* Wp = nullptr;               // [N, K] weights in the packed operand layout (launch_pack_skinny_weight / _f16)
+    int w_f16 = 0;                           // the packed image holds fp16 values
     const float* bias = nullptr;       // [N] (ksplit == 1 only)
     float* C = nullptr; int ldc = 0;   // [M, N], or the partial sums [ksplit][M][N] when ksplit > 1
     int M = 0, N = 0, K = 0, ksplit = 0 /* 0 = skinny_fused_ksplit(N, K) */, act = 0;
@@ -189,6 +191,7 @@ struct SkinnyFusedArgs {
 };
 size_t skinny_packed_floats(int N, int K);
 void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStream_t s);
+void launch_pack_skinny_weight_f16(const float* W, void* Wp /* N16 * K halves */, int N, int K, hipStream_t s);
 int skinny_fused_ksplit(int N, int K);
 bool skinny_fused_supported(int M, int N, int K, bool ln);
 void launch_skinny_fused(const SkinnyFusedArgs& g, hipStream_t s);

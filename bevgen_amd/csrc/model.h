@@ -43,7 +43,8 @@ struct ArLayer {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     float *wqkv, *bqkv;  // fused [3D, D], [3D], owned
     const float *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
-    float *mlp0_wp = nullptr, *mlp2_wp = nullptr;   // decode-step operand images of the MLP weights (owned; fused decode path)
+    float *mlp0_wp = nullptr, *mlp2_wp = nullptr;   // decode-step operand images of the MLP weights (owned; fused decode path; fp32 or fp16 packed)
+    void* wqkv_h = nullptr;                          // decode_weights = f16: fp16 copy of the fused QKV weight [3D, D]
 };
 
 struct ConvW { float* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 0; };  // w re-laid [Cout][kh][kw][Cin] (owned)
@@ -182,6 +183,7 @@ void launch_store_tokens(const int64_t* tok, const int64_t* fwd_idx, const int* 
 void launch_gather_rows(const float* x, float* out, int B, int row, int rows_per_batch, int D, hipStream_t s);
 void launch_replicate_prefix(void* kc, void* vc, int layers, int B, int H, int L, int rows, int src, int dst0, int count, int elem_bytes, hipStream_t s);
 void launch_increment(int* p, hipStream_t s);
+void launch_round_to_f16(float* w /* rounded in place */, void* h /* fp16 copy or null */, long n, hipStream_t s);
 void launch_relayout_conv_weight(const float* w_oihw, float* w_ohwi, int cout, int cin, int kh, int kw, hipStream_t s);
 void launch_fuse_qkv(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, float* w, float* b, int D, hipStream_t s);
 void launch_pad_rows(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t s);

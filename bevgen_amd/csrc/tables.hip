@@ -128,6 +128,20 @@ void launch_replicate_prefix(void* kc, void* vc, int layers, int B, int H, int L
     LAUNCH_CHECK();
 }
 
+// decode_weights = f16: the matrix is replaced by its fp16-representable rounding (so that every consumer - prefill GEMMs, split planes, decode kernels - sees
+// the same values) and a packed fp16 copy is written for the kernels that stream it
+__global__ void round_to_f16_kernel(float* __restrict__ w, _Float16* __restrict__ h, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const _Float16 v = (_Float16)w[i];
+        w[i] = (float)v;
+        if (h) h[i] = v;
+    }
+}
+void launch_round_to_f16(float* w, void* h, long n, hipStream_t s) {
+    hipLaunchKernelGGL(round_to_f16_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(h), n);
+    LAUNCH_CHECK();
+}
+
 __global__ void increment_kernel(int* p) { *p += 1; }
 void launch_increment(int* p, hipStream_t s) {
     hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(1), 0, s, p);

@@ -52,7 +52,7 @@ class Context:
     """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
-                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "fused"):
+                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "fused", decode_weights: str = "f32"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bevgen_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product")
@@ -75,6 +75,10 @@ class Context:
         # Route A decode step: 'fused' (three launches per layer) or 'per_op' (one kernel per operator, the A/B reference)
         c.decode_path = {"fused": _lib.DECODE_FUSED, "per_op": _lib.DECODE_PER_OP}[decode_path]
         self.decode_path = decode_path
+        # Route A projection weights: 'f32', or 'f16' = the model with fp16-representable q/k/v, MLP and head weights (rounded at finalize), whose decode
+        # step streams 2-byte weights
+        c.decode_weight_dtype = {"f32": _lib.W_F32, "f16": _lib.W_F16}[decode_weights]
+        self.decode_weights = decode_weights
         if cfg is not None:
             c.num_layers, c.num_heads, c.dim = cfg.num_layers, cfg.num_heads, cfg.num_embed
             c.vocab_size, c.cond_vocab_size = cfg.vocab_size, cfg.cond_vocab_size

@@ -36,6 +36,7 @@ enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
 enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 /* reserved */, BEVGEN_PRECISION_F16X3 = 2 };
 enum { BEVGEN_KV_F32 = 0, BEVGEN_KV_F16 = 1 };
 enum { BEVGEN_DECODE_FUSED = 0, BEVGEN_DECODE_PER_OP = 1 };
+enum { BEVGEN_W_F32 = 0, BEVGEN_W_F16 = 1 };
 enum { BEVGEN_DTYPE_F32 = 0, BEVGEN_DTYPE_I64 = 1, BEVGEN_DTYPE_U8 = 2, BEVGEN_DTYPE_F64 = 3 };
 
 enum {
@@ -70,7 +71,10 @@ typedef struct bevgen_cfg {
                                                           fp32 accumulate: half the decode-attention HBM traffic; tokens no longer guaranteed identical) */
     int32_t decode_path;                               /* Route A decode step: BEVGEN_DECODE_FUSED (default: three launches per layer, decode_fused.hip) or
                                                           BEVGEN_DECODE_PER_OP (one kernel per operator: the round-1 path, kept as the A/B reference) */
-    int32_t reserved[13];
+    int32_t decode_weight_dtype;                       /* Route A projection weights (q/k/v, MLP, head): BEVGEN_W_F32 (default) or BEVGEN_W_F16: bevgen_finalize rounds them to
+                                                          fp16-representable values (prefill and decode then use the same model: the reference's Route A runs fp16,
+                                                          sparse_self_attention.py:127) and the decode step streams the 2-byte copies: half the weight traffic */
+    int32_t reserved[12];
 } bevgen_cfg;
 
 typedef struct bevgen_ctx bevgen_ctx;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Route A decode probe: BASELINE config 4 (L=2368, 24 layers), B sequences, `steps` greedy steps through the hipGraph path.
-usage: decode_probe.py [B] [steps] [paths=fused,per_op] [kv=f32,f16] [samples_per_layout=1]"""
+usage: decode_probe.py [B] [steps] [paths=fused,per_op] [kv=f32,f16] [samples_per_layout=1] [weights=f32]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,14 +13,15 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 paths = (sys.argv[3] if len(sys.argv) > 3 else "fused,per_op").split(",")
 kvs = (sys.argv[4] if len(sys.argv) > 4 else "f32,f16").split(",")
 S = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+weights = (sys.argv[6] if len(sys.argv) > 6 else "f32").split(",")
 cfg = presets.config4()
 sd = gpt_state_dict(cfg, 1234)
 layouts = B // S
 bt = {k: v.repeat_interleave(S, dim=0).cuda() for k, v in synthetic.make_batch(cfg, layouts, seed=0).items()}
 ref = None
-for kv in kvs:
+for kv, wt in [(k, w) for k in kvs for w in weights]:
     for path in paths:
-        ctx = Context(cfg, route="ar", max_batch=B, kv_cache=kv, decode_path=path)
+        ctx = Context(cfg, route="ar", max_batch=B, kv_cache=kv, decode_path=path, decode_weights=wt)
         ctx.load_state_dict(sd)
         ctx.set_tables()
         ctx.finalize()
@@ -34,5 +35,5 @@ for kv in kvs:
         same = "" if ref is None else f" tokens equal to first run: {bool(torch.equal(x, ref))} ({(x != ref).sum().item()} differ)"
         if ref is None:
             ref = x
-        print(f"B={B} S={S} steps={steps} kv={kv} path={path}: wall {dt:.3f}s -> {dt * 1e3 / steps:.3f} ms/step (incl. prefill){same}", flush=True)
+        print(f"B={B} S={S} steps={steps} kv={kv} weights={wt} path={path}: wall {dt:.3f}s -> {dt * 1e3 / steps:.3f} ms/step (incl. prefill){same}", flush=True)
         ctx.close()
