@@ -286,7 +286,7 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     out = {
         "ms_per_decode_step": wall * 1e3 / steps, "ms_per_decode_step_median": pct(st, 50), "ms_per_decode_step_p99": pct(st, 99), "decode_prefill_ms": prefill_ms,
         "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                      "traffic": None, "kernel": "ar_attn_fused_kernel (ln1 + q/k/v projection + decode attention in one launch; achieved = K/V bytes / WHOLE kernel time)",
+                                      "traffic": pmc_traffic("ar_attn_fused_kernel") if kv_cache == "f32" and weights == "f32" and S == 1 else None, "kernel": "ar_attn_fused_kernel (ln1 + q/k/v projection + decode attention in one launch; achieved = K/V bytes / WHOLE kernel time)",
                                       "attention_phase": {"GBs": phase_bytes / (phase_us * 1e-6) / 1e9 if phase_us else None, "frac": phase_bytes / (phase_us * 1e-6) / 1e9 / HBM_PEAK_GBS if phase_us else None,
                                                           "us": phase_us, "context": n_last, "note": "K/V streaming phase alone, device timestamps of one launch"},
                                       "launches": int(da["launches"]), "avg_us": da["ms"] * 1e3 / max(da["launches"], 1),

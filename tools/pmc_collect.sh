@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-rXX}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o pmc --output-format csv -- python $R/tools/pmc_probe.py > $R/gpurun_out/pmc_$c.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o pmc --output-format csv -- python $R/tools/pmc_probe.py ${PMC_DECODE_STEPS:-40} > $R/gpurun_out/pmc_$c.log 2>&1
   cp $(find $R/gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1) $R/gpurun_out/${TAG}_pmc_$(echo $c | tr A-Z a-z).csv
   rm -rf $R/gpurun_out/pmc_$c
 done

@@ -1,29 +1,36 @@
 #!/usr/bin/env python
-"""Launch the two rooflined kernels a few times with bench-sized operands (for `rocprofv3 --pmc` passes: FETCH_SIZE / WRITE_SIZE).
-    gemm:    M=24576 (16 scenes x 1536 tokens), N=1024, K=1024 fp32  -> algorithmic bytes = (M*K + N*K + M*N)*4
-    decode:  B=16, H=16, n=1500 of Lmax=2368, fp32 KV               -> algorithmic bytes = 2*B*H*n*64*4
+"""Launch the rooflined kernels with bench-sized operands for `rocprofv3 --pmc` passes (FETCH_SIZE / WRITE_SIZE):
+    gemm:    M=24576 (16 scenes x 1536 tokens), N=1024, K=1024, exact-fp32 kernel and the split-precision LDS-DMA kernel
+             -> algorithmic bytes = (M*K + N*K + M*N)*4
+    decode:  Route A BASELINE config 4 (B=16, H=16, 24 layers, fp32 KV cache), STEPS decode steps through the fused kernels
+             -> per launch of ar_attn_fused_kernel, averaged over the steps: 2*B*H*mean_n*64*4 bytes of K/V (+ 786 KB x 16 of q/k/v weights per head)
+             -> per launch of skinny_fused_kernel: the weight matrix once ((N*K + M*K + M*N)*4)
 """
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from bevgen_amd.runtime import Context
+from bevgen_amd import presets, synthetic
+from bevgen_amd.runtime import Context, _ptr, _stream
+from bevgen_amd.weights import gpt_state_dict
 
+STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 ctx = Context(None)
 M, N, K = 24576, 1024, 1024
 a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda")
 for _ in range(5):
     ctx.op_gemm(a, w)
-# split-precision LDS-DMA GEMM (the production path of the default f16x3 mode): operands are split on the fly by the op entry point,
-# the GEMM kernel itself reads 4 B per element of A and B (interleaved hi/lo f16 planes) and writes fp32 C -> same algorithmic bytes
-from bevgen_amd.runtime import _ptr, _stream
 out = torch.empty(M, N, device="cuda")
 for _ in range(5):
     ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(a), _ptr(w), None, None, _ptr(out), M, N, K, 0, 3, _stream()))
-B, H, n, L = 16, 16, 1500, 2368
-q = torch.randn(B, H * 64, device="cuda")
-kc = torch.randn(B, H, L, 64, device="cuda"); vc = torch.randn(B, H, L, 64, device="cuda")
-bias = torch.randn(L, L, device="cuda")
-for _ in range(5):
-    ctx.op_decode_attention(q, kc, vc, n, bias=bias)
 torch.cuda.synchronize()
-print("gemm algorithmic MB", (M * K + N * K + M * N) * 4 / 1e6, "decode algorithmic MB", 2 * B * H * n * 64 * 4 / 1e6)
+ctx.close()
+cfg = presets.config4()
+ctx = Context(cfg, route="ar", max_batch=16)
+ctx.load_state_dict(gpt_state_dict(cfg, 1234))
+ctx.set_tables()
+ctx.finalize()
+bt = {k: v.cuda() for k, v in synthetic.make_batch(cfg, 16, seed=0).items()}
+ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=STEPS, return_logits=True)   # return_logits: the eager launch path (counter collection + hipGraph replay is unusably slow)
+torch.cuda.synchronize()
+mean_n = cfg.num_cond_tokens + 1 + (STEPS - 2) / 2.0
+print("gemm algorithmic MB", (M * K + N * K + M * N) * 4 / 1e6, "decode steps", STEPS, "mean context", mean_n, "K/V MB per fused launch", 2 * 16 * 16 * mean_n * 64 * 4 / 1e6)
