@@ -130,3 +130,51 @@ def test_net2net_fully_native_forward_from_raw_batch():
     assert (out["gen"].cpu() - gen_ref).abs().max() < 1e-3
     assert (out["rec"].cpu() - rec_ref).abs().max() < 1e-3
     assert (out["gt"].cpu() - R.denormalize(img).reshape(B, cfg.num_cams, 3, 64, 64)).abs().max() < 1e-6
+
+
+def test_route_a_net2net_forward_from_raw_batch_with_partial_decoding():
+    """Route A drop-in (ar_lm Net2NetTransformer): forward / log_images with the reference's raw batch keys only - BEV segmentation -> HIP encoder -> cond ids,
+    images -> HIP encoder -> z ids for 'rec' and for partial decoding (partial_decoding=4 fixes cameras [3, 0, 2] deterministically, ar_lm:509-510),
+    greedy sampling through prefill + KV-cache decode, non-square 4 x 5 latents through the fully convolutional decoder - every stage against the oracle."""
+    from bevgen_amd.modules.stage1.vqgan import VQModel, VQSegmentationModel
+    from bevgen_amd.modules.stage2.cond_transformer_multi_view import Net2NetTransformer
+    from bevgen_amd.modules.transformer.mingpt_sparse import GPT
+    from oracle import cases
+
+    cfg = presets.route_a(6, num_layers=2, dim=128, heads=2, vocab=64, cam_res=(32, 40), cam_latent_res=(4, 5), bev_latent_res=(8, 8), block=16, window_len=8)
+    dd, dds = cases.VQ_TINY["dd"], cases.VQ_TINY_SEG["dd"]
+    gpt = GPT(cfg)
+    vq = VQModel(ddconfig=dd, n_embed=64, embed_dim=64, cam_res=(32, 40), cam_latent_res=(4, 5), cam_emd_dim=64)
+    vqc = VQSegmentationModel(n_labels=7, ddconfig=dds, n_embed=64, embed_dim=64, cam_res=(64, 64), cam_latent_res=(8, 8), cam_emd_dim=64, image_key="segmentation")
+    model = Net2NetTransformer(gpt, vq, vqc, partial_decoding=4)
+    sd_g = W.gpt_state_dict(cfg, 1234)
+    sd_v = W.vq_state_dict(dd, 64, 64, 99, with_encoder=True)
+    sd_c = W.vq_state_dict(dds, 64, 64, 77, with_encoder=True)
+    full = {("transformer." + k): v for k, v in sd_g.items()}
+    full.update({("first_stage_model." + k): v for k, v in sd_v.items()})
+    full.update({("cond_stage_model." + k): v for k, v in sd_c.items()})
+    missing, unexpected = model.load_state_dict(full, strict=False)
+    assert not unexpected and missing == ["cond_stage_model.colorize"], (missing, unexpected)
+    model = model.to("cuda")
+    B, C, T = 2, cfg.num_cams, cfg.num_cam_tokens
+    bt = synthetic.make_batch(cfg, B, seed=9)
+    g = torch.Generator().manual_seed(6)
+    batch = {"image": torch.randn(B, C, 32, 40, 3, generator=g), "segmentation": torch.randn(B, 64, 64, 7, generator=g),
+             "intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
+    out = model.log_images(batch, sample=False)          # greedy instead of the reference's top-k-100 draw: comparable with the oracle
+    # oracle chain
+    c_ids = R.vq_encode_ids(sd_c, dds, batch["segmentation"].movedim(-1, -3))
+    img = batch["image"].movedim(-1, -3).reshape(B * C, 3, 32, 40)
+    z_ids = R.vq_encode_ids(sd_v, dd, img)
+    forced = R.partial_forced_ids(cfg, [3, 0, 2], z_ids.reshape(B, C, T))
+    x = R.ar_sample_cached(sd_g, cfg, c_ids, bt["intrinsics_inv"], bt["extrinsics_inv"], forced_ids=forced)
+    assert torch.equal(x[:, [0, 2, 3]], z_ids.reshape(B, C, T)[:, [0, 2, 3]])
+    gen_ref = R.vq_decode_ids(sd_v, dd, x.reshape(B * C, T), (4, 5), denorm=True).reshape(B, C, 3, 32, 40)
+    rec_ref = R.vq_decode_ids(sd_v, dd, z_ids, (4, 5), denorm=True).reshape(B, C, 3, 32, 40)
+    assert tuple(out["gen"].shape) == (B, C, 3, 32, 40)
+    assert (out["gen"].cpu() - gen_ref).abs().max() < 1e-3
+    assert (out["rec"].cpu() - rec_ref).abs().max() < 1e-3
+    assert (out["gt"].cpu() - R.denormalize(img).reshape(B, C, 3, 32, 40)).abs().max() < 1e-6
+    # forward() = log_images(generate_only=True) with the module's top_k: the stochastic default path runs and returns the three entries
+    out2 = model(batch)
+    assert set(out2) == {"gen", "rec", "gt"} and tuple(out2["gen"].shape) == (B, C, 3, 32, 40) and float(out2["gen"].min()) >= 0 and float(out2["gen"].max()) <= 1
