@@ -183,6 +183,11 @@ static void finalize_muse(Ctx& c) {
             c.split_weight(l.to_out[j], (long)D * inner);
         }
         c.split_weight(l.ff_w1, 2L * F * D);
+        if (g.precision == BEVGEN_PRECISION_F16X3 && c.Fpad % 64 == 0) {
+            l.ff_w1_geglu = reinterpret_cast<float*>(c.own((size_t)2 * c.Fpad * D * sizeof(float)));
+            launch_geglu_weight_order(l.ff_w1, l.ff_w1_geglu, F, c.Fpad, D, 0);
+            c.split_weight(l.ff_w1_geglu, 2L * c.Fpad * D);
+        }
         c.split_weight(l.ff_w4_padded, (long)D * c.Fpad);
     }
     c.split_weight(c.pf(p + "to_logits.weight"), (long)g.vocab_size * D);

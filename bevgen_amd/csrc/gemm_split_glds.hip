@@ -291,6 +291,31 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         }
         return;
     }
+    if (MODE == MODE_PLAIN && g.epi == EPI_GEGLU) {   // (compiled out of the convolution variant: its register budget has no room for a third epilogue)
+        // GEGLU fused into the feed-forward up-projection (muse_net:71-76: x, gate = chunk(2); gate * gelu(x)): the weight rows were ordered so that a
+        // wave's MFMA column tile j = 0 holds 32 `x` columns and j = 1 the 32 matching `gate` columns; the product leaves as ONE [M, N/2] matrix
+        // (half the bytes of the raw projection, and the separate GEGLU pass over [M, N] disappears: its LayerNorm half runs on the result).
+        float* C = g.C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int o = (n0 >> 1) + wn * 32 + 8 * qq + 4 * h;   // output column: this tile's 64 outputs start at n0 / 2
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = qq * 4 + e;
+                    const float xa = (accM[i][0][q] + accC[i][0][q] * kGLoInv) * g.alpha;
+                    const float gt = (accM[i][1][q] + accC[i][1][q] * kGLoInv) * g.alpha;
+                    v[e] = gt * gelu_erf(xa);
+                }
+                *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + o) = v;
+            }
+        }
+        return;
+    }
     float* C = g.C;
     const float* Rp = g.R;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
@@ -348,6 +373,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
     BG_REQUIRE(g.K % GBK == 0 && g.lda % GBK == 0 && g.ldb % GBK == 0, "gemm_split_glds: K, lda, ldb must be multiples of 32 (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
     BG_REQUIRE(g.batch == 1, "gemm_split_glds: batched form not provided");
+    if (g.epi == EPI_GEGLU)
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.N % GBN == 0 && g.ldc % 4 == 0 && g.ldc >= g.N / 2 && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE,
+                   "gemm_split_glds: bad fused GEGLU arguments (N=%d ldc=%d)", g.N, g.ldc);
     if (g.epi == EPI_MUSE_Q)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");

@@ -8,7 +8,7 @@ namespace bevgen {
 // ---------------------------------------------------------------- gemm.hip
 enum { MODE_PLAIN = 0, MODE_CONV3 = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1 };
-enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1 };
+enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1, EPI_GEGLU = 2 };
 
 struct GemmArgs {
     const float* A = nullptr;  // [M,K] row-major (lda)   | MODE_CONV3: NHWC input [n, Hin, Win, Cin]
@@ -40,6 +40,8 @@ struct GemmArgs {
     const void* zero_page = nullptr;  // filled in by the launcher
     // fused epilogues of the LDS-DMA kernel: EPI_MUSE_Q writes l2norm(8 x) * epi_scale[d] per head as (hi, lo) f16 planes [B, epi_heads, epi_rows, 64]
     // (rows of the GEMM = B * epi_rows tokens) instead of C
+    // EPI_GEGLU (Route M feed-forward, muse_net:71-76): the weight rows are pre-ordered [a(32) | gate(32)] per wave (launch_geglu_weight_order), the epilogue
+    // writes gate * gelu(a) - HALF the columns (N/2, ldc) - instead of the raw projection
     int epi = 0;
     const float* epi_scale = nullptr;
     void* epi_hi = nullptr;

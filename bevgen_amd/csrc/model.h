@@ -37,6 +37,7 @@ struct MuseLayer {
     const float *norm_g[2], *to_q[2], *to_kv[2], *to_out[2], *q_scale[2], *k_scale[2], *null_kv[2];
     const float *ff_g0, *ff_w1, *ff_g3;
     float* ff_w4_padded;  // [D, Fpad], owned
+    float* ff_w1_geglu = nullptr;   // split-precision mode: [2 Fpad, D] rows ordered for the fused GEGLU epilogue (owned)
 };
 
 struct ArLayer {
@@ -183,6 +184,7 @@ void launch_store_tokens(const int64_t* tok, const int64_t* fwd_idx, const int* 
 void launch_gather_rows(const float* x, float* out, int B, int row, int rows_per_batch, int D, hipStream_t s);
 void launch_replicate_prefix(void* kc, void* vc, int layers, int B, int H, int L, int rows, int src, int dst0, int count, int elem_bytes, hipStream_t s);
 void launch_increment(int* p, hipStream_t s);
+void launch_geglu_weight_order(const float* W, float* Wo, int F, int Fpad, int D, hipStream_t s);
 void launch_round_to_f16(float* w /* rounded in place */, void* h /* fp16 copy or null */, long n, hipStream_t s);
 void launch_relayout_conv_weight(const float* w_oihw, float* w_ohwi, int cout, int cin, int kh, int kw, hipStream_t s);
 void launch_fuse_qkv(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, float* w, float* b, int D, hipStream_t s);

@@ -193,8 +193,20 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         if (split) {
             gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
             launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
-            gemm_planes(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
-            launch_geglu_layernorm_planes(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+            if (l.ff_w1_geglu) {
+                // GEGLU in the up-projection's epilogue: h = gate * gelu(x) as [rows, Fpad] (pad columns exactly 0), then the LayerNorm half on its own
+                GemmArgs ge;
+                ge.A_hi = reinterpret_cast<const uint16_t*>(w.xn); ge.A_lo = ge.A_hi + 32;
+                ge.B = l.ff_w1_geglu; ge.C = w.h;
+                ge.M = rows; ge.N = 2 * c.Fpad; ge.K = D;
+                ge.lda = D; ge.ldb = D; ge.ldc = c.Fpad;
+                ge.epi = EPI_GEGLU;
+                launch_gemm(ge, s);
+                launch_layernorm_planes(w.h, c.Fpad, l.ff_g3, nullptr, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+            } else {
+                gemm_planes(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
+                launch_geglu_layernorm_planes(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+            }
             gemm_planes(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s);
         } else {
             gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);

@@ -38,17 +38,25 @@ constexpr int LN_MAXV = 12;  // float4 per lane -> D <= 3072
 template <bool PLANES>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, int ldy, int rows, int D, float eps) {
+    // D need not be a multiple of 4 (Route M: LayerNorm over F = 2730 columns of a row padded to 2752): the last vector of a row is then partly
+    // padding - read (the row storage is ldx >= round_up(D, 4) wide), excluded from the statistics, written as zero.
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
-    const int nv = D >> 2;
+    const int nv = (D + 3) >> 2;
     float4 v[LN_MAXV];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
         const int i = lane + 64 * j;
         v[j] = i < nv ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (4 * i + 3 >= D) {   // boundary / padding vector: elements at columns >= D do not exist
+            if (4 * i + 0 >= D) v[j].x = 0.f;
+            if (4 * i + 1 >= D) v[j].y = 0.f;
+            if (4 * i + 2 >= D) v[j].z = 0.f;
+            v[j].w = 0.f;
+        }
     }
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -56,9 +64,11 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
-        if (lane + 64 * j < nv) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
             const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
+            if (4 * i + 3 < D) q += (a * a + b * b) + (c * c + d * d);
+            else q += ((4 * i + 0 < D ? a * a : 0.f) + (4 * i + 1 < D ? b * b : 0.f)) + (4 * i + 2 < D ? c * c : 0.f);
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
@@ -69,9 +79,21 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     for (int j = 0; j < LN_MAXV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) {
-            const float4 g = g4[i];
-            float4 o = make_float4((v[j].x - mean) * rstd * g.x, (v[j].y - mean) * rstd * g.y, (v[j].z - mean) * rstd * g.z, (v[j].w - mean) * rstd * g.w);
-            if (beta) { const float4 bb = b4[i]; o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
+            float4 o;
+            if (4 * i + 3 < D) {
+                const float4 g = g4[i];
+                o = make_float4((v[j].x - mean) * rstd * g.x, (v[j].y - mean) * rstd * g.y, (v[j].z - mean) * rstd * g.z, (v[j].w - mean) * rstd * g.w);
+                if (beta) { const float4 bb = b4[i]; o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
+            } else {   // boundary vector: element-wise, gamma / beta are only D long
+                const float in[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+                float out[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = 4 * i + e;
+                    out[e] = col < D ? (in[e] - mean) * rstd * gamma[col] + (beta ? beta[col] : 0.f) : 0.f;
+                }
+                o = make_float4(out[0], out[1], out[2], out[3]);
+            }
             if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 4, o);
             else yr[i] = o;
         } else if (i < (ldy >> 2)) {
@@ -83,7 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 
 void launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int rows, int D, float eps, hipStream_t s) {
     if (rows <= 0) return;
-    const bool vec = D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && D <= 256 * LN_MAXV && ldy <= 256 * LN_MAXV &&
+    const bool vec = ldx % 4 == 0 && ldy % 4 == 0 && ldx >= round_up(D, 4) && ldy >= round_up(D, 4) && D <= 256 * LN_MAXV && ldy <= 256 * LN_MAXV &&
                      (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0;
     if (vec)
         hipLaunchKernelGGL(layernorm_vec_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
@@ -94,7 +116,7 @@ void launch_layernorm(const float* x, int ldx, const float* gamma, const float* 
 
 void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const float* beta, void* planes, int ldy, int rows, int D, float eps, hipStream_t s) {
     if (rows <= 0) return;
-    BG_REQUIRE(D % 4 == 0 && ldx % 4 == 0 && ldy % 32 == 0 && ldy <= 256 * LN_MAXV &&
+    BG_REQUIRE(ldx % 4 == 0 && ldx >= round_up(D, 4) && ldy % 32 == 0 && ldy >= round_up(D, 4) && ldy <= 256 * LN_MAXV &&
                    (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0,
                "layernorm_planes: unsupported shape D=%d ldx=%d ldy=%d", D, ldx, ldy);
     hipLaunchKernelGGL(layernorm_vec_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps);

@@ -142,6 +142,24 @@ void launch_round_to_f16(float* w, void* h, long n, hipStream_t s) {
     LAUNCH_CHECK();
 }
 
+// Row order of the GEGLU up-projection weight for the fused epilogue (EPI_GEGLU): W [2F, D] (rows 0..F-1 = x, F..2F-1 = gate, muse_net:74) ->
+// Wo [2 Fpad, D], 64-row groups: group (t, wn) = [x rows 64t + 32wn .. +31 | gate rows of the same 32 outputs]; rows of outputs >= F are zero
+__global__ void geglu_weight_order_kernel(const float* __restrict__ W, float* __restrict__ Wo, int F, int Fpad, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)2 * Fpad * D;
+    if (i >= total) return;
+    const int col = (int)(i % D);
+    const int row = (int)(i / D);              // output row of Wo
+    const int grp = row >> 6, within = row & 63;
+    const int is_gate = within >> 5, f = grp * 32 + (within & 31);   // grp = 2 t + wn  ->  outputs 32 grp .. 32 grp + 31
+    Wo[i] = f < F ? W[((long)is_gate * F + f) * D + col] : 0.f;
+}
+void launch_geglu_weight_order(const float* W, float* Wo, int F, int Fpad, int D, hipStream_t s) {
+    const long total = (long)2 * Fpad * D;
+    hipLaunchKernelGGL(geglu_weight_order_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, W, Wo, F, Fpad, D);
+    LAUNCH_CHECK();
+}
+
 __global__ void increment_kernel(int* p) { *p += 1; }
 void launch_increment(int* p, hipStream_t s) {
     hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(1), 0, s, p);
