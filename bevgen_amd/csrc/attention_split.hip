@@ -285,6 +285,25 @@ __global__ __launch_bounds__(256) void muse_kv_prep_split_kernel(const float* __
     }
 }
 
+// prepared null key / value of one attention module for the fused to_kv epilogue (EPI_MUSE_KV): out = [k_hi | k_lo | v_hi | v_lo][H][64] halves
+__global__ __launch_bounds__(64) void muse_null_kv_prep_kernel(const float* __restrict__ null_kv, const float* __restrict__ k_scale, _Float16* __restrict__ out, int H) {
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const float kv = null_kv[h * 64 + lane], vv = null_kv[(long)H * 64 + h * 64 + lane];
+    const float nrm = fmaxf(sqrtf(wave_sum(kv * kv)), 1e-12f);
+    const float k = (kv / nrm) * k_scale[lane];
+    _Float16 hi, lo;
+    split1(k, hi, lo);
+    out[h * 64 + lane] = hi;
+    out[H * 64 + h * 64 + lane] = lo;
+    split1(vv, hi, lo);
+    out[2 * H * 64 + h * 64 + lane] = hi;
+    out[3 * H * 64 + h * 64 + lane] = lo;
+}
+void launch_muse_null_kv_prep(const float* null_kv, const float* k_scale, void* out, int H, hipStream_t s) {
+    hipLaunchKernelGGL(muse_null_kv_prep_kernel, dim3(H), dim3(64), 0, s, null_kv, k_scale, reinterpret_cast<_Float16*>(out), H);
+    LAUNCH_CHECK();
+}
+
 void launch_muse_kv_prep_split(const float* kvraw, const float* null_kv, const float* k_scale, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nk,
                                int Nk_pad, hipStream_t s) {
     dim3 grid(cdiv(Nk_pad, 64), H, B);

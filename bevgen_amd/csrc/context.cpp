@@ -183,6 +183,10 @@ static void finalize_muse(Ctx& c) {
             c.split_weight(l.to_out[j], (long)D * inner);
         }
         c.split_weight(l.ff_w1, 2L * F * D);
+        if (g.precision == BEVGEN_PRECISION_F16X3) {
+            l.null_self = c.own((size_t)4 * H * 64 * sizeof(_Float16));
+            launch_muse_null_kv_prep(l.null_kv[0], l.k_scale[0], l.null_self, H, 0);
+        }
         if (g.precision == BEVGEN_PRECISION_F16X3 && c.Fpad % 64 == 0) {
             l.ff_w1_geglu = reinterpret_cast<float*>(c.own((size_t)2 * c.Fpad * D * sizeof(float)));
             launch_geglu_weight_order(l.ff_w1, l.ff_w1_geglu, F, c.Fpad, D, 0);

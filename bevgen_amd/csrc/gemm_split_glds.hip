@@ -291,6 +291,77 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         }
         return;
     }
+    if (MODE == MODE_PLAIN && g.epi == EPI_MUSE_KV) {
+        // Route M key / value preparation fused into the to_kv projection (muse_net:132-146; replaces muse_kv_prep_split and its pass over the raw projection):
+        // the wave's 64 columns are one head of k (columns < H*64) or of v.  k: l2norm (eps 1e-12) * k_scale, hi/lo planes [B, H, ld, 64] at key row 1 + token.
+        // v: hi/lo planes written TRANSPOSED [B, H, 64, ld] (column 1 + token): 32 consecutive tokens of a lane half are 64 contiguous bytes.
+        const int HD = g.epi_heads * 64;
+        const int ncol = n0 + wn * 64;
+        const bool is_v = ncol >= HD;
+        const int head = (is_v ? ncol - HD : ncol) >> 6;
+        const _Float16* aux = reinterpret_cast<const _Float16*>(g.epi_aux);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + r;
+            const int mc = min(m, g.M - 1);
+            const int bb = mc / g.epi_rows, nk = mc - bb * g.epi_rows;
+            float v[2][16];
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    v[j][q] = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha;
+                    ss = fmaf(v[j][q], v[j][q], ss);
+                }
+            ss += xor32(ss);   // (uniform control flow up to here: the exchange needs both lane halves)
+            if (m >= g.M) continue;
+            if (!is_v) {
+                const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                _Float16* Kh = reinterpret_cast<_Float16*>(g.epi_hi);
+                _Float16* Kl = reinterpret_cast<_Float16*>(g.epi_lo);
+                const long dst = (((long)bb * g.epi_heads + head) * g.epi_ld + 1 + nk) * 64;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int d = j * 32 + 8 * qq + 4 * h;
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(g.epi_scale + d);
+                        half4_t hi4, lo4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float kv = (v[j][qq * 4 + e] / nrm) * sc[e];
+                            hi4[e] = split_hi(kv);
+                            lo4[e] = split_lo(kv, hi4[e]);
+                        }
+                        *reinterpret_cast<half4_t*>(Kh + dst + d) = hi4;
+                        *reinterpret_cast<half4_t*>(Kl + dst + d) = lo4;
+                        if (nk == 0) {   // the learned null key of this (batch, head): row 0
+                            *reinterpret_cast<half4_t*>(Kh + dst - (long)64 + d) = *reinterpret_cast<const half4_t*>(aux + head * 64 + d);
+                            *reinterpret_cast<half4_t*>(Kl + dst - (long)64 + d) = *reinterpret_cast<const half4_t*>(aux + HD + head * 64 + d);
+                        }
+                    }
+            } else {
+                _Float16* Vh = reinterpret_cast<_Float16*>(g.epi_hi2);
+                _Float16* Vl = reinterpret_cast<_Float16*>(g.epi_lo2);
+                const long base = ((long)bb * g.epi_heads + head) * 64 * g.epi_ld + 1 + nk;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int d = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                        const _Float16 hi = split_hi(v[j][q]);
+                        Vh[base + (long)d * g.epi_ld] = hi;
+                        Vl[base + (long)d * g.epi_ld] = split_lo(v[j][q], hi);
+                        if (nk == 0) {
+                            Vh[base - 1 + (long)d * g.epi_ld] = aux[2 * HD + head * 64 + d];
+                            Vl[base - 1 + (long)d * g.epi_ld] = aux[3 * HD + head * 64 + d];
+                        }
+                    }
+            }
+        }
+        return;
+    }
     if (MODE == MODE_PLAIN && g.epi == EPI_GEGLU) {   // (compiled out of the convolution variant: its register budget has no room for a third epilogue)
         // GEGLU fused into the feed-forward up-projection (muse_net:71-76: x, gate = chunk(2); gate * gelu(x)): the weight rows were ordered so that a
         // wave's MFMA column tile j = 0 holds 32 `x` columns and j = 1 the 32 matching `gate` columns; the product leaves as ONE [M, N/2] matrix
@@ -373,6 +444,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
     BG_REQUIRE(g.K % GBK == 0 && g.lda % GBK == 0 && g.ldb % GBK == 0, "gemm_split_glds: K, lda, ldb must be multiples of 32 (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
     BG_REQUIRE(g.batch == 1, "gemm_split_glds: batched form not provided");
+    if (g.epi == EPI_MUSE_KV)
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.N == 2 * g.epi_heads * 64 && g.epi_hi && g.epi_lo && g.epi_hi2 && g.epi_lo2 && g.epi_aux && g.epi_scale && g.epi_rows > 0 &&
+                       g.epi_ld >= g.epi_rows + 1 && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE && g.M % g.epi_rows == 0,
+                   "gemm_split_glds: bad fused k/v-preparation arguments");
     if (g.epi == EPI_GEGLU)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % GBN == 0 && g.ldc % 4 == 0 && g.ldc >= g.N / 2 && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE,
                    "gemm_split_glds: bad fused GEGLU arguments (N=%d ldc=%d)", g.N, g.ldc);

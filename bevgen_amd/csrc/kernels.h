@@ -8,7 +8,7 @@ namespace bevgen {
 // ---------------------------------------------------------------- gemm.hip
 enum { MODE_PLAIN = 0, MODE_CONV3 = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1 };
-enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1, EPI_GEGLU = 2 };
+enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1, EPI_GEGLU = 2, EPI_MUSE_KV = 3 };
 
 struct GemmArgs {
     const float* A = nullptr;  // [M,K] row-major (lda)   | MODE_CONV3: NHWC input [n, Hin, Win, Cin]
@@ -47,6 +47,13 @@ struct GemmArgs {
     void* epi_hi = nullptr;
     void* epi_lo = nullptr;
     int epi_rows = 0, epi_heads = 0;
+    // EPI_MUSE_KV (Route M self-attention, to_kv projection [rows, 2 H 64] = k | v): k columns leave as l2norm(k) * epi_scale planes [B, H, epi_ld, 64] at key row
+    // 1 + token (row 0 = the learned null key), v columns as the TRANSPOSED planes [B, H, 64, epi_ld] the attention kernel reads (epi_hi2 / epi_lo2); the row of
+    // token 0 also writes the prepared null key / value (epi_aux: [k_hi | k_lo | v_hi | v_lo][H][64] halves)
+    void* epi_hi2 = nullptr;
+    void* epi_lo2 = nullptr;
+    const void* epi_aux = nullptr;
+    int epi_ld = 0;
     float epi_post = 1.f;             // EPI_MUSE_Q: extra factor on the prepared query (the attention kernel's score scale, folded in here)
     int a_bytes = 0;                  // MODE_CONV3: size of the activation plane image (buffer-resource bound), filled in by the launcher
     int tile_band = 0;                // tile-order band height (0 = row-major); filled in by the launcher
@@ -114,6 +121,7 @@ struct AttnSplitArgs {
 };
 void launch_attention_split(const AttnSplitArgs& a, hipStream_t s);
 void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, float post, hipStream_t s);
+void launch_muse_null_kv_prep(const float* null_kv, const float* k_scale, void* out /* 4*H*64 halves */, int H, hipStream_t s);
 void launch_muse_kv_prep_split(const float* kvraw, const float* null_kv, const float* k_scale, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nk,
                                int Nk_pad, hipStream_t s);
 

@@ -37,6 +37,7 @@ struct MuseLayer {
     const float *norm_g[2], *to_q[2], *to_kv[2], *to_out[2], *q_scale[2], *k_scale[2], *null_kv[2];
     const float *ff_g0, *ff_w1, *ff_g3;
     float* ff_w4_padded;  // [D, Fpad], owned
+    void* null_self = nullptr;      // split-precision mode: prepared null key / value of the self-attention ([k_hi|k_lo|v_hi|v_lo][H][64] halves, owned)
     float* ff_w1_geglu = nullptr;   // split-precision mode: [2 Fpad, D] rows ordered for the fused GEGLU epilogue (owned)
 };
 

@@ -138,7 +138,17 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         if (split) {
             launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
             gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s);
-            gemm_planes(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
+            {   // to_kv with the key / value preparation in its epilogue: k planes [B, H, NkS_pad, 64], v planes transposed [B, H, 64, NkS_pad]
+                const size_t kvS_ = (size_t)B * H * c.NkS_pad * 64;
+                _Float16 *Kp = reinterpret_cast<_Float16*>(w.Ks), *Vp = reinterpret_cast<_Float16*>(w.Vs);
+                GemmArgs gk;
+                gk.A_hi = reinterpret_cast<const uint16_t*>(w.xn); gk.A_lo = gk.A_hi + 32;
+                gk.B = l.to_kv[0];
+                gk.M = rows; gk.N = 2 * D; gk.K = D; gk.lda = D; gk.ldb = D; gk.ldc = 2 * D;
+                gk.epi = EPI_MUSE_KV; gk.epi_scale = l.k_scale[0]; gk.epi_hi = Kp; gk.epi_lo = Kp + kvS_; gk.epi_hi2 = Vp; gk.epi_lo2 = Vp + kvS_;
+                gk.epi_aux = l.null_self; gk.epi_rows = N; gk.epi_heads = H; gk.epi_ld = c.NkS_pad;
+                launch_gemm(gk, s);
+            }
         } else {
             launch_layernorm(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
             gemm(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
@@ -148,7 +158,6 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         _Float16 *Qh = reinterpret_cast<_Float16*>(w.Q), *Ksh = reinterpret_cast<_Float16*>(w.Ks), *VTsh = reinterpret_cast<_Float16*>(w.Vs);
         AttnSplitArgs sa{};
         if (split) {
-            launch_muse_kv_prep_split(w.kvraw, l.null_kv[0], l.k_scale[0], Ksh, Ksh + kvS, VTsh, VTsh + kvS, B, H, N, c.NkS_pad, s);
             sa.Qh = Qh; sa.Ql = Qh + qN; sa.Kh = Ksh; sa.Kl = Ksh + kvS; sa.VTh = VTsh; sa.VTl = VTsh + kvS;
             sa.bias = c.bias_self; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
             sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f * kLog2e;
