@@ -97,6 +97,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension has not been built. Run `make -C {os.path.join(_HERE, 'csrc')}` "
             "(hipcc --offload-arch=gfx950) or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback."
         )
+    # torch ships its own libamdhip64: it has to be in the process BEFORE this library is mapped, so that the NEEDED entry of libbevgen_hip.so resolves to
+    # the runtime torch uses (one HIP runtime per process; with the opposite order the second runtime reports "no ROCm-capable device")
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
