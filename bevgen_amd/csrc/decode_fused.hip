@@ -196,7 +196,7 @@ template <int DT, int G, int WT>   // KV-cache storage (0 fp32, 1 fp16), sequenc
 __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) {
     using T = KvRow<DT>;
     constexpr int LPK = T::LPK, DPL = T::DPL, KPI = 64 / LPK, NW = AF_WAVES, TW = NW / G;
-    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // keys per lane group and pipeline stage
+    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // keys per lane group and pipeline stage (fp16 rows: 3 or 4 measured no faster)
     constexpr int UP = G >= 4 ? 1 : U;   // same for the shared-prefix phase (G queries' state lives in registers)
     extern __shared__ float smem[];
     const int D = a.D;
