@@ -7,7 +7,7 @@ N > 1: the script launches its own N ranks (one per GPU, `python -m torch.distri
 unless it already runs under a launcher (WORLD_SIZE set); inside, the RCCL world size must equal N or the run fails.
 
 Workload (BASELINE.json configs[1]): Route M (muse_stage_two bidirectional MaskGit decoder, released hyper-parameters: 14 layers, D=1024, 16 heads,
-18 iterations, top-k thres 0.9, self token critic), 6 views of 256x256, batch = 16 scenes per GPU: BEV token grid -> MaskGit generate -> VQGAN decode
+18 iterations, top-k thres 0.9, gumbel / critic noise drawn in the sampler kernels, self token critic), 6 views of 256x256, batch = 16 scenes per GPU: BEV token grid -> MaskGit generate -> VQGAN decode
 -> uint8 pixels.  A "step" is one batch of 16 scenes.  Inputs (BEV token ids, camera matrices) and random-init weights of the reference
 architecture are synthetic and resident in HBM before the timed region.  N > 1: independent scenes are sharded over ranks (weak scaling, 16 scenes
 per GPU), no data-path collective; the only RCCL traffic is the final gather of the uint8 pixels to rank 0 (inside the timed region); a
@@ -332,10 +332,13 @@ def main():
         bt = synthetic.make_batch(cfg, batch, seed=1000 + rank)  # each rank: its own shard of scenes
         bt = {k: v.to(ctx.device) for k, v in bt.items()}
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+        seeds = []
 
         def one_step(e=None):
             if e: e[0].record()
-            ids = ctx.maskgit_generate(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], timesteps=args.timesteps)
+            # stochastic sampling like the reference's default generate (gumbel + critic noise, top-k 0.9): uniforms drawn inside the sampler kernels
+            ids = ctx.maskgit_generate(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], timesteps=args.timesteps, noise_seed=2025 + 7919 * rank + len(seeds))
+            seeds.append(0)
             if e: e[1].record()
             px = ctx.vq_decode(ids.reshape(batch * cams, -1), latent_hw=(cfg.cam_latent_h, cfg.cam_latent_w), uint8=True)      # [B*C,3,256,256] uint8
             if e: e[2].record()
@@ -399,7 +402,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM/conv/attention products as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; everything else fp32)",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: Route M MaskGit (14 layers, D=1024, 18 iterations, self-critic) {args.cams}x256x256, batch {args.batch} scenes/GPU, + VQGAN f16 decode to uint8",
+        "config": {"workload": f"BASELINE configs[1]: Route M MaskGit (14 layers, D=1024, 18 iterations, top-k 0.9 + gumbel / critic noise, self-critic) {args.cams}x256x256, batch {args.batch} scenes/GPU, + VQGAN f16 decode to uint8",
                    "global_batch": n_gpus * args.batch, "parallelism": f"scene-parallel x{n_gpus} (RCCL gather of uint8 pixels)", "precision_mode": args.precision},
         "ms_per_maskgit_iteration": float(np.mean(parts["generate"])) / args.timesteps,
         "vqgan_decode_ms_per_scene": float(np.mean(parts["vq_decode"])) / args.batch,

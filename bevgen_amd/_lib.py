@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVGEN_LIB_PATH") or os.path.join(_HERE, "csrc", "libbevgen_hip.so")   # override: A/B runs of two builds on one GPU box
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevgen_hip.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
@@ -58,7 +58,8 @@ SIGNATURES = {
     "bevgen_set_tables": (_i, [_p, _p, _p, _p, _p, _p]),
     "bevgen_finalize": (_i, [_p]),
     "bevgen_muse_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
-    "bevgen_maskgit_generate": (_i, [_p, _p, _p, _p, _i, _i, C.POINTER(C.c_int32), _f, _i, _f, _p, _p, _p, _p, _p]),
+    "bevgen_maskgit_generate": (_i, [_p, _p, _p, _p, _i, _i, C.POINTER(C.c_int32), _f, _i, _f, _p, _p, _p, _p, C.c_uint64, _p]),
+    "bevgen_op_philox_uniform": (_i, [_p, C.c_uint64, C.c_uint, C.c_uint, _i, _l, _p, _p]),
     "bevgen_sparse_self_attention": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "bevgen_ar_prefill": (_i, [_p, _p, _p, _p, _i, _p]),
     "bevgen_ar_logits": (_i, [_p, _p, _p]),

@@ -102,7 +102,8 @@ int bevgen_muse_forward(bevgen_ctx* ctx, const int64_t* ids, const int64_t* cond
 }
 
 int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
-                            int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, void* stream) {
+                            int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out,
+                            unsigned long long noise_seed, void* stream) {
     return guarded(ctx, [&] {
         need_final(ctx);
         BG_REQUIRE(cond && I_inv && E_inv && out && sched, "maskgit_generate: null argument");
@@ -110,7 +111,14 @@ int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* cond, const float* I
         BG_REQUIRE(topk_k >= 1 && topk_k <= ctx->cfg.vocab_size, "maskgit_generate: topk_k=%d out of range", topk_k);
         for (int i = 0; i < timesteps; ++i)
             BG_REQUIRE(sched[i] >= 1 && sched[i] <= ctx->cfg.cam_latent_h * ctx->cfg.cam_latent_w, "maskgit_generate: mask_schedule[%d]=%d out of range", i, sched[i]);
-        maskgit_generate(*ctx, cond, I_inv, E_inv, B, timesteps, sched, temperature, topk_k, critic_noise_scale, gumbel_u, critic_u, init_ids, out, (hipStream_t)stream);
+        maskgit_generate(*ctx, cond, I_inv, E_inv, B, timesteps, sched, temperature, topk_k, critic_noise_scale, gumbel_u, critic_u, init_ids, out, (hipStream_t)stream, noise_seed);
+    });
+}
+
+int bevgen_op_philox_uniform(bevgen_ctx* ctx, unsigned long long seed, unsigned iter, unsigned stream_id, int V, long n, float* out, void* stream) {
+    return guarded(ctx, [&] {
+        BG_REQUIRE(out && n >= 0, "op_philox_uniform: bad arguments");
+        launch_philox_fill(out, n, seed, iter, stream_id, V, (hipStream_t)stream);
     });
 }
 

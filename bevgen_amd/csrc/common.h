@@ -127,6 +127,36 @@ __device__ __forceinline__ float exp_softmax(float x) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }
 
+// Philox4x32-10 counter-based generator (Salmon et al. 2011): uniform in [0,1) with 24 random bits for element `idx` of noise stream (iter, stream) under `seed`.
+// Stateless: the MaskGit samplers draw their gumbel / critic uniforms in registers instead of reading [timesteps, rows, T, V] tensors (1.8 GB at the bench size).
+__host__ __device__ inline unsigned philox_mulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+struct Philox4 { unsigned v[4]; };
+__host__ __device__ inline Philox4 philox4(unsigned long long seed, unsigned long long idx, unsigned iter, unsigned stream) {
+    unsigned c0 = (unsigned)idx, c1 = (unsigned)(idx >> 32), c2 = iter, c3 = stream;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned h0 = philox_mulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const unsigned h1 = philox_mulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{{c0, c1, c2, c3}};
+}
+__host__ __device__ inline float philox_to_unit(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+// stream 1 (critic noise, one value per row): element idx -> word 0 of block idx
+__host__ __device__ inline float philox_uniform(unsigned long long seed, unsigned long long idx, unsigned iter, unsigned stream) {
+    return philox_to_unit(philox4(seed, idx, iter, stream).v[0]);
+}
+// stream 0 (gumbel noise, V values per row, consumed by a wave whose lane l holds elements l + 64 j): element (row, i) -> word (j & 3) of block
+// row * V + l + 256 (j >> 2), l = i % 64, j = i / 64: one Philox block serves four of a lane's values
+__host__ __device__ inline void philox_gumbel_block(long row, int V, int i, unsigned long long& block, int& word) {
+    const int l = i & 63, j = i >> 6;
+    block = (unsigned long long)(row * V + l + 256 * (j >> 2));
+    word = j & 3;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

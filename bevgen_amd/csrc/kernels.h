@@ -235,10 +235,11 @@ void launch_ar_kv_append(const float* qkv, void* kcache, void* vcache, int kv_dt
 void launch_remask(int64_t* ids, const float* scores, const int64_t* init_ids /*or null*/, int rows, int T, int n_mask, int64_t mask_id, hipStream_t s);
 // MaskGit token pick (muse_net:587-599): top-k filter, /max(temp,1e-10), + gumbel(u), argmax; only masked positions are overwritten
 void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float* gumbel_u /*or null*/, int rows, int V, int k, float temperature,
-                         int64_t mask_id, hipStream_t s);
+                         int64_t mask_id, hipStream_t s, unsigned long long seed = 0 /* != 0 and gumbel_u null: uniforms from Philox(seed, iter) */, unsigned iter = 0);
 // Self-critic scores (muse_net:392-396, 602-611): scores = embed . w + b + ((u - 0.5) * noise_scale) * frac
 void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u /*or null*/, float noise_scale, float frac,
-                          float* scores, int rows, int D, hipStream_t s);
+                          float* scores, int rows, int D, hipStream_t s, unsigned long long seed = 0, unsigned iter = 0);
+void launch_philox_fill(float* out, long n, unsigned long long seed, unsigned iter, unsigned stream, int V /* stream 0: vocabulary size (row layout) */, hipStream_t s);
 // Route A token pick (ar_lm:204-219): logits/temperature, top-k (ties kept), softmax, argmax or inverse-CDF draw with explicit u
 //   forced [steps, rows] (or null): entries >= 0 are emitted instead of a drawn token (partial decoding, ar_lm:161-165,181-182)
 void launch_ar_pick(const float* logits, int ldl, const float* u /*[steps, rows] or null*/, const int* d_step /*or null: u is this step's row*/, const int64_t* forced,

@@ -242,7 +242,8 @@ void muse_forward(Ctx& c, const int64_t* ids, const int64_t* cond, const float* 
 }
 
 void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
-                      int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, hipStream_t s) {
+                      int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, hipStream_t s,
+                      unsigned long long noise_seed) {
     BG_REQUIRE(c.cfg.route == BEVGEN_ROUTE_MASKGIT, "context was not created for the MaskGit route");
     BG_REQUIRE(B >= 1 && timesteps >= 1 && sched, "bad generate arguments");
     MuseWs w;
@@ -262,11 +263,12 @@ void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const flo
         launch_remask(ids, scores, init_ids, seqs, T, sched[step], mask_id, s);
         muse_blocks(c, w, ids, s);
         gemm(w.xn, D, c.pf("transformer.to_logits.weight"), D, logits, V, rows, V, D, nullptr, 0, s);
-        launch_maskgit_pick(ids, logits, V, gumbel_u ? gumbel_u + (size_t)step * rows * V : nullptr, rows, V, topk_k, (float)((double)temperature * frac), mask_id, s);
+        launch_maskgit_pick(ids, logits, V, gumbel_u ? gumbel_u + (size_t)step * rows * V : nullptr, rows, V, topk_k, (float)((double)temperature * frac), mask_id, s,
+                            noise_seed, (unsigned)step);
         if (step + 1 < timesteps) {  // the critic scores only select what the NEXT iteration re-masks
             muse_blocks(c, w, ids, s);
             launch_critic_scores(w.xn, D, c.pf("token_critic.to_pred.weight"), c.pf("token_critic.to_pred.bias"),
-                                 critic_u ? critic_u + (size_t)step * rows : nullptr, critic_noise_scale, (float)frac, scores, rows, D, s);
+                                 critic_u ? critic_u + (size_t)step * rows : nullptr, critic_noise_scale, (float)frac, scores, rows, D, s, noise_seed, (unsigned)step);
         }
     }
 }

@@ -70,7 +70,7 @@ void launch_remask(int64_t* ids, const float* scores, const int64_t* init_ids, i
 
 // ---------------------------------------------------------------------------------------------- MaskGit token pick
 __global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__ ids, const float* __restrict__ logits, int ldl, const float* __restrict__ gumbel_u,
-                                                           long rows, int V, int k, float temp_div, int64_t mask_id) {
+                                                           long rows, int V, int k, float temp_div, int64_t mask_id, unsigned long long seed, unsigned iter) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -86,17 +86,21 @@ __global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__
         x[j] = valid[j] ? lr[i] : 0.f;
         key[j] = ordered_key(x[j]);
     }
+    const bool noisy = gumbel_u != nullptr || seed != 0;   // explicit uniforms, or drawn in registers (Philox keyed by seed / iteration / element)
     uint32_t thr = 0;
-    if (gumbel_u) thr = kth_largest_key(key, valid, k);  // without noise the arg-max is unaffected by the top-k filter
+    if (noisy) thr = kth_largest_key(key, valid, k);  // without noise the arg-max is unaffected by the top-k filter
     float best = -INFINITY;
     int bidx = 0x7fffffff;
+    Philox4 ph{};
 #pragma unroll
     for (int j = 0; j < VPL_MAX; ++j) {
         const int i = lane + 64 * j;
-        if (!valid[j] || key[j] < thr) continue;
+        if (!valid[j]) continue;
+        if (!gumbel_u && seed && (j & 3) == 0) ph = philox4(seed, (unsigned long long)(row * V + lane + 256 * (j >> 2)), iter, 0u);   // philox_gumbel_block(row, V, i)
+        if (key[j] < thr) continue;
         float v = x[j] / temp_div;
-        if (gumbel_u) {
-            const float u = gumbel_u[row * V + i];
+        if (noisy) {
+            const float u = gumbel_u ? gumbel_u[row * V + i] : philox_to_unit(ph.v[j & 3]);
             const float l1 = logf(fmaxf(u, 1e-20f));
             v += -logf(fmaxf(-l1, 1e-20f));
         }
@@ -106,16 +110,18 @@ __global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__
     if (lane == 0) ids[row] = bidx;
 }
 
-void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float* gumbel_u, int rows, int V, int k, float temperature, int64_t mask_id, hipStream_t s) {
+void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float* gumbel_u, int rows, int V, int k, float temperature, int64_t mask_id, hipStream_t s,
+                         unsigned long long seed, unsigned iter) {
     BG_REQUIRE(V <= 64 * VPL_MAX, "maskgit_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
     const float temp_div = fmaxf(temperature, 1e-10f);
-    hipLaunchKernelGGL(maskgit_pick_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, logits, ldl, gumbel_u, (long)rows, V, k, temp_div, mask_id);
+    hipLaunchKernelGGL(maskgit_pick_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, logits, ldl, gumbel_u, (long)rows, V, k, temp_div, mask_id, seed, iter);
     LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------------- self-critic scores
 __global__ __launch_bounds__(256) void critic_scores_kernel(const float* __restrict__ embed, int lde, const float* __restrict__ w, const float* __restrict__ b,
-                                                            const float* __restrict__ u, float noise_scale, float frac, float* __restrict__ scores, long rows, int D) {
+                                                            const float* __restrict__ u, float noise_scale, float frac, float* __restrict__ scores, long rows, int D,
+                                                            unsigned long long seed, unsigned iter) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -129,15 +135,16 @@ __global__ __launch_bounds__(256) void critic_scores_kernel(const float* __restr
     acc = wave_sum(acc);
     if (lane == 0) {
         float sc = acc + b[0];
-        const float uu = u ? u[row] : 0.5f;
+        const float uu = u ? u[row] : (seed ? philox_uniform(seed, (unsigned long long)row, iter, 1u) : 0.5f);
         sc += ((uu - 0.5f) * noise_scale) * frac;
         scores[row] = sc;
     }
 }
 
-void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u, float noise_scale, float frac, float* scores, int rows, int D, hipStream_t s) {
+void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u, float noise_scale, float frac, float* scores, int rows, int D, hipStream_t s,
+                          unsigned long long seed, unsigned iter) {
     BG_REQUIRE(D % 4 == 0, "critic_scores: D must be a multiple of 4");
-    hipLaunchKernelGGL(critic_scores_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, embed, lde, w, b, u, noise_scale, frac, scores, (long)rows, D);
+    hipLaunchKernelGGL(critic_scores_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, embed, lde, w, b, u, noise_scale, frac, scores, (long)rows, D, seed, iter);
     LAUNCH_CHECK();
 }
 
@@ -217,6 +224,23 @@ void launch_ar_pick(const float* logits, int ldl, const float* u, const int* d_s
                     hipStream_t s) {
     BG_REQUIRE(V <= 64 * VPL_MAX, "ar_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
     hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, d_step, forced, out, V, top_k, temperature);
+    LAUNCH_CHECK();
+}
+
+// the uniforms the samplers draw in registers, written out (tests: explicit-noise run == seeded run)
+__global__ void philox_fill_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned iter, unsigned stream, int V) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        if (stream == 0 && V > 0) {   // gumbel stream: the per-row block layout of maskgit_pick_kernel
+            unsigned long long block; int word;
+            philox_gumbel_block(i / V, V, (int)(i % V), block, word);
+            out[i] = philox_to_unit(philox4(seed, block, iter, 0u).v[word]);
+        } else {
+            out[i] = philox_uniform(seed, (unsigned long long)i, iter, stream);
+        }
+    }
+}
+void launch_philox_fill(float* out, long n, unsigned long long seed, unsigned iter, unsigned stream, int V, hipStream_t s) {
+    hipLaunchKernelGGL(philox_fill_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, out, n, seed, iter, stream, V);
     LAUNCH_CHECK();
 }
 

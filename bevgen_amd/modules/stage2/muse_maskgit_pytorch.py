@@ -134,8 +134,8 @@ class MaskGit(nn.Module):
     def generate(self, init_ids: Optional[torch.Tensor] = None, cond_images: Optional[torch.Tensor] = None, fmap_size=None, temperature=1.0,
                  topk_filter_thres=0.9, can_remask_prev_masked=False, force_not_use_token_critic=False, timesteps=12, cond_scale=3,
                  critic_noise_scale=1, batch=None, noise=None):
-        """muse_net:511-627.  ``noise``: None -> draw the uniforms from torch's device RNG (stochastic, like the reference);
-        'greedy' -> gumbel noise 0 / critic uniform 0.5; or {'gumbel_u','critic_u'} explicit uniforms."""
+        """muse_net:511-627.  ``noise``: None -> stochastic like the reference (uniforms drawn in the sampler kernels, seeded from torch's generator);
+        an int -> that seed; 'greedy' -> gumbel noise 0 / critic uniform 0.5; or {'gumbel_u','critic_u'} explicit uniforms."""
         if force_not_use_token_critic or can_remask_prev_masked:
             raise NotImplementedError("only the token-critic scoring path of the shipped configuration is implemented")
         cfg = self.transformer.cfg
@@ -144,15 +144,21 @@ class MaskGit(nn.Module):
             raise ValueError(f"fmap_size {tuple(fmap_size)} != cam_latent_res {(cfg.cam_latent_h, cfg.cam_latent_w)}")
         B = len(cond_images)
         rows, T, V = B * cfg.num_cams, cfg.num_cam_tokens, cfg.vocab_size
+        gu = cu = None
+        seed = 0
         if noise is None:
-            gu = torch.rand((timesteps, rows, T, V), device=ctx.device)
-            cu = torch.rand((timesteps, rows, T), device=ctx.device)
+            # stochastic like the reference: the uniforms are drawn inside the sampler kernels (Philox keyed by a seed taken from torch's CPU generator, so
+            # torch.manual_seed / pl.seed_everything make a run reproducible); nothing of size [timesteps, rows, T, V] is ever materialised
+            seed = int(torch.randint(1, 2 ** 62, (), dtype=torch.int64).item())
+        elif isinstance(noise, int):
+            seed = noise
         elif isinstance(noise, str) and noise == "greedy":
-            gu = cu = None
+            pass
         else:
             gu, cu = noise["gumbel_u"], noise["critic_u"]
         return ctx.maskgit_generate(cond_images, batch["intrinsics_inv"], batch["extrinsics_inv"], timesteps=timesteps, temperature=temperature,
-                                    topk_filter_thres=topk_filter_thres, critic_noise_scale=critic_noise_scale, gumbel_u=gu, critic_u=cu, init_ids=init_ids)
+                                    topk_filter_thres=topk_filter_thres, critic_noise_scale=critic_noise_scale, gumbel_u=gu, critic_u=cu, init_ids=init_ids,
+                                    noise_seed=seed)
 
     @torch.no_grad()
     def transformer_forward(self, x, conditioning_token_ids, batch, return_embed=False):

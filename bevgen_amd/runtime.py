@@ -179,7 +179,8 @@ class Context:
         return logits, embed
 
     def maskgit_generate(self, cond_ids, I_inv, E_inv, *, timesteps=18, temperature=1.0, topk_filter_thres=0.9, critic_noise_scale=1.0,
-                         gumbel_u=None, critic_u=None, init_ids=None):
+                         gumbel_u=None, critic_u=None, init_ids=None, noise_seed=0):
+        """gumbel_u / critic_u: explicit uniforms (parity tests); else noise_seed != 0: the samplers draw them in registers (Philox); else deterministic."""
         cfg = self.cfg
         d = self.device
         cond_ids = _req(cond_ids, torch.int64, d, "cond_ids")
@@ -201,8 +202,14 @@ class Context:
         out = torch.empty((rows, T), dtype=torch.int64, device=d)
         self._check(self.lib.bevgen_maskgit_generate(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, timesteps, sched_c, float(temperature),
                                                       topk_count(topk_filter_thres, cfg.vocab_size), float(critic_noise_scale), _ptr(gumbel_u), _ptr(critic_u),
-                                                      _ptr(init_ids), _ptr(out), self._s()))
+                                                      _ptr(init_ids), _ptr(out), C.c_uint64(int(noise_seed) & 0xFFFFFFFFFFFFFFFF), self._s()))
         return out.reshape(rows, cfg.cam_latent_h, cfg.cam_latent_w)
+
+    def philox_uniform(self, seed, it, stream_id, n, V=0):
+        """The uniforms maskgit_generate(noise_seed=seed) draws at iteration `it` (stream 0: gumbel [rows*V], 1: critic [rows])."""
+        out = torch.empty((n,), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_op_philox_uniform(self._h, C.c_uint64(int(seed)), int(it), int(stream_id), int(V), int(n), _ptr(out), self._s()))
+        return out
 
     # ------------------------------------------------------------------------------------------ Route A
     def sparse_self_attention(self, q, k, v, layout, attn_mask, add_mask, block):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BEVGEN_ABI_VERSION 2
+#define BEVGEN_ABI_VERSION 3
 
 enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
 /* FP32  : every product and accumulation in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32) - bit-exact greedy tokens vs the CPU reference.
@@ -123,13 +123,17 @@ int bevgen_muse_forward(bevgen_ctx* ctx, const int64_t* d_ids, const int64_t* d_
  *   topk_k                      ceil((1 - topk_filter_thres) * V) (:453-454)
  *   d_gumbel_u [timesteps, B*C, T, V], d_critic_u [timesteps, B*C, T]  explicit U[0,1) noise replacing :430-431/:446-448,
  *                               NULL = deterministic setting (gumbel noise 0, critic uniform 0.5)
+ *   noise_seed                  used when the explicit tensors are NULL: != 0 -> the samplers draw their uniforms in registers (Philox4x32-10 keyed by
+ *                               (noise_seed, iteration, element): stream 0 = gumbel [rows*V], stream 1 = critic [rows]; bevgen_op_philox_uniform writes the
+ *                               same numbers out) - stochastic sampling without 1.8 GB of noise tensors; 0 -> the deterministic setting
  *   d_init_ids [B*C, T] or NULL (partial decoding, :543-544, 573-574)
  *   -> d_out_ids [B*C, T]
  * The classifier-free-guidance "null" forwards of the reference (:272-276, 394-396) are bit-identical to the conditional
  * ones in eval mode and are not executed; the critic forward after the last iteration (result unused) is skipped. */
 int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_I_inv, const float* d_E_inv, int B,
                             int timesteps, const int32_t* h_mask_schedule, float temperature, int topk_k, float critic_noise_scale,
-                            const float* d_gumbel_u, const float* d_critic_u, const int64_t* d_init_ids, int64_t* d_out_ids, void* stream);
+                            const float* d_gumbel_u, const float* d_critic_u, const int64_t* d_init_ids, int64_t* d_out_ids,
+                            unsigned long long noise_seed, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Route A - autoregressive sparse-causal transformer with camera bias (prefill + KV-cache decode)                 */
@@ -198,6 +202,9 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_w, const fl
  * d_c receives the split-K partial sums [ksplit, M, N] that the consumer adds; ksplit 0 = the library's choice for (N, K), returned through *ksplit_out if non-NULL. */
 int bevgen_op_ln_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w, const float* d_bias, float* d_c,
                       int M, int N, int K, int act_gelu, int ksplit, int* ksplit_out, void* stream);
+/* d_out[i] = the uniform the MaskGit samplers draw for element i of noise stream `stream_id` (0 gumbel, 1 critic) at iteration `iter` under `seed`. */
+int bevgen_op_philox_uniform(bevgen_ctx* ctx, unsigned long long seed, unsigned iter, unsigned stream_id, int V /* vocabulary size: row layout of stream 0 */, long n,
+                             float* d_out, void* stream);
 int bevgen_op_layernorm(bevgen_ctx* ctx, const float* d_x, const float* d_gamma, const float* d_beta, float* d_y, int rows, int D, float eps, void* stream);
 int bevgen_op_geglu_layernorm(bevgen_ctx* ctx, const float* d_h, const float* d_gamma, float* d_y, int rows, int F, int ldy, void* stream);
 int bevgen_op_attention(bevgen_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, const float* d_bias, int ldbias,
