@@ -207,17 +207,26 @@ __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ l
     }
     const float total = __shfl(incl, 63, 64);
     const float target = u[row] * total;
+    // first index (in vocabulary order) that carries probability AND whose cumulative sum exceeds the target.  The running sum is rebuilt per lane from
+    // a cross-lane scan, so it need not be monotone across lane boundaries to the last bit: selecting by "first crossing with e > 0" (per-lane candidate,
+    // wave minimum) can never land on a top-k-filtered token, unlike counting the entries below the target.
     float run = incl - local;
-    int cnt = 0;
+    int cand = 0x7fffffff, last = -1;
 #pragma unroll
     for (int j = 0; j < VPL_MAX; ++j) {
         if (!valid[j]) continue;
         run += e[j];
-        cnt += (run <= target) ? 1 : 0;
+        if (e[j] > 0.f) {
+            last = lane * per + j;
+            if (run > target && cand == 0x7fffffff) cand = lane * per + j;
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) out[row] = min(cnt, V - 1);
+    for (int o = 32; o > 0; o >>= 1) {
+        cand = min(cand, __shfl_xor(cand, o, 64));
+        last = max(last, __shfl_xor(last, o, 64));
+    }
+    if (lane == 0) out[row] = cand != 0x7fffffff ? cand : last;   // u * total rounding up to the total: the last token with probability
 }
 
 void launch_ar_pick(const float* logits, int ldl, const float* u, const int* d_step, const int64_t* forced, int64_t* out, int rows, int V, int top_k, float temperature,
