@@ -286,6 +286,8 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     out = {
         "ms_per_decode_step": wall * 1e3 / steps, "ms_per_decode_step_median": pct(st, 50), "ms_per_decode_step_p99": pct(st, 99), "decode_prefill_ms": prefill_ms,
         "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                      "frac_by_survey_8d_fp16_bytes": ach / HBM_PEAK_GBS * (2.0 / kvb),   # SURVEY 8(d) counts 98 304 n bytes per sequence-step (fp16 K/V) whatever the storage
+
                                       "traffic": pmc_traffic("ar_attn_fused_kernel") if kv_cache == "f32" and weights == "f32" and S == 1 else None, "kernel": "ar_attn_fused_kernel (ln1 + q/k/v projection + decode attention in one launch; achieved = K/V bytes / WHOLE kernel time)",
                                       "attention_phase": {"GBs": phase_bytes / (phase_us * 1e-6) / 1e9 if phase_us else None, "frac": phase_bytes / (phase_us * 1e-6) / 1e9 / HBM_PEAK_GBS if phase_us else None,
                                                           "us": phase_us, "context": n_last, "note": "K/V streaming phase alone, device timestamps of one launch"},
