@@ -95,17 +95,27 @@ def pct(xs, q):
     return float(np.percentile(np.asarray(xs, dtype=np.float64), q)) if len(xs) else None
 
 
+_SD_CACHE = {}
+
+
+def cached(key, make):
+    """Synthetic weights are regenerated from (seed, parameter name) on the host: seconds per model, so every leg of one run shares them."""
+    if key not in _SD_CACHE:
+        _SD_CACHE[key] = make()
+    return _SD_CACHE[key]
+
+
 def build_route_m(cams, batch, device, precision="fp32"):
     from bevgen_amd import presets
     from bevgen_amd.runtime import Context
     from bevgen_amd.weights import maskgit_state_dict, vq_state_dict
 
     cfg = presets.config2(cams)
-    sd = maskgit_state_dict(cfg, 1234)
+    sd = cached(("maskgit", cams), lambda: maskgit_state_dict(cfg, 1234))
     dd = presets.VQ_DDCONFIG_F16
     ctx = Context(cfg, route="maskgit", vq_ddconfig=dd, vq_n_embed=1024, vq_embed_dim=256, device=device, max_batch=batch, precision=precision)
     ctx.load_state_dict(sd)
-    ctx.load_state_dict(vq_state_dict(dd, 1024, 256, 99), prefix="first_stage_model.")
+    ctx.load_state_dict(cached(("vq",), lambda: vq_state_dict(dd, 1024, 256, 99)), prefix="first_stage_model.")
     ctx.set_tables()
     ctx.finalize()
     return cfg, ctx, sd
@@ -235,7 +245,7 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
 
     cfg = presets.config4()
     ctx = Context(cfg, route="ar", device=device, max_batch=batch, kv_cache=kv_cache, decode_weights=weights)
-    ctx.load_state_dict(gpt_state_dict(cfg, 1234))
+    ctx.load_state_dict(cached(("gpt", "config4"), lambda: gpt_state_dict(cfg, 1234)))
     ctx.set_tables()
     ctx.finalize()
     bt = synthetic.make_batch(cfg, batch // S, seed=0)
