@@ -118,7 +118,12 @@ struct AttnSplitArgs {
     float scale;
     long o_bstride, o_qstride, o_hstride;
     _Float16* Op;   // non-null: write the output as interleaved (hi, lo) planes of the [B*Nq, H*64] matrix instead of fp32 O
+    const float* bias_pk = nullptr;   // packed bias image (launch_pack_attn_bias); same head stride convention as `bias`
+    int bias_tile_step = 0, bias_pk_tile_step = 0;   // set by the launcher
+    long bias_pk_qb_stride = 0;
 };
+long attn_bias_packed_floats(int Nq, int Nk_pad);
+void launch_pack_attn_bias(const float* bias, int ld, int Nq, int Nk_pad, float* out, hipStream_t s);
 void launch_attention_split(const AttnSplitArgs& a, hipStream_t s);
 void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, float post, hipStream_t s);
 void launch_muse_null_kv_prep(const float* null_kv, const float* k_scale, void* out /* 4*H*64 halves */, int H, hipStream_t s);
