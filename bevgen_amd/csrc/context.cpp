@@ -207,6 +207,11 @@ static void finalize_muse(Ctx& c) {
     if (g.precision == BEVGEN_PRECISION_F16X3) {  // the split-precision attention kernel evaluates the softmax as 2^x (kernels.h)
         launch_scale(c.bias_self, (long)c.N * c.ldS, kLog2e, 0);
         launch_scale(c.bias_cross, (long)c.N * c.ldC, kLog2e, 0);
+        // ... and reads them as packed images: one wave load instruction = 1 KiB contiguous, in the accumulator order of its 32 x 32 score tile
+        c.bias_self_pk = reinterpret_cast<float*>(c.own(attn_bias_packed_floats(c.N, c.NkS_pad) * sizeof(float)));
+        c.bias_cross_pk = reinterpret_cast<float*>(c.own(attn_bias_packed_floats(c.N, c.NkC_pad) * sizeof(float)));
+        launch_pack_attn_bias(c.bias_self, c.ldS, c.N, c.NkS_pad, c.bias_self_pk, 0);
+        launch_pack_attn_bias(c.bias_cross, c.ldC, c.N, c.NkC_pad, c.bias_cross_pk, 0);
     }
 }
 

@@ -112,14 +112,15 @@ void launch_attention(const AttnArgs& a, hipStream_t s);
 constexpr float kLog2e = 1.44269504088896340736f;
 struct AttnSplitArgs {
     const _Float16 *Qh, *Ql, *Kh, *Kl, *VTh, *VTl;
-    const float* bias; float* O;
+    const float* bias;   // row-major [Nq, ldbias]: read only by the round-1 kernel of tools/attn_lab
+    float* O;
     int B, H, Nq, Nk_pad;
     int ldbias; long bias_head_stride;
     float scale;
     long o_bstride, o_qstride, o_hstride;
     _Float16* Op;   // non-null: write the output as interleaved (hi, lo) planes of the [B*Nq, H*64] matrix instead of fp32 O
-    const float* bias_pk = nullptr;   // packed bias image (launch_pack_attn_bias); same head stride convention as `bias`
-    int bias_tile_step = 0, bias_pk_tile_step = 0;   // set by the launcher
+    const float* bias_pk = nullptr;   // packed bias image (launch_pack_attn_bias) of the [Nq, Nk_pad] bias, or null; bias_head_stride applies to it
+    int bias_pk_tile_step = 0;        // set by the launcher
     long bias_pk_qb_stride = 0;
 };
 long attn_bias_packed_floats(int Nq, int Nk_pad);

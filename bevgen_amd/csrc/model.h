@@ -76,6 +76,7 @@ struct Ctx {
     // ---- Route M
     std::vector<MuseLayer> muse;
     float *bias_self = nullptr, *bias_cross = nullptr;  // [N, ldS] / [N, ldC] with the null-key column and masks baked in
+    float *bias_self_pk = nullptr, *bias_cross_pk = nullptr;  // the same two matrices as packed images for attention_split (launch_pack_attn_bias)
     int ldS = 0, ldC = 0, NkS_pad = 0, NkC_pad = 0;
 
     // ---- Route A

@@ -159,7 +159,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         AttnSplitArgs sa{};
         if (split) {
             sa.Qh = Qh; sa.Ql = Qh + qN; sa.Kh = Ksh; sa.Kl = Ksh + kvS; sa.VTh = VTsh; sa.VTl = VTsh + kvS;
-            sa.bias = c.bias_self; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
+            sa.bias = c.bias_self; sa.bias_pk = c.bias_self_pk; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
             sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f * kLog2e;
             sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
             sa.Op = reinterpret_cast<_Float16*>(w.att);
@@ -189,7 +189,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         if (split) {
             _Float16 *ckh = reinterpret_cast<_Float16*>(w.crossK[i]), *cvh = reinterpret_cast<_Float16*>(w.crossV[i]);
             sa.Kh = ckh; sa.Kl = ckh + kvC; sa.VTh = cvh; sa.VTl = cvh + kvC;
-            sa.bias = c.bias_cross; sa.Nk_pad = c.NkC_pad; sa.ldbias = c.ldC;
+            sa.bias = c.bias_cross; sa.bias_pk = c.bias_cross_pk; sa.Nk_pad = c.NkC_pad; sa.ldbias = c.ldC;
             launch_attention_split(sa, s);
         } else {
             launch_muse_q_prep(w.qraw, l.q_scale[1], w.Q, B, H, N, s);
