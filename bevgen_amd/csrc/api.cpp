@@ -41,6 +41,8 @@ int bevgen_create(const bevgen_cfg* cfg, int device, bevgen_ctx** out) {
         BG_REQUIRE(cfg->route == BEVGEN_ROUTE_MASKGIT || cfg->route == BEVGEN_ROUTE_AR, "bevgen_create: unknown route %d", cfg->route);
         BG_REQUIRE(cfg->kv_cache_dtype == BEVGEN_KV_F32 || cfg->kv_cache_dtype == BEVGEN_KV_F16, "bevgen_create: kv_cache_dtype must be BEVGEN_KV_F32 or BEVGEN_KV_F16");
         BG_REQUIRE(cfg->precision == BEVGEN_PRECISION_FP32 || cfg->precision == BEVGEN_PRECISION_F16X3, "bevgen_create: precision must be BEVGEN_PRECISION_FP32 or BEVGEN_PRECISION_F16X3");
+        BG_REQUIRE(cfg->weight_dtype == BEVGEN_W_F32 || (cfg->weight_dtype == BEVGEN_W_F16 && cfg->precision == BEVGEN_PRECISION_F16X3),
+                   "bevgen_create: weight_dtype must be BEVGEN_W_F32, or BEVGEN_W_F16 together with BEVGEN_PRECISION_F16X3");
         int ndev = 0;
         HIP_CHECK(hipGetDeviceCount(&ndev));
         BG_REQUIRE(device >= 0 && device < ndev, "bevgen_create: device %d not present (%d visible)", device, ndev);

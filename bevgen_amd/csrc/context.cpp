@@ -32,8 +32,12 @@ void Arena::release() {
 void Ctx::split_weight(const float* w, long n) {
     if (cfg.precision != BEVGEN_PRECISION_F16X3 || split.count(w)) return;
     void* planes = own((size_t)n * 4);
+    const bool w16 = cfg.weight_dtype == BEVGEN_W_F16;
+    // weight_dtype = f16: the model becomes the one whose matrices are f16-representable (rounded once, in place, so that every other consumer of
+    // the fp32 copy sees the same values); the low plane is then zero and the GEMM issues two MFMAs per product instead of three
+    if (w16) launch_round_to_f16(const_cast<float*>(w), nullptr, n, 0);
     launch_split_weight(w, planes, n, 0);
-    split[w] = SplitPlanes{reinterpret_cast<const uint16_t*>(planes), reinterpret_cast<const uint16_t*>(planes) + 32};
+    split[w] = SplitPlanes{reinterpret_cast<const uint16_t*>(planes), reinterpret_cast<const uint16_t*>(planes) + 32, w16};
 }
 
 void Ctx::retire_graph(hipGraphExec_t e, hipGraph_t g) {
@@ -225,6 +229,7 @@ static void finalize_ar(Ctx& c) {
     expect_shape(c, "head.weight", {g.vocab_size, D});
     const bool wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
     BG_REQUIRE(!wf16 || (g.decode_path == BEVGEN_DECODE_FUSED && D % 256 == 0), "decode_weights = f16 needs the fused decode path and dim %% 256 == 0 (dim = %d)", D);
+    BG_REQUIRE(g.weight_dtype != BEVGEN_W_F16 || wf16, "Route A: weight_dtype = f16 needs decode_weight_dtype = f16 as well (prefill and decode must run ONE rounded model)");
     c.ar.resize(g.num_layers);
     for (int i = 0; i < g.num_layers; ++i) {
         ArLayer& l = c.ar[i];

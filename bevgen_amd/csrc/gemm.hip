@@ -203,6 +203,7 @@ void launch_gemm(const GemmArgs& g_in, hipStream_t stream) {
             GemmArgs s = g;
             s.B_hi = it->second.hi;
             s.B_lo = it->second.lo;
+            s.b_lo_zero = it->second.lo_zero;
             if (s.A_hi) return launch_gemm_split_glds(s, stream);
             return launch_gemm_split(s, stream);
         }

@@ -43,7 +43,9 @@ __device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE, int WM, int S>
+// W16: the B operand (a weight matrix) is f16-representable, its low plane is zero: the product is  b_hi a_hi + 2^-11 b_hi a_lo  - TWO MFMAs per
+// k-step pair instead of three, and no low-plane fragment reads (weight_dtype = f16 contexts)
+template <int MODE, int WM, int S, bool W16 = false>
 __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
     constexpr int TBM = WM * 64;                 // block rows
     constexpr int NW = WM * 2;                   // waves
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
             f.ah[i] = *reinterpret_cast<const half8*>(st + a_rd[i][ks]);
             f.al[i] = *reinterpret_cast<const half8*>(st + (a_rd[i][ks] ^ 32));
             f.bh[i] = *reinterpret_cast<const half8*>(st + b_rd[i][ks]);
-            f.bl[i] = *reinterpret_cast<const half8*>(st + (b_rd[i][ks] ^ 32));
+            if (!W16) f.bl[i] = *reinterpret_cast<const half8*>(st + (b_rd[i][ks] ^ 32));
         }
     };
     auto mma_main = [&](const Frag& f) {
@@ -162,6 +164,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
             for (int j = 0; j < 2; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], accM[i][j], 0, 0, 0);
     };
     auto mma_c1 = [&](const Frag& f) {
+        if (W16) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -470,18 +473,28 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
 #undef BG_SET
         attr_set = true;
     }
     ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : PROF_GEMM, 2.0 * g.M * (double)g.N * g.K, stream);
     const bool conv = g.mode == MODE_CONV3;
+#define BG_LAUNCH(MODE_, WM_, S_, THREADS)                                                                                           \
+    do {                                                                                                                             \
+        if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, true>), grid, dim3(THREADS), lds, stream, g);    \
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, false>), grid, dim3(THREADS), lds, stream, g);               \
+    } while (0)
     if (wm == 2) {
-        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), grid, dim3(256), lds, stream, g);
-        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), grid, dim3(256), lds, stream, g);
+        if (conv) BG_LAUNCH(MODE_CONV3, 2, 2, 256);
+        else BG_LAUNCH(MODE_PLAIN, 2, 2, 256);
     } else {
-        if (conv) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), grid, dim3(512), lds, stream, g);
-        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), grid, dim3(512), lds, stream, g);
+        if (conv) BG_LAUNCH(MODE_CONV3, 4, 3, 512);
+        else BG_LAUNCH(MODE_PLAIN, 4, 3, 512);
     }
+#undef BG_LAUNCH
     LAUNCH_CHECK();
 }
 

@@ -33,6 +33,7 @@ struct GemmArgs {
     // null = exact fp32 MFMA path
     const uint16_t* B_hi = nullptr;
     const uint16_t* B_lo = nullptr;
+    bool b_lo_zero = false;   // B's low plane is all zeros (f16-rounded weight): the LDS-DMA kernel skips the b_lo a_hi product
     // LDS-DMA path (gemm_split_glds.hip): A also arrives as interleaved (hi, lo) f16 planes ([M][lda/32][2][32] / NHWC pixels x channels),
     // written by the producing kernel; A_lo = A_hi + 32
     const uint16_t* A_hi = nullptr;
@@ -62,7 +63,7 @@ void launch_gemm(const GemmArgs& g, hipStream_t stream);
 void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);
 
 // Split-precision (3x f16 MFMA, fp32-class accuracy) variant and its weight preparation
-struct SplitPlanes { const uint16_t* hi; const uint16_t* lo; };
+struct SplitPlanes { const uint16_t* hi; const uint16_t* lo; bool lo_zero = false; /* the matrix was rounded to f16: its low plane is all zeros */ };
 void launch_gemm_split(const GemmArgs& g, hipStream_t stream);
 void launch_split_weight(const float* w, void* planes /* 2n halves, interleaved (gemm_split.hip) */, long n, hipStream_t s);
 // Table of pre-split weights of the context whose call is executing (null = exact fp32 everywhere): launch_gemm consults it by B pointer.

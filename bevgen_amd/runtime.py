@@ -52,7 +52,8 @@ class Context:
     """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
-                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "fused", decode_weights: str = "f32"):
+                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "fused", decode_weights: str = "f32",
+                 weights: Optional[str] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bevgen_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product")
@@ -79,6 +80,10 @@ class Context:
         # step streams 2-byte weights
         c.decode_weight_dtype = {"f32": _lib.W_F32, "f16": _lib.W_F16}[decode_weights]
         self.decode_weights = decode_weights
+        # weights='f16' (or $BEVGEN_WEIGHTS): the GEMM / convolution matrices are rounded to f16 at finalize - two MFMAs per product instead of three
+        weights = weights or os.environ.get("BEVGEN_WEIGHTS", "f32")
+        c.weight_dtype = {"f32": _lib.W_F32, "f16": _lib.W_F16}[weights]
+        self.weights = weights
         if cfg is not None:
             c.num_layers, c.num_heads, c.dim = cfg.num_layers, cfg.num_heads, cfg.num_embed
             c.vocab_size, c.cond_vocab_size = cfg.vocab_size, cfg.cond_vocab_size

@@ -74,7 +74,13 @@ typedef struct bevgen_cfg {
     int32_t decode_weight_dtype;                       /* Route A projection weights (q/k/v, MLP, head): BEVGEN_W_F32 (default) or BEVGEN_W_F16: bevgen_finalize rounds them to
                                                           fp16-representable values (prefill and decode then use the same model: the reference's Route A runs fp16,
                                                           sparse_self_attention.py:127) and the decode step streams the 2-byte copies: half the weight traffic */
-    int32_t reserved[12];
+    int32_t weight_dtype;                              /* every matrix that feeds a split-precision GEMM / convolution (needs BEVGEN_PRECISION_F16X3): BEVGEN_W_F32
+                                                          (default: hi + lo f16 planes, three MFMAs per product, fp32-class results on the fp32 weights) or BEVGEN_W_F16:
+                                                          bevgen_finalize rounds those matrices to f16 once (the reference's own GPU runs cast them to bf16 / fp16 on
+                                                          every call: muse bf16 autocast, sparse_self_attention.py:127) - activations keep their hi + lo planes, a
+                                                          product is two MFMAs, and the results are fp32-class results OF THE ROUNDED MODEL.  Route A: together with
+                                                          decode_weight_dtype = BEVGEN_W_F16 only */
+    int32_t reserved[11];
 } bevgen_cfg;
 
 typedef struct bevgen_ctx bevgen_ctx;
