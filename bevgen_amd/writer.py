@@ -9,7 +9,11 @@ which is the wire format its evaluation tooling reads (one directory per sample 
                                                             batch carries 'image_paths' and the dataset is nuScenes
 
 ``_XXXXX`` is the 5-character [A-Z0-9] suffix of ``rand_str=True`` (callback.py:93: several samples of one layout do not overwrite each other).
-Not written: the ``viz/<token>.png`` contact sheet and ``bev.png`` (visualisation helpers of the reference, out of scope - DESIGN.md section 8).
+    <save_dir>/viz/<token>.png                              contact sheet (six-view scenes)      (callback.py:76-86)
+    <save_dir>/sample/<token>/bev.png                       class-coloured BEV (rand_str runs)   (callback.py:105)
+The two PNGs are visualisations: same file names and content (generated row over ground-truth row, the BEV rendering beside them; class colours of
+the nuScenes devkit, highest class wins, blended with light grey by confidence - bev_utils/visualize.py:67-107), own layout (the reference composes
+its sheet with the third-party ``image_utils`` package).
 
 MI355X side: the float pixels are converted to uint8 ON THE GPU (``parallel.to_uint8``: round(x*255), clamp) and leave the device in ONE copy per
 batch (1.18 MB per six-view 256x256 scene instead of 4.7 MB of fp32); JPEG encoding runs on a host thread pool off the sampling path - ``flush()``
@@ -38,6 +42,53 @@ def _save_jpeg(chw_u8: np.ndarray, path: Path) -> None:
 
     os.makedirs(path.parent, exist_ok=True)
     Image.fromarray(np.ascontiguousarray(chw_u8.transpose(1, 2, 0))).save(path)
+
+
+# class colours (nuScenes devkit colour map; Argoverse ordering of the 7-channel segmentation after the reference's channel shuffle, visualize.py:86-88)
+_BEV_COLORS = np.array([(110, 110, 110), (130, 130, 130), (255, 200, 0), (255, 127, 80), (0, 0, 230), (255, 158, 0), (255, 99, 71)], dtype=np.float32)
+_BEV_EMPTY = np.array((200, 200, 200), dtype=np.float32)
+_BEV_CHANNEL_ORDER = [4, 5, 6, 3, 1, 0, 2]
+
+
+def render_bev(seg: np.ndarray) -> np.ndarray:
+    """[c, h, w] (or [h, w, c]) class probabilities in [0, 1] (or uint8 0..255) -> [h, w, 3] uint8: per cell the highest class label wins (ties go to the
+    higher index), its colour blended with light grey by its confidence (visualize.py:67-107).  Other channel counts get the palette cyclically."""
+    a = np.asarray(seg, dtype=np.float32)
+    if a.ndim != 3:
+        raise ValueError(f"render_bev: expected a 3-D segmentation, got shape {a.shape}")
+    if a.max() > 1:
+        a = a / 255.0
+    if a.shape[0] < a.shape[1] and a.shape[1] == a.shape[2]:
+        a = a.transpose(1, 2, 0)
+    c = a.shape[-1]
+    if c == len(_BEV_CHANNEL_ORDER):
+        a = a[..., _BEV_CHANNEL_ORDER]
+    colors = _BEV_COLORS[np.arange(c) % len(_BEV_COLORS)]
+    idx = (a + 1e-5 * np.arange(c)[None, None]).argmax(-1)
+    val = np.take_along_axis(a, idx[..., None], -1).clip(0, 1)
+    return np.uint8(val * colors[idx] + (1 - val) * _BEV_EMPTY[None, None])
+
+
+def _resize_nearest(img: np.ndarray, h: int, w: int) -> np.ndarray:
+    ys = (np.arange(h) * img.shape[0] // h).clip(0, img.shape[0] - 1)
+    xs = (np.arange(w) * img.shape[1] // w).clip(0, img.shape[1] - 1)
+    return img[ys][:, xs]
+
+
+def contact_sheet(gen: np.ndarray, gt: Optional[np.ndarray], bev_rgb: np.ndarray) -> np.ndarray:
+    """gen / gt [C, 3, H, W] uint8 -> [rows*H, C*W + H, 3] uint8: the generated views in a row, the ground truth below, the BEV rendering at the right."""
+    rows = [gen] + ([gt] if gt is not None else [])
+    H = gen.shape[-2]
+    bev = _resize_nearest(bev_rgb, H, H)
+    strips = [np.concatenate([np.concatenate([v.transpose(1, 2, 0) for v in r], 1), bev], 1) for r in rows]
+    return np.concatenate(strips, 0)
+
+
+def _save_png(hwc_u8: np.ndarray, path: Path) -> None:
+    from PIL import Image
+
+    os.makedirs(path.parent, exist_ok=True)
+    Image.fromarray(np.ascontiguousarray(hwc_u8)).save(path)
 
 
 def _cam_name(batch: Mapping, cam: int, b: int) -> str:
@@ -81,6 +132,13 @@ class SceneWriter:
                 d = self.save_dir / split / tok
                 os.makedirs(d, exist_ok=True)
                 np.savez_compressed(d / "bev.npz", seg_b)
+            if seg_b.ndim == 3:
+                bev_rgb = render_bev(seg_b)
+                if self.rand_str:                                                        # callback.py:105
+                    self._pending.append(self._pool.submit(_save_png, bev_rgb, self.save_dir / "sample" / tok / "bev.png"))
+                if C == 6:                                                               # callback.py:76-86 (six-view scenes only)
+                    sheet = contact_sheet(gen[b], host.get("gt", None)[b] if "gt" in host else None, bev_rgb)
+                    self._pending.append(self._pool.submit(_save_png, sheet, self.save_dir / "viz" / f"{batch['sample_token'][b]}.png"))
             for cam in range(C):
                 name = _cam_name(batch, cam, b)
                 self._submit(gen[b, cam], self.save_dir / "sample" / tok / f"{name}.jpg")

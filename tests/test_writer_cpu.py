@@ -75,3 +75,40 @@ def test_callback_dropin(tmp_path):
     cb.on_test_batch_end(None, M(), out, batch, 0)
     cb.on_test_end()
     assert (tmp_path / "sample" / "tok000" / "CAM_BACK.jpg").exists() and (tmp_path / "sample_gt" / "tok000" / "bev.npz").exists()
+
+
+def test_bev_rendering_and_contact_sheet(tmp_path):
+    """viz/<token>.png (six-view scenes, callback.py:76-86) and sample/<token>/bev.png (rand_str runs, callback.py:105): the class-colour rule of
+    visualize.py:67-107 on a hand-made map, and the sheet's geometry."""
+    from PIL import Image
+    from bevgen_amd.writer import contact_sheet, render_bev
+
+    seg = np.zeros((7, 8, 8), dtype=np.float32)   # (channel-first is recognised by c < h == w, as in the reference)
+    seg[5, 0, 0] = 1.0            # channel 5 -> slot 1 after the channel shuffle [4,5,6,3,1,0,2]: lane_divider grey
+    seg[0, 1, 1] = 1.0            # channel 0 -> slot 5: vehicle orange
+    seg[0, 2, 2] = seg[1, 2, 2] = 1.0   # a tie: the higher slot wins; channel 0 -> slot 5, channel 1 -> slot 4
+    seg[2, 3, 3] = 0.5            # channel 2 -> slot 6 (large vehicle) at half confidence: blended with the empty colour
+    rgb = render_bev(seg)
+    assert rgb.shape == (8, 8, 3) and rgb.dtype == np.uint8
+    assert tuple(rgb[0, 0]) == (130, 130, 130) and tuple(rgb[1, 1]) == (255, 158, 0) and tuple(rgb[2, 2]) == (255, 158, 0)
+    assert tuple(rgb[3, 3]) == (227, 149, 135)                     # 0.5 (255, 99, 71) + 0.5 (200, 200, 200)
+    assert tuple(rgb[0, 3]) == (200, 200, 200)                     # nothing there
+    assert np.array_equal(render_bev((seg * 255).astype(np.uint8)), rgb)
+
+    cams = ["CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_LEFT", "CAM_BACK", "CAM_BACK_RIGHT"]
+    batch, out = _batch(2, cams), _outputs(2, 6)
+    with SceneWriter(str(tmp_path), rand_str=True, seed=1) as w:
+        toks = w.write(out, batch, dataset=Dataset.NUSCENES)
+    for b, tok in enumerate(toks):
+        sheet = np.asarray(Image.open(tmp_path / "viz" / f"{batch['sample_token'][b]}.png"))
+        assert sheet.shape == (2 * 24, 6 * 40 + 24, 3)             # generated row over ground-truth row, BEV tile at the right
+        gen_u8 = (out["gen"][b] * 255).round().clamp(0, 255).to(torch.uint8).numpy()
+        assert np.abs(sheet[:24, 40:80].astype(int) - gen_u8[1].transpose(1, 2, 0).astype(int)).max() <= 1
+        bev = np.asarray(Image.open(tmp_path / "sample" / tok / "bev.png"))
+        assert np.array_equal(bev, render_bev(batch["segmentation"][b].float().numpy()))
+    # three-camera scenes get no sheet (the reference builds it for six views only)
+    w2 = SceneWriter(str(tmp_path / "c3"))
+    w2.write(_outputs(1, 3), _batch(1, cams[:3]), dataset=Dataset.NUSCENES)
+    w2.close()
+    assert not (tmp_path / "c3" / "viz").exists() and not (tmp_path / "c3" / "sample" / "tok000" / "bev.png").exists()
+    assert contact_sheet(gen_u8, None, render_bev(seg)).shape == (24, 6 * 40 + 24, 3)
