@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One Route M transformer forward at the bench shape (B scenes x 6 views, f16x3) + a VQGAN decode of 16 images, for rocprofv3 passes.
-usage: routem_probe.py [B=16] [precision=f16x3] [zero=0]   (zero=1: all-zero weights / inputs - the same instruction stream at minimum switching power)"""
+usage: routem_probe.py [B=16] [precision=f16x3] [weights=f32|f16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,9 +10,10 @@ from bevgen_amd.weights import maskgit_state_dict, vq_state_dict
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 precision = sys.argv[2] if len(sys.argv) > 2 else "f16x3"
+weights = sys.argv[3] if len(sys.argv) > 3 else "f32"
 cfg = presets.config2(6)
 dd = presets.VQ_DDCONFIG_F16
-ctx = Context(cfg, route="maskgit", vq_ddconfig=dd, vq_n_embed=1024, vq_embed_dim=256, max_batch=B, precision=precision)
+ctx = Context(cfg, route="maskgit", vq_ddconfig=dd, vq_n_embed=1024, vq_embed_dim=256, max_batch=B, precision=precision, weights=weights)
 ctx.load_state_dict(maskgit_state_dict(cfg, 1234))
 ctx.load_state_dict(vq_state_dict(dd, 1024, 256, 99), prefix="first_stage_model.")
 ctx.set_tables()
