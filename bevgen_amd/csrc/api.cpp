@@ -215,13 +215,15 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float*
         g.A = a; g.B = w; g.C = c; g.R = residual; g.bias_n = bias;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
         g.act = act_gelu ? ACT_GELU : ACT_NONE;
-        if (skinny == 3 || skinny == 2) {  // split-precision paths with on-the-fly operand splits (tests / roofline probes): 3 = LDS-DMA kernel
+        if (skinny == 4 || skinny == 3 || skinny == 2) {  // split-precision paths with on-the-fly operand splits (tests / roofline probes): 3 = LDS-DMA kernel, 4 = the same for
+                                                          // an f16-representable w (two MFMAs per product: the weights='f16' mode's kernel)
             ctx->arena.reserve(((size_t)N * K + (size_t)M * K) * 4 + 4096);
             ctx->arena.reset();
             uint16_t* bp = reinterpret_cast<uint16_t*>(ctx->arena.alloc((size_t)N * K * 4));
             launch_split_weight(w, bp, (long)N * K, (hipStream_t)stream);
             g.B_hi = bp; g.B_lo = bp + 32;
-            if (skinny == 3) {
+            if (skinny >= 3) {
+                g.b_lo_zero = skinny == 4;
                 uint16_t* ap = reinterpret_cast<uint16_t*>(ctx->arena.alloc((size_t)M * K * 4));
                 launch_split_weight(a, ap, (long)M * K, (hipStream_t)stream);
                 g.A_hi = ap; g.A_lo = ap + 32;

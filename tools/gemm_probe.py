@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""GEMM probe for PMC / timing: bench-sized Route M projections through bevgen_op_gemm.  usage: gemm_probe.py [mode: 0 fp32 | 2 split | 3 split LDS-DMA] [reps]"""
+"""GEMM probe for PMC / timing: bench-sized Route M projections through bevgen_op_gemm.  usage: gemm_probe.py [mode: 0 fp32 | 2 split | 3 split LDS-DMA | 4 LDS-DMA with f16 weights (two MFMAs per product)] [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,6 +13,7 @@ if len(sys.argv) > 3:   # extra shapes "M,N,K M,N,K ..."
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:]]
 for (M, N, K) in shapes:
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.03
+    if mode == 4: w = w.half().float()
     out = torch.empty(M, N, device="cuda")
     def run():
         ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(a), _ptr(w), None, None, _ptr(out), M, N, K, 0, mode, _stream()))
@@ -22,4 +23,6 @@ for (M, N, K) in shapes:
     torch.cuda.synchronize()
     prof = ctx.profile_end()["gemm"]
     dt = prof["ms"] * 1e-3 / prof["launches"]
-    print(f"mode={mode} M={M} N={N} K={K}: {dt*1e6:.0f} us  {2*M*N*K/dt/1e12:.1f} TF (GEMM kernel only, HIP events)")
+    ref = (a[:64].double() @ w.double().t()).float()
+    err = ((out[:64] - ref).abs().max() / ref.abs().max()).item()
+    print(f"mode={mode} M={M} N={N} K={K}: {dt*1e6:.0f} us  {2*M*N*K/dt/1e12:.1f} TF (GEMM kernel only, HIP events)  rel err of 64 rows vs fp64 {err:.2e}")
