@@ -63,15 +63,20 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = wave >> 2;
     const int qi = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z;
-    const int qrow = blockIdx.x * 256 + wave * 32 + qi;
+    // XCD-aware order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  The q blocks of one (batch, head) read the same K / V planes, so they
+    // are given to ONE XCD: virtual id v = (L % 8) * (total / 8) + L / 8, q block = v % nqb - K / V enter one L2 instead of (up to) all eight
+    const int nqb = gridDim.x, total = nqb * gridDim.y * gridDim.z;
+    const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int vid = (total % 8 == 0) ? (lin % 8) * (total / 8) + lin / 8 : lin;
+    const int qblk = vid % nqb, head = (vid / nqb) % gridDim.y, b = vid / (nqb * gridDim.y);
+    const int qrow = qblk * 256 + wave * 32 + qi;
     const bool qvalid = qrow < a.Nq;
     const int qc = qvalid ? qrow : a.Nq - 1;
 
     const long qoff = ((long)b * a.H + head) * a.Nq * 64 + (long)qc * 64 + 8 * h;
     const long koff = ((long)b * a.H + head) * (long)a.Nk_pad * 64;
     // (no bias: the launcher points bias_pk at a zero block with both steps 0 - unconditional loads, no select in the loop)
-    const float* Bp = a.bias_pk + (long)head * a.bias_head_stride + (long)(blockIdx.x * 8 + wave) * a.bias_pk_qb_stride + lane * 4;
+    const float* Bp = a.bias_pk + (long)head * a.bias_head_stride + (long)(qblk * 8 + wave) * a.bias_pk_qb_stride + lane * 4;
     const int bstep = a.bias_pk_tile_step;
 
     // q_hi, q_hi 2^-11, q_lo 2^-11
