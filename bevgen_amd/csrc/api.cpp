@@ -270,6 +270,34 @@ int bevgen_op_geglu_layernorm(bevgen_ctx* ctx, const float* h, const float* gamm
 int bevgen_op_attention(bevgen_ctx* ctx, const float* q, const float* k, const float* v, const float* bias, int ldbias, int B, int H, int Nq, int Nk_pad, float scale,
                         float* out, void* stream) {
     return guarded(ctx, [&] {
+        if (ctx->cfg.precision == BEVGEN_PRECISION_F16X3) {
+            // the split-precision flash-attention kernel of Route M on caller-supplied fp32 operands: operand images and the packed bias are built here
+            BG_REQUIRE(Nk_pad % 32 == 0 && (bias == nullptr || (ldbias % 4 == 0 && ldbias >= Nk_pad)), "op_attention (split precision): Nk_pad %% 32, bias row stride %% 4 and >= Nk_pad");
+            hipStream_t s = (hipStream_t)stream;
+            const size_t nq = (size_t)B * H * Nq * 64, nk = (size_t)B * H * Nk_pad * 64;
+            const size_t bpk = bias ? (size_t)attn_bias_packed_floats(Nq, Nk_pad) : 0, braw = bias ? (size_t)Nq * ldbias : 0;
+            ctx->arena.reserve((nq + 2 * nk) * 4 + (bpk + braw) * 4 + 8192);
+            ctx->arena.reset();
+            _Float16* Qp = reinterpret_cast<_Float16*>(ctx->arena.alloc(nq * 4));
+            _Float16* Kp = reinterpret_cast<_Float16*>(ctx->arena.alloc(nk * 4));
+            _Float16* Vp = reinterpret_cast<_Float16*>(ctx->arena.alloc(nk * 4));
+            launch_attn_split_operands(q, k, v, Qp, Qp + nq, Kp, Kp + nk, Vp, Vp + nk, B, H, Nq, Nk_pad, scale * kLog2e, s);
+            AttnSplitArgs sa{};
+            sa.Qh = Qp; sa.Ql = Qp + nq; sa.Kh = Kp; sa.Kl = Kp + nk; sa.VTh = Vp; sa.VTl = Vp + nk;
+            if (bias) {
+                float* b2 = reinterpret_cast<float*>(ctx->arena.alloc(braw * 4));
+                float* pk = reinterpret_cast<float*>(ctx->arena.alloc(bpk * 4));
+                HIP_CHECK(hipMemcpyAsync(b2, bias, braw * 4, hipMemcpyDeviceToDevice, s));
+                launch_scale(b2, (long)braw, kLog2e, s);
+                launch_pack_attn_bias(b2, ldbias, Nq, Nk_pad, pk, s);
+                sa.bias = b2; sa.bias_pk = pk; sa.ldbias = ldbias;
+            }
+            sa.bias_head_stride = 0;
+            sa.O = out; sa.Op = nullptr; sa.B = B; sa.H = H; sa.Nq = Nq; sa.Nk_pad = Nk_pad; sa.scale = scale * kLog2e;
+            sa.o_bstride = (long)Nq * H * 64; sa.o_qstride = (long)H * 64; sa.o_hstride = 64;
+            launch_attention_split(sa, s);
+            return;
+        }
         AttnArgs a{};
         a.Q = q; a.K = k; a.V = v; a.bias = bias; a.R = nullptr; a.O = out;
         a.B = B; a.H = H; a.Nq = Nq; a.Nk_pad = Nk_pad;

@@ -29,6 +29,8 @@
 // read in phase 2t+1, V(t+1) first in 2t+4).  Measured on BASELINE configs[1]'s self-attention shape (16 scenes x 16 heads, 1536 x 1568):
 // 651 -> 528 us.  Tried on top and rejected by measurement (same file): s_setprio on either phase, tile-major V^T, packed-f32 VALU, fetching the
 // first V^T fragments before the barrier, splitting half of P inside the M-phase, both waves of a SIMD in the same phase (597 us).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 #include "profiler.h"
@@ -318,6 +320,37 @@ void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
     else
 #endif
         hipLaunchKernelGGL(attention_split_kernel<false>, grid, dim3(512), 0, s, a);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------ operator-level entry (bevgen_op_attention in a split-precision context)
+// fp32 q [B,H,Nq,64], k / v [B,H,Nk_pad,64] -> the kernel's operand images: Q planes with qmul (= score scale x log2 e) folded in, K planes, V^T planes
+__global__ __launch_bounds__(256) void attn_split_operands_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, _Float16* __restrict__ Qh,
+                                                                 _Float16* __restrict__ Ql, _Float16* __restrict__ Kh, _Float16* __restrict__ Kl, _Float16* __restrict__ VTh,
+                                                                 _Float16* __restrict__ VTl, long nq, long nk, int Nk_pad, float qmul) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < nq) {
+        const float x = q[i] * qmul;
+        const _Float16 hi = (_Float16)x;
+        Qh[i] = hi; Ql[i] = (_Float16)((x - (float)hi) * kLo);
+    }
+    if (i < nk) {
+        const float x = k[i];
+        const _Float16 hi = (_Float16)x;
+        Kh[i] = hi; Kl[i] = (_Float16)((x - (float)hi) * kLo);
+        const long bh = i / ((long)Nk_pad * 64), r = i % ((long)Nk_pad * 64);
+        const int j = (int)(r / 64), d = (int)(r % 64);
+        const float y = v[i];
+        const _Float16 vh = (_Float16)y;
+        const long dst = bh * (long)Nk_pad * 64 + (long)d * Nk_pad + j;
+        VTh[dst] = vh; VTl[dst] = (_Float16)((y - (float)vh) * kLo);
+    }
+}
+void launch_attn_split_operands(const float* q, const float* k, const float* v, void* Qh, void* Ql, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nq, int Nk_pad,
+                                float qmul, hipStream_t s) {
+    const long nq = (long)B * H * Nq * 64, nk = (long)B * H * Nk_pad * 64;
+    hipLaunchKernelGGL(attn_split_operands_kernel, dim3((unsigned)cdiv(std::max(nq, nk), 256L)), dim3(256), 0, s, q, k, v, reinterpret_cast<_Float16*>(Qh), reinterpret_cast<_Float16*>(Ql),
+                       reinterpret_cast<_Float16*>(Kh), reinterpret_cast<_Float16*>(Kl), reinterpret_cast<_Float16*>(VTh), reinterpret_cast<_Float16*>(VTl), nq, nk, Nk_pad, qmul);
     LAUNCH_CHECK();
 }
 

@@ -126,6 +126,8 @@ struct AttnSplitArgs {
 };
 long attn_bias_packed_floats(int Nq, int Nk_pad);
 void launch_pack_attn_bias(const float* bias, int ld, int Nq, int Nk_pad, float* out, hipStream_t s);
+void launch_attn_split_operands(const float* q, const float* k, const float* v, void* Qh, void* Ql, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nq, int Nk_pad,
+                                float qmul, hipStream_t s);
 void launch_attention_split(const AttnSplitArgs& a, hipStream_t s);
 void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, float post, hipStream_t s);
 void launch_muse_null_kv_prep(const float* null_kv, const float* k_scale, void* out /* 4*H*64 halves */, int H, hipStream_t s);

@@ -99,6 +99,60 @@ def test_attention(gpu_ctx, B, H, Nq, Nk, use_bias):
     assert rel(out.cpu().double(), ref) < 5e-6
 
 
+@pytest.fixture(scope="module")
+def gpu_ctx_split():
+    """A model-less context in split-precision mode: bevgen_op_attention then runs the Route M flash-attention kernel (8-wave ping-pong, attention_split.hip)."""
+    from bevgen_amd.runtime import Context
+
+    ctx = Context(None, precision="f16x3")
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 48, 49), (2, 3, 200, 257), (1, 16, 300, 17), (2, 2, 128, 128), (1, 2, 513, 1568), (2, 1, 256, 32)])
+@pytest.mark.parametrize("use_bias", [True, False])
+def test_attention_split_precision(gpu_ctx_split, B, H, Nq, Nk, use_bias):
+    """The split-precision kernel at operator level against fp64: ragged query counts (not multiples of 32 / 256), one-tile and 49-tile key ranges, masked
+    entries, and the bias-less form (the launcher's zero block)."""
+    if not use_bias and Nk % 32:
+        pytest.skip("bias-less form needs Nk % 32 == 0")
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q = torch.randn(B, H, Nq, 64, generator=g)
+    k = torch.randn(B, H, Nk, 64, generator=g)
+    v = torch.randn(B, H, Nk, 64, generator=g)
+    Nk_pad = (Nk + 31) // 32 * 32
+    kp = torch.zeros(B, H, Nk_pad, 64); kp[:, :, :Nk] = k
+    vp = torch.zeros(B, H, Nk_pad, 64); vp[:, :, :Nk] = v
+    scale = 0.31
+    sim = torch.einsum("bhid,bhjd->bhij", q.double(), k.double()) * scale
+    bias = None
+    if use_bias:
+        bias_real = torch.randn(Nq, Nk, generator=g) * 2
+        bias_real[::3, 1::2] = -1e30
+        bias_real[:, 0] = 0.5
+        sim = sim + bias_real.double()
+        bias = torch.full((Nq, Nk_pad), -1e30)
+        bias[:, :Nk] = bias_real
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v.double()).permute(0, 2, 1, 3).reshape(B, Nq, H * 64)
+    out = gpu_ctx_split.op_attention(dev(q), dev(kp), dev(vp), dev(bias) if use_bias else None, scale)
+    assert rel(out.cpu().double(), ref) < 5e-6
+
+
+def test_attention_split_precision_rescale_branch(gpu_ctx_split):
+    """A key far above the running maximum in a LATE tile (every accumulator rescaled exactly once), split-precision kernel."""
+    B, H, Nq, Nk = 1, 1, 64, 256
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, H, Nq, 64, generator=g)
+    k = torch.randn(B, H, Nk, 64, generator=g) * 0.1
+    v = torch.randn(B, H, Nk, 64, generator=g)
+    k[0, 0, 200] = q[0, 0, 7] * 3.0
+    k[0, 0, 40] = q[0, 0, 9] * 2.0
+    sim = torch.einsum("bhid,bhjd->bhij", q.double(), k.double())
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v.double()).permute(0, 2, 1, 3).reshape(B, Nq, 64)
+    out = gpu_ctx_split.op_attention(dev(q), dev(k), dev(v), None, 1.0)
+    assert rel(out.cpu().double(), ref) < 5e-6
+
+
 def test_attention_online_softmax_rescale_branch(gpu_ctx):
     """A key far above the running maximum appears in a LATE tile: every accumulator must be rescaled exactly once."""
     B, H, Nq, Nk = 1, 1, 64, 256
