@@ -11,6 +11,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the CPU oracle's operators are small: on a 256-thread host torch's default (one thread per logical core) is several times SLOWER than 32 threads
+    # (bench.py's cpu_baseline tunes the same knob); results do not depend on the thread count on the fixtures
+    try:
+        import torch
+
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only; skipped elsewhere)")
 
