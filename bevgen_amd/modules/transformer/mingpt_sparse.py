@@ -57,12 +57,11 @@ class GPT(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("GPT must live on a ROCm device before sampling; libbevgen_hip has no CPU path")
             ctx = Context(self.cfg, route="ar", device=dev.index if dev.index is not None else torch.cuda.current_device())
-            ctx.load_state_dict({k: v for k, v in self.state_dict().items() if not k.endswith("master_layout")})
+            # every blocks.{i}...master_layout buffer travels as int64: the reference draws one layout PER attention layer when density < 1
+            # (gpt:176, maskgen:217-251) and finalize_ar reads each layer's own buffer (csrc/context.cpp); table.layout only backs absent ones
+            sd = self.state_dict()
+            ctx.load_state_dict({k: (v.to(torch.int64) if k.endswith("master_layout") else v) for k, v in sd.items()})
             ctx.set_tables(self.cfg)
-            # per-head layouts stored in the checkpoint win over the freshly built ones (random layouts when density < 1)
-            lay = self.state_dict().get("blocks.0.attention.sparse_self_attention.master_layout")
-            if lay is not None:
-                ctx.load_tensor("table.layout", lay.to(torch.int64))
             ctx.finalize()
             self._ctx = ctx
         return self._ctx

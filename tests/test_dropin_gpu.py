@@ -178,3 +178,33 @@ def test_route_a_net2net_forward_from_raw_batch_with_partial_decoding():
     # forward() = log_images(generate_only=True) with the module's top_k: the stochastic default path runs and returns the three entries
     out2 = model(batch)
     assert set(out2) == {"gen", "rec", "gt"} and tuple(out2["gen"].shape) == (B, C, 3, 32, 40) and float(out2["gen"].min()) >= 0 and float(out2["gen"].max()) <= 1
+
+
+@pytest.mark.parametrize("name", ["a_tiny_d06", "a_config4_d035_head"])
+def test_gpt_dropin_keeps_every_layers_master_layout(name):
+    """density < 1: the reference draws one random layout PER attention layer (gpt:176, maskgen:217-251) and keeps them in the checkpoint as
+    blocks.{i}...master_layout.  The drop-in GPT must hand every one of them to the library (round 2 uploaded only block 0's): tokens of the module path
+    = the tokens the imported reference generated with those layouts."""
+    from conftest import golden
+    from bevgen_amd.modules.stage2.cond_transformer_multi_view import Net2NetTransformer
+    from bevgen_amd.modules.transformer.mingpt_sparse import GPT
+    from oracle import cases
+
+    case = cases.CASES[name]
+    g = golden("route_a_" + name)
+    cfg = case.make_cfg()
+    sd = cases.golden_state_dict(case, cfg, g)
+    lay = [sd[f"blocks.{i}.attention.sparse_self_attention.master_layout"] for i in range(cfg.num_layers)]
+    assert any(not torch.equal(lay[0], l) for l in lay[1:]), "fixture must carry different layouts per layer"
+    gpt = GPT(cfg)
+    missing, unexpected = gpt.load_state_dict(sd)
+    assert not missing and not unexpected
+    gpt = gpt.to("cuda")
+    cond = torch.from_numpy(g["cond_ids"]).long().cuda()
+    batch = {"intrinsics_inv": torch.from_numpy(g["I_inv"]).cuda(), "extrinsics_inv": torch.from_numpy(g["E_inv"]).cuda()}
+    want = torch.from_numpy(g["sample_greedy"]).long()
+    if case.steps == 0:
+        x = Net2NetTransformer(gpt, None, None).sample(None, cond, batch, sample=False).cpu()
+    else:   # full-size model: the golden holds the first `steps` tokens only
+        x = gpt.context().ar_sample(cond, batch["intrinsics_inv"], batch["extrinsics_inv"], greedy=True, steps=case.steps).cpu()
+    assert torch.equal(x, want), f"{(x != want).sum().item()} tokens differ from the reference's (per-layer layouts lost?)"
