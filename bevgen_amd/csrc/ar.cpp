@@ -37,7 +37,8 @@ bool fused_path(const Ctx& c, int B, int G) {
     if (c.cfg.decode_path != BEVGEN_DECODE_FUSED) return false;
     const int D = c.D;
     return ar_attn_fused_supported(B, G, D, c.H) && skinny_fused_supported(B, 4 * D, D, true) && skinny_fused_supported(B, D, 4 * D, false) &&
-           skinny_fused_supported(B, c.V, D, true) && ((size_t)round_up(c.L, 4) + (size_t)G * D + G * 192 + 16 * (G + 1) * 66 + 16 * G) * 4 <= 64 * 1024;
+           skinny_fused_supported(B, c.V, D, true) && ar_attn_fused_lds_bytes(G, D, (int)round_up(c.L, 4)) <= 64 * 1024 &&
+           (c.cfg.decode_weight_dtype != BEVGEN_W_F16 || (skinny_fused_f16_ok(4 * D, D, true) && skinny_fused_f16_ok(D, 4 * D, false) && skinny_fused_f16_ok(c.V, D, true)));
 }
 
 size_t part_floats(const Ctx& c, int B) { return (size_t)skinny_fused_ksplit(c.D, 4 * c.D) * B * c.D; }
@@ -369,6 +370,7 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     BG_REQUIRE(greedy || noise_u, "stochastic sampling needs explicit uniform noise d_noise_u [steps, B]");
     ar_prefill(c, cond, I_inv, E_inv, B, s, samples_per_layout);
     auto& st = c.ars;
+    c.step_events_used = 0;   // bevgen_ar_step_times describes THIS call: a call that takes the eager path below reports no steps
     c.arena.reset();
     StepWs w = step_ws(c, B);
     launch_fill_i64(out, (long)B * c.N, c.cfg.vocab_size, s);  // x = vocab_size everywhere (ar_lm:157)
@@ -425,7 +427,6 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
         c.graph = graph;
         c.graph_key = key;
     }
-    c.step_events_used = 0;
     auto stamp = [&]() {
         if (!c.time_steps) return;
         if (c.step_events_used == (int)c.step_events.size()) {

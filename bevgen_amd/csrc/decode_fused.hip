@@ -718,6 +718,12 @@ bool skinny_fused_supported(int M, int N, int K, bool ln) {
     return kw <= 1024 && kw % (SF_WAVES * 16) == 0;
 }
 
+// fp16 weight images: the K slice of a workgroup must be a multiple of 32 per wave
+bool skinny_fused_f16_ok(int N, int K, bool ln) {
+    const int s = ln ? 1 : skinny_fused_ksplit(N, K);
+    return K % s == 0 && (K / s) % (SF_WAVES * 32) == 0;
+}
+
 void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     SkinnyFusedArgs g = g0;
     const bool ln = g.ln_w != nullptr;

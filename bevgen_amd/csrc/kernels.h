@@ -213,6 +213,8 @@ void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStrea
 void launch_pack_skinny_weight_f16(const float* W, void* Wp /* N16 * K halves */, int N, int K, hipStream_t s);
 int skinny_fused_ksplit(int N, int K);
 bool skinny_fused_supported(int M, int N, int K, bool ln);
+bool skinny_fused_f16_ok(int N, int K, bool ln);   // fp16 weight image: K slice per wave a multiple of 32
+size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad);
 void launch_skinny_fused(const SkinnyFusedArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------- embed.hip

@@ -10,7 +10,7 @@ which is the wire format its evaluation tooling reads (one directory per sample 
 
 ``_XXXXX`` is the 5-character [A-Z0-9] suffix of ``rand_str=True`` (callback.py:93: several samples of one layout do not overwrite each other).
     <save_dir>/viz/<token>.png                              contact sheet (six-view scenes)      (callback.py:76-86)
-    <save_dir>/sample/<token>/bev.png                       class-coloured BEV (rand_str runs)   (callback.py:105)
+    <save_dir>/sample/<token>/bev.png                       class-coloured BEV (rand_str runs: callback.py:105; nuScenes otherwise: callback.py:117-118)
 The two PNGs are visualisations: same file names and content (generated row over ground-truth row, the BEV rendering beside them; class colours of
 the nuScenes devkit, highest class wins, blended with light grey by confidence - bev_utils/visualize.py:67-107), own layout (the reference composes
 its sheet with the third-party ``image_utils`` package).
@@ -50,16 +50,20 @@ _BEV_EMPTY = np.array((200, 200, 200), dtype=np.float32)
 _BEV_CHANNEL_ORDER = [4, 5, 6, 3, 1, 0, 2]
 
 
-def render_bev(seg: np.ndarray) -> np.ndarray:
-    """[c, h, w] (or [h, w, c]) class probabilities in [0, 1] (or uint8 0..255) -> [h, w, 3] uint8: per cell the highest class label wins (ties go to the
-    higher index), its colour blended with light grey by its confidence (visualize.py:67-107).  Other channel counts get the palette cyclically."""
+def render_bev(seg: np.ndarray, channel_axis: Optional[int] = None) -> np.ndarray:
+    """Class probabilities in [0, 1] (or uint8 0..255) -> [h, w, 3] uint8: per cell the highest class label wins (ties go to the higher index), its
+    colour blended with light grey by its confidence (visualize.py:67-107).  Other channel counts get the palette cyclically.
+    ``channel_axis``: 0 for [c, h, w], -1 for [h, w, c] (the batch layout of the reference: get_input moves the LAST axis, muse_lm:166-179);
+    None = the smallest axis (class counts are far below the grid size)."""
     a = np.asarray(seg, dtype=np.float32)
     if a.ndim != 3:
         raise ValueError(f"render_bev: expected a 3-D segmentation, got shape {a.shape}")
     if a.max() > 1:
         a = a / 255.0
-    if a.shape[0] < a.shape[1] and a.shape[1] == a.shape[2]:
-        a = a.transpose(1, 2, 0)
+    if channel_axis is None:
+        channel_axis = 0 if a.shape[0] < a.shape[2] else -1
+    if channel_axis % 3 != 2:
+        a = np.moveaxis(a, channel_axis, -1)
     c = a.shape[-1]
     if c == len(_BEV_CHANNEL_ORDER):
         a = a[..., _BEV_CHANNEL_ORDER]
@@ -117,7 +121,9 @@ class SceneWriter:
         host: Dict[str, np.ndarray] = {}
         for k in ("gen", "gt", "rec"):
             if k in outputs and outputs[k] is not None:
-                host[k] = to_uint8(outputs[k].detach()).cpu().numpy()   # uint8 on the device, one D2H copy per tensor
+                t = outputs[k].detach()
+                # uint8 is the storage / wire format (vq_decode(uint8=True), parallel.gather_scenes): passed through; floats are converted on the device
+                host[k] = (t if t.dtype == torch.uint8 else to_uint8(t)).cpu().numpy()   # one D2H copy per tensor
         gen = host["gen"]
         B, C = gen.shape[:2]
         seg = batch["segmentation"]
@@ -134,7 +140,7 @@ class SceneWriter:
                 np.savez_compressed(d / "bev.npz", seg_b)
             if seg_b.ndim == 3:
                 bev_rgb = render_bev(seg_b)
-                if self.rand_str:                                                        # callback.py:105
+                if self.rand_str or dataset == Dataset.NUSCENES:                         # callback.py:105 (rand_str runs), :117-118 (nuScenes otherwise)
                     self._pending.append(self._pool.submit(_save_png, bev_rgb, self.save_dir / "sample" / tok / "bev.png"))
                 if C == 6:                                                               # callback.py:76-86 (six-view scenes only)
                     sheet = contact_sheet(gen[b], host.get("gt", None)[b] if "gt" in host else None, bev_rgb)

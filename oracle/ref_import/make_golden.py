@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import argparse
 import hashlib
+import json
 import os
 import sys
 import time
@@ -42,9 +43,18 @@ def top2_margin(logits: torch.Tensor) -> float:
 
 
 def save(name, **arrays):
+    """Fixture = data only: wall-clock fields (`*_seconds`: how long the imported reference took here) go to tests/golden/ref_timings.json, so that
+    re-running this script reproduces every .npz byte for byte (numpy stamps the zip members with a fixed date)."""
     os.makedirs(GOLDEN, exist_ok=True)
     path = os.path.join(GOLDEN, name + ".npz")
-    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    timings = {k: round(float(np.asarray(v)), 3) for k, v in arrays.items() if k.endswith("_seconds")}
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items() if k not in timings})
+    if timings:
+        tpath = os.path.join(GOLDEN, "ref_timings.json")
+        allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        allt[name] = timings
+        with open(tpath, "w") as f:
+            json.dump(allt, f, indent=1, sort_keys=True)
     print(f"  wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 

@@ -40,7 +40,8 @@ def test_layout_and_contents(tmp_path):
     for b, tok in enumerate(toks):
         for split in ("sample", "sample_gt"):
             d = tmp_path / split / tok
-            assert sorted(os.listdir(d)) == sorted([f"{c}.jpg" for c in cams] + ["bev.npz"])
+            # nuScenes, rand_str off: the class-coloured bev.png goes beside the generated views only (callback.py:117-118)
+            assert sorted(os.listdir(d)) == sorted([f"{c}.jpg" for c in cams] + ["bev.npz"] + (["bev.png"] if split == "sample" else []))
             seg = np.load(d / "bev.npz")["arr_0"]                  # np.savez_compressed(path, array) -> key arr_0
             assert seg.dtype == np.float32 and np.array_equal(seg, batch["segmentation"][b].float().numpy())
         img = np.asarray(Image.open(tmp_path / "sample" / tok / "CAM_FRONT.jpg"))
@@ -64,6 +65,26 @@ def test_rand_str_and_non_nuscenes(tmp_path):
     assert len(set(toks)) == 3
     assert not (tmp_path / "gen").exists()                          # the nuScenes-format copies are nuScenes only (callback.py:127)
     assert sorted(os.listdir(tmp_path / "sample")) == sorted(toks)
+    # Argoverse without rand_str: no bev.png (callback.py:117 is nuScenes only)
+    w = SceneWriter(str(tmp_path / "plain"))
+    w.write(out, batch, dataset=Dataset.ARGOVERSE)
+    w.close()
+    assert not (tmp_path / "plain" / "sample" / "tok000" / "bev.png").exists() and (tmp_path / "plain" / "sample" / "tok000" / "bev.npz").exists()
+
+
+def test_uint8_outputs_are_the_wire_format_and_pass_through(tmp_path):
+    """vq_decode(uint8=True) / parallel.gather_scenes hand over uint8 pixels: the writer must not rescale them (x255 would saturate every nonzero pixel)."""
+    from PIL import Image
+    cams = ["CAM_FRONT"]
+    batch, out = _batch(1, cams), _outputs(1, 1)
+    u8 = {k: (v * 255).round().clamp(0, 255).to(torch.uint8) for k, v in out.items()}
+    with SceneWriter(str(tmp_path / "u8")) as w:
+        w.write(u8, batch, dataset=Dataset.ARGOVERSE)
+    with SceneWriter(str(tmp_path / "f32")) as w:
+        w.write(out, batch, dataset=Dataset.ARGOVERSE)
+    a = np.asarray(Image.open(tmp_path / "u8" / "sample" / "tok000" / "CAM_FRONT.jpg"))
+    b = np.asarray(Image.open(tmp_path / "f32" / "sample" / "tok000" / "CAM_FRONT.jpg"))
+    assert np.array_equal(a, b) and a.max() < 255
 
 
 def test_callback_dropin(tmp_path):
@@ -94,6 +115,11 @@ def test_bev_rendering_and_contact_sheet(tmp_path):
     assert tuple(rgb[3, 3]) == (227, 149, 135)                     # 0.5 (255, 99, 71) + 0.5 (200, 200, 200)
     assert tuple(rgb[0, 3]) == (200, 200, 200)                     # nothing there
     assert np.array_equal(render_bev((seg * 255).astype(np.uint8)), rgb)
+    # non-square grids and channel-last input: the channel axis is explicit or the smallest one, never guessed from squareness
+    rect = np.zeros((7, 6, 10), dtype=np.float32)
+    rect[0, 1, 9] = 1.0
+    assert render_bev(rect).shape == (6, 10, 3) and tuple(render_bev(rect)[1, 9]) == (255, 158, 0)
+    assert np.array_equal(render_bev(rect.transpose(1, 2, 0), channel_axis=-1), render_bev(rect, channel_axis=0))
 
     cams = ["CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_LEFT", "CAM_BACK", "CAM_BACK_RIGHT"]
     batch, out = _batch(2, cams), _outputs(2, 6)
@@ -110,5 +136,5 @@ def test_bev_rendering_and_contact_sheet(tmp_path):
     w2 = SceneWriter(str(tmp_path / "c3"))
     w2.write(_outputs(1, 3), _batch(1, cams[:3]), dataset=Dataset.NUSCENES)
     w2.close()
-    assert not (tmp_path / "c3" / "viz").exists() and not (tmp_path / "c3" / "sample" / "tok000" / "bev.png").exists()
+    assert not (tmp_path / "c3" / "viz").exists() and (tmp_path / "c3" / "sample" / "tok000" / "bev.png").exists()   # bev.png: nuScenes (callback.py:117-118)
     assert contact_sheet(gen_u8, None, render_bev(seg)).shape == (24, 6 * 40 + 24, 3)
