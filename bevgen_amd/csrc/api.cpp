@@ -314,12 +314,61 @@ int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* q, const void* kc, 
     return guarded(ctx, [&] {
         DecodeAttnArgs a;
         a.q = q; a.ldq = H * 64; a.kcache = kc; a.vcache = vc; a.kv_dtype = kv_dtype;
-        a.bias = bias; a.ldbias = ldbias; a.keep = keep; a.ldkeep = ldkeep; a.keep_head_stride = keep_head_stride;
+        a.bias = bias; a.ldbias = ldbias;
+        a.vis.allowed = keep; a.vis.ldallowed = ldkeep; a.vis.allowed_head_stride = keep_head_stride;   // a dense per-head plane is an element mask with a head stride
         a.O = out; a.ldo = H * 64; a.B = B; a.H = H; a.n = n; a.Lmax = Lmax; a.scale = scale;
         const int S = decode_attention_splits(a.B, a.H, a.n);
         ctx->arena.reserve(decode_attention_ws_bytes(a.B, a.H, S) + 4096);
         ctx->arena.reset();
         launch_decode_attention_ws(a, reinterpret_cast<float*>(ctx->arena.alloc(decode_attention_ws_bytes(a.B, a.H, S))), S, (hipStream_t)stream);
+    });
+}
+
+int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partial, int ns, const float* rbias, const float* ln_w, const float* ln_b, const float* wqkv,
+                            const float* bqkv, int w_f16, void* kc, void* vc, int kv_dtype, const float* bias, int ldbias, const float* attn_mask, const int64_t* layout,
+                            int block, int B, int G, int H, int n, int Lmax, int prefix, float* out, void* stream) {
+    return guarded(ctx, [&] {
+        hipStream_t s = (hipStream_t)stream;
+        const int D = H * 64, L = Lmax;
+        BG_REQUIRE(x && ln_w && ln_b && wqkv && bqkv && kc && vc && out && n >= 1 && n <= Lmax, "op_ar_attn_fused: bad arguments");
+        BG_REQUIRE(ar_attn_fused_supported(B, G, D, H), "op_ar_attn_fused: unsupported shape B=%d G=%d D=%d H=%d", B, G, D, H);
+        BG_REQUIRE(!layout || (block >= 1 && L % block == 0), "op_ar_attn_fused: Lmax %d is not a multiple of the block size %d", L, block);
+        const int nb = layout ? L / block : 0, cld = (int)cdiv(L, 16) + 1;
+        ctx->arena.reserve((size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * cld * 2 + (size_t)3 * D * D * 2 + 8 * 256);
+        ctx->arena.reset();
+        ArAttnFusedArgs a;
+        a.x.base = x; a.x.ld = D;
+        if (partial && ns > 0) { a.x.partial = partial; a.x.ns = ns; a.x.pstride = (long)B * D; a.x.pld = D; }
+        a.x.bias = rbias;
+        a.ln_w = ln_w; a.ln_b = ln_b; a.wqkv = wqkv; a.bqkv = bqkv;
+        if (w_f16) {
+            void* h = ctx->arena.alloc((size_t)3 * D * D * 2);
+            float* tmp = nullptr;   // round_to_f16 rounds in place: work on a copy of the caller's matrix
+            HIP_CHECK(hipMalloc(&tmp, (size_t)3 * D * D * 4));
+            HIP_CHECK(hipMemcpyAsync(tmp, wqkv, (size_t)3 * D * D * 4, hipMemcpyDeviceToDevice, s));
+            launch_round_to_f16(tmp, h, 3L * D * D, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(hipFree(tmp));
+            a.wqkv_h = h;
+        }
+        a.kcache = kc; a.vcache = vc; a.kv_dtype = kv_dtype;
+        a.bias = bias; a.ldbias = ldbias;
+        if (attn_mask) {
+            uint8_t* al = ctx->arena.get<uint8_t>((size_t)L * L);
+            launch_build_allowed(attn_mask, al, (long)L * L, s);
+            a.vis.allowed = al; a.vis.ldallowed = L;
+        }
+        if (layout) {
+            uint8_t* lay = ctx->arena.get<uint8_t>((size_t)H * nb * nb);
+            uint16_t* ch = ctx->arena.get<uint16_t>((size_t)H * nb * cld);
+            launch_build_layout(layout, lay, ch, H, nb, block, L, cld, s);
+            a.vis.lay = lay; a.vis.lay_head_stride = (long)nb * nb; a.vis.nb = nb; a.vis.blk = block;
+            a.vis.chunks = ch; a.vis.chunks_head_stride = (long)nb * cld; a.vis.chunks_ld = cld;
+        }
+        a.out = out; a.ldo = D;
+        a.B = B; a.G = G; a.H = H; a.D = D; a.Lmax = Lmax; a.n = n; a.prefix = prefix; a.scale = 0.125f;
+        a.trace = ctx->trace;
+        launch_ar_attn_fused(a, s);
     });
 }
 

@@ -36,6 +36,7 @@ struct StepWs {
 bool fused_path(const Ctx& c, int B, int G) {
     if (c.cfg.decode_path != BEVGEN_DECODE_FUSED) return false;
     const int D = c.D;
+    if (G > 1 && c.K % 16 != 0) return false;   // the shared condition prefix must end on a 16-key chunk boundary (the per-operator path replicates it instead)
     return ar_attn_fused_supported(B, G, D, c.H) && skinny_fused_supported(B, 4 * D, D, true) && skinny_fused_supported(B, D, 4 * D, false) &&
            skinny_fused_supported(B, c.V, D, true) && ar_attn_fused_lds_bytes(G, D, (int)round_up(c.L, 4)) <= 64 * 1024 &&
            (c.cfg.decode_weight_dtype != BEVGEN_W_F16 || (skinny_fused_f16_ok(4 * D, D, true) && skinny_fused_f16_ok(D, 4 * D, false) && skinny_fused_f16_ok(c.V, D, true)));
@@ -92,15 +93,24 @@ void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const floa
                               int L, int block, float* out, hipStream_t s) {
     BG_REQUIRE(L % block == 0, "Sequence Length, %d, needs to be dividable by Block size %d!", L, block);  // ssa:54-57
     const int Lpad = (int)round_up(L, 32);
-    const size_t keep_b = (size_t)H * L * L;
+    const int nb = L / block;
+    const size_t keep_b = (size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * (cdiv(L, 16) + 1) * sizeof(uint16_t) + 3 * 256;
     const size_t bias_b = (size_t)H * L * Lpad * sizeof(float);
     const size_t kv_b = Lpad != L ? (size_t)2 * B * H * Lpad * 64 * sizeof(float) : 0;
     c.arena.reserve(keep_b + bias_b + kv_b + 8 * 256);
     c.arena.reset();
-    uint8_t* keep = c.arena.get<uint8_t>(keep_b);
+    SparseVis vis;
+    {
+        uint8_t* allowed = c.arena.get<uint8_t>((size_t)L * L);
+        uint8_t* lay = c.arena.get<uint8_t>((size_t)H * nb * nb);
+        uint16_t* chunks = c.arena.get<uint16_t>((size_t)H * nb * (cdiv(L, 16) + 1));
+        launch_build_allowed(mask, allowed, (long)L * L, s);
+        launch_build_layout(layout, lay, chunks, H, nb, block, L, (int)cdiv(L, 16) + 1, s);
+        vis.allowed = allowed; vis.ldallowed = L;
+        vis.lay = lay; vis.lay_head_stride = (long)nb * nb; vis.nb = nb; vis.blk = block;
+    }
     float* bias = c.arena.get<float>((size_t)H * L * Lpad);
-    launch_build_keep(mask, layout, keep, H, L, block, s);
-    launch_build_masked_bias(add, keep, (long)L * L, L, bias, H, L, L, Lpad, L, 0.125f, s);
+    launch_build_masked_bias(add, vis, bias, H, L, L, Lpad, L, 0.125f, s);
     const float *kp = k, *vp = v;
     if (Lpad != L) {
         float* kpad = c.arena.get<float>((size_t)B * H * Lpad * 64);
@@ -154,7 +164,8 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     // workspace: the decode-step buffers first (stable addresses), then the prefill activations
     const size_t rows = (size_t)G * K;
     const size_t tmp_kv = cache_dtype(c) ? (size_t)2 * G * H * c.Kpad * 64 : 0;   // fp16 cache: the prefill attention reads exact fp32 K/V from a scratch pair
-    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)G * H * K * 64 + tmp_kv) * sizeof(float) + (size_t)G * (K * 8 + (size_t)(g.num_cams + 1) * D * 4) + 32 * 256;
+    const size_t layer_bias = c.prefill_bias ? 0 : (size_t)c.keep_heads * K * c.Kpad;   // per-layer layouts: this layer's masked bias is built on the fly
+    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)G * H * K * 64 + tmp_kv + layer_bias) * sizeof(float) + (size_t)G * (K * 8 + (size_t)(g.num_cams + 1) * D * 4) + 32 * 256;
     c.arena.reserve(step_ws_bytes(c, B) + pre_b);
     c.arena.reset();
     (void)step_ws(c, B);
@@ -165,6 +176,7 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     float* qkv = c.arena.get<float>(rows * 3 * D);
     float* m1 = c.arena.get<float>(rows * 4 * D);
     float* Q = c.arena.get<float>((size_t)G * H * K * 64);
+    float* lbias = c.prefill_bias ? nullptr : c.arena.get<float>(layer_bias);
 
     if (g.image_embed)   // per-sequence state of the decode steps: for all B sequences
         launch_camera_embed(I_inv, E_inv, c.image_plane, c.pf("img_embed.weight"), c.pf("cam_embed.weight"), st.img_embed, st.c_embed, B, g.num_cams, c.T, D, s);
@@ -201,7 +213,8 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
         launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, G, H, K, 0, Lk, s);   // cache slots [0, G) for now
         if (kvd) launch_ar_qkv_scatter(qkv, nullptr, kcb, vcb, kvd, G, H, K, 0, L, s);   // the fp16 image the decode steps read
         AttnArgs a{};
-        a.Q = Q; a.K = kc; a.V = vc; a.bias = c.prefill_bias + (c.keep_layers > 1 ? (size_t)i * c.keep_heads * K * c.Kpad : 0); a.R = xn; a.O = x2;
+        if (lbias) launch_build_masked_bias(c.attn_bias, c.vis_of_layer(i), lbias, c.keep_heads, K, K, c.Kpad, c.L, 0.125f, s);
+        a.Q = Q; a.K = kc; a.V = vc; a.bias = lbias ? lbias : c.prefill_bias; a.R = xn; a.O = x2;
         a.B = G; a.H = H; a.Nq = K; a.Nk_pad = c.Kpad;
         a.q_bstride = (long)H * K * 64; a.q_hstride = (long)K * 64;
         a.kv_bstride = (long)H * Lk * 64; a.kv_hstride = (long)Lk * 64;
@@ -283,7 +296,7 @@ static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipS
         a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes;
         a.kv_dtype = cache_dtype(c);
         a.bias = c.attn_bias; a.ldbias = L;
-        a.keep = c.keep + (c.keep_layers > 1 ? (size_t)i * c.keep_heads * L * L : 0); a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
+        a.vis = c.vis_of_layer(i);
         a.out = x2; a.ldo = D;
         a.B = B; a.G = st.G; a.H = H; a.D = D; a.Lmax = L;
         a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step;
@@ -340,7 +353,7 @@ static void decode_step_launch(Ctx& c, StepWs& w, const int64_t* tok, hipStream_
         a.append_k = w.qkv + D; a.append_v = w.qkv + 2 * D;  // the new row (sequence position K + step) is appended inside the attention kernel
         a.kcache = kc; a.vcache = vc;
         a.bias = c.attn_bias; a.ldbias = L;
-        a.keep = c.keep + (c.keep_layers > 1 ? (size_t)i * c.keep_heads * L * L : 0); a.keep_head_stride = c.keep_heads > 1 ? (long)L * L : 0; a.ldkeep = L;
+        a.vis = c.vis_of_layer(i);
         a.R = w.xn; a.ldr = D; a.O = w.x2; a.ldo = D;
         a.B = B; a.H = H; a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step; a.Lmax = L;
         a.scale = 0.125f; a.kv_dtype = cache_dtype(c);

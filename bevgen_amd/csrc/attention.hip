@@ -235,7 +235,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
         for (int i = 0; i < DPL; ++i) qv[i] = qp[i] * (a.scale * kLog2eDec);   // scores live in the base-2 domain: exp(x) = 2^(x log2 e), one v_exp_f32
     }
     const long cache_row0 = ((long)b * a.H + head) * a.Lmax;
-    const uint8_t* keep = a.keep ? a.keep + (long)head * a.keep_head_stride + (long)row * a.ldkeep : nullptr;
+    // visibility of key k = element mask x block layout (SparseVis); this per-operator kernel masks per key and walks every key
+    const SparseVis& vis = a.vis;
+    const uint8_t* arow = vis.allowed + (long)head * vis.allowed_head_stride + (long)row * vis.ldallowed;
+    const uint8_t* lrow = vis.lay + (long)head * vis.lay_head_stride + (long)(row / vis.blk) * vis.nb;
     const float* bias_row = a.bias ? a.bias + (long)row * a.ldbias : nullptr;
 
     // fused KV append: the workgroup that owns the newest key writes this step's k/v row into the cache, then everybody reads it back
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
             for (int i = 0; i < DPL; ++i) d = fmaf(qv[i], kx[u][i], d);
             d = group_sum<LPK>(d);
             const int kc = min(key[u], k_end - 1);
-            const bool ok = key[u] < k_end && (!keep || keep[kc]);
+            const bool ok = key[u] < k_end && (!vis.has_allowed || arow[kc]) && (!vis.has_lay || lrow[kc / vis.blk]);
             sc[u] = ok ? d + (bias_row ? bias_row[kc] * (a.scale * kLog2eDec) : 0.f) : kNegBig;
             mx = fmaxf(mx, sc[u]);
         }
@@ -365,7 +368,9 @@ int decode_attention_splits(int B, int H, int n_max) {
 
 size_t decode_attention_ws_bytes(int B, int H, int S) { return (size_t)B * H * S * 66 * sizeof(float); }
 
-void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipStream_t s) {
+void launch_decode_attention_ws(const DecodeAttnArgs& a0, float* ws, int S, hipStream_t s) {
+    DecodeAttnArgs a = a0;
+    a.vis = vis_fix(a.vis, a.q);
     BG_REQUIRE(a.d_n || (a.n > 0 && a.n <= a.Lmax), "decode attention: n=%d out of range (Lmax=%d)", a.n, a.Lmax);
     BG_REQUIRE(a.group <= 1, "decode attention: shared-prefix groups not implemented in this kernel");
     dim3 grid(S, a.H, a.B);

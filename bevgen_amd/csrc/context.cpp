@@ -297,15 +297,29 @@ static void finalize_ar(Ctx& c) {
     }
     c.keep_heads = same_heads ? 1 : c.H;
     c.keep_layers = same_layers ? 1 : g.num_layers;
-    const size_t plane = (size_t)c.keep_heads * c.L * c.L;
-    c.keep = reinterpret_cast<uint8_t*>(c.own(plane * c.keep_layers));
-    // prefill bias over the condition rows: scale*(bias) where visible, -1e30 elsewhere
+    // can any row skip anything?  Rows are causal (keys beyond the row are never walked), so chunk lists only pay when a block at or below the diagonal is absent
+    bool skippable = false;
+    for (int i = 0; i < g.num_layers && !skippable; ++i)
+        for (int h = 0; h < c.H && !skippable; ++h)
+            for (int r = 0; r < nb && !skippable; ++r)
+                for (int j = 0; j <= r && !skippable; ++j) skippable = hl[i][((size_t)h * nb + r) * nb + j] == 0;
+    c.allowed = reinterpret_cast<uint8_t*>(c.own((size_t)c.L * c.L));
+    launch_build_allowed(c.pf("table.attention_mask"), c.allowed, (long)c.L * c.L, 0);
+    const size_t lay_plane = (size_t)c.keep_heads * nb * nb;
+    c.chunks_ld = (int)cdiv(c.L, 16) + 1;
+    const size_t chunk_plane = (size_t)c.keep_heads * nb * c.chunks_ld;
+    c.lay = reinterpret_cast<uint8_t*>(c.own(lay_plane * c.keep_layers));
+    uint16_t* chunks = reinterpret_cast<uint16_t*>(c.own(chunk_plane * c.keep_layers * sizeof(uint16_t)));
+    for (int i = 0; i < c.keep_layers; ++i)
+        launch_build_layout(reinterpret_cast<const int64_t*>(lays[i]->ptr), c.lay + i * lay_plane, chunks + i * chunk_plane, c.keep_heads, nb, blk, c.L, c.chunks_ld, 0);
+    c.chunks = skippable ? chunks : nullptr;
+    // prefill bias over the condition rows: scale*(bias) where visible, -1e30 elsewhere.  One image when the layers share their layout;
+    // per-layer layouts (density < 1) build theirs in the prefill's workspace, layer by layer (ar.cpp)
     c.Kpad = (int)round_up(c.K, 32);
-    const size_t pb = (size_t)c.keep_heads * c.K * c.Kpad;
-    c.prefill_bias = reinterpret_cast<float*>(c.own(pb * c.keep_layers * sizeof(float)));
-    for (int i = 0; i < c.keep_layers; ++i) {
-        launch_build_keep(c.pf("table.attention_mask"), reinterpret_cast<const int64_t*>(lays[i]->ptr), c.keep + i * plane, c.keep_heads, c.L, blk, 0);
-        launch_build_masked_bias(c.attn_bias, c.keep + i * plane, (long)c.L * c.L, c.L, c.prefill_bias + i * pb, c.keep_heads, c.K, c.K, c.Kpad, c.L, 0.125f, 0);
+    c.prefill_bias = nullptr;
+    if (c.keep_layers == 1) {
+        c.prefill_bias = reinterpret_cast<float*>(c.own((size_t)c.keep_heads * c.K * c.Kpad * sizeof(float)));
+        launch_build_masked_bias(c.attn_bias, c.vis_of_layer(0), c.prefill_bias, c.keep_heads, c.K, c.K, c.Kpad, c.L, 0.125f, 0);
     }
 }
 

@@ -106,20 +106,24 @@ struct Attend {
     static constexpr int LPK = T::LPK, DPL = T::DPL;
     struct Buf { typename T::Raw k[U], v[U]; };
 
-    __device__ static __forceinline__ void load(Buf& b, const void* kc, const void* vc, long row0, int key0, int stride, int k_end, int sub) {
+    // A wave walks 16-key chunks.  KPS keys per pipeline step (U loads of KPI consecutive keys = 1 KiB each), SPC steps per chunk.
+    static constexpr int KPI = 64 / LPK, KPS = U * KPI, SPC = 16 / KPS;
+    static_assert(KPS <= 16 && 16 % KPS == 0, "a pipeline step must tile a 16-key chunk");
+
+    __device__ static __forceinline__ void load(Buf& b, const void* kc, const void* vc, long row0, int key0, int k_end, int sub) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kcl = min(key0 + u * stride, k_end - 1);   // clamped address, masked in compute()
+            const int kcl = min(key0 + u * KPI, k_end - 1);   // clamped address, masked in compute()
             b.k[u] = T::load(kc, row0 + kcl, sub);
             b.v[u] = T::load(vc, row0 + kcl, sub);
         }
     }
-    __device__ static __forceinline__ void compute(const Buf& b, int key0, int stride, int k_end, const float* bias_s, const float (&q)[NQ][DPL], float (&m)[NQ],
+    __device__ static __forceinline__ void compute(const Buf& b, int key0, int k_end, const float* bias_s, const float (&q)[NQ][DPL], float (&m)[NQ],
                                                    float (&l)[NQ], float (&acc)[NQ][DPL]) {
         float sc[NQ][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = key0 + u * stride;
+            const int key = key0 + u * KPI;
             const float bv = key < k_end ? bias_s[min(key, k_end - 1)] : kNegBig;
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
@@ -149,24 +153,26 @@ struct Attend {
             m[qi] = mx;
         }
     }
-    // keys k_begin + slot + i * stride (i = 0, 1, ...) < k_end belong to this lane group; two register buffers: the loads of iteration
-    // it + 1 are in flight while iteration it is scored
-    __device__ static __forceinline__ void run(const void* kc, const void* vc, long row0, int k_begin, int k_end, int slot, int stride, int sub, const float* bias_s,
-                                               const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL]) {
-        const int first = k_begin + slot;
-        if (k_end <= k_begin) return;
-        const int span = stride * U;
-        // the whole wave iterates the same number of times (slot differs per lane group): based on the wave's smallest slot
-        const int wave_first = k_begin + (slot / (64 / LPK)) * (64 / LPK);
-        const int iters = wave_first < k_end ? (k_end - wave_first + span - 1) / span : 0;
-        if (iters == 0) return;
+    // The walk covers list positions [lo, hi): position p stands for chunk list_s[p] (block-sparse layouts: only chunks with a present block are listed)
+    // or for chunk p itself (list_s == null).  Wave `slot` of a team of `nslots` takes positions lo + slot, lo + slot + nslots, ...; step j of its walk
+    // reads keys 16 c + (j % SPC) KPS + u KPI + kslot.  Two register buffers: the loads of step j + 1 are in flight while step j is scored.
+    __device__ static __forceinline__ int key_of(const uint16_t* list_s, int lo, int slot, int nslots, int j, int kslot) {
+        const int p = lo + slot + (j / SPC) * nslots;
+        const int c = list_s ? (int)list_s[p] : p;
+        return 16 * c + (j % SPC) * KPS + kslot;
+    }
+    __device__ static __forceinline__ void run(const void* kc, const void* vc, long row0, const uint16_t* list_s, int lo, int hi, int slot, int nslots, int kslot, int k_end,
+                                               int sub, const float* bias_s, const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL]) {
+        const int mine = hi - lo - slot;
+        const int steps = mine > 0 ? ((mine + nslots - 1) / nslots) * SPC : 0;   // wave-uniform
+        if (steps == 0) return;
         Buf b0, b1;
-        load(b0, kc, vc, row0, first, stride, k_end, sub);
-        for (int it = 0; it < iters; it += 2) {
-            if (it + 1 < iters) load(b1, kc, vc, row0, first + (it + 1) * span, stride, k_end, sub);
-            compute(b0, first + it * span, stride, k_end, bias_s, q, m, l, acc);
-            if (it + 2 < iters) load(b0, kc, vc, row0, first + (it + 2) * span, stride, k_end, sub);
-            if (it + 1 < iters) compute(b1, first + (it + 1) * span, stride, k_end, bias_s, q, m, l, acc);
+        load(b0, kc, vc, row0, key_of(list_s, lo, slot, nslots, 0, kslot), k_end, sub);
+        for (int j = 0; j < steps; j += 2) {
+            if (j + 1 < steps) load(b1, kc, vc, row0, key_of(list_s, lo, slot, nslots, j + 1, kslot), k_end, sub);
+            compute(b0, key_of(list_s, lo, slot, nslots, j, kslot), k_end, bias_s, q, m, l, acc);
+            if (j + 2 < steps) load(b0, kc, vc, row0, key_of(list_s, lo, slot, nslots, j + 2, kslot), k_end, sub);
+            if (j + 1 < steps) compute(b1, key_of(list_s, lo, slot, nslots, j + 1, kslot), k_end, bias_s, q, m, l, acc);
         }
     }
 };
@@ -191,12 +197,12 @@ __device__ __forceinline__ void wave_merge(float& m, float& l, float (&acc)[DPL]
 }
 
 // ----------------------------------------------------------------------------------------------------------------- ln1 + qkv + attention
-// grid (H, B / G), 1024 threads.  Dynamic LDS: bias row [Lpad] | xn [G][D] | qkv [G][192] | red [16][G+1][66] | stat [16][G]
+// grid (H, B / G), 1024 threads.  Dynamic LDS: bias row [Lpad] | xn [G][D] | qkv [G][192] | red [16][G+1][66] | stat [16][G] | chunk list [Lpad/16 + 2] (uint16)
 template <int DT, int G, int WT>   // KV-cache storage (0 fp32, 1 fp16), sequences per workgroup, decode-weight storage (0 fp32, 1 fp16)
 __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) {
     using T = KvRow<DT>;
-    constexpr int LPK = T::LPK, DPL = T::DPL, KPI = 64 / LPK, NW = AF_WAVES, TW = NW / G;
-    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // keys per lane group and pipeline stage (fp16 rows: 3 or 4 measured no faster)
+    constexpr int LPK = T::LPK, DPL = T::DPL, NW = AF_WAVES, TW = NW / G;
+    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // key loads per lane group and pipeline step (fp16 rows: 3 or 4 measured no faster)
     constexpr int UP = G >= 4 ? 1 : U;   // same for the shared-prefix phase (G queries' state lives in registers)
     extern __shared__ float smem[];
     const int D = a.D;
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     float* qkv_s = xn_s + G * D;
     float* red = qkv_s + G * 192;
     float* stat = red + NW * (G + 1) * 66;
+    uint16_t* list_s = reinterpret_cast<uint16_t*>(stat + NW * G);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane % LPK, kslot = lane / LPK;
@@ -249,17 +256,24 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     };
     // bias row of this step with the visibility mask folded in (shared by every sequence and head of the step): through registers, stored after ln1
     constexpr int BR = 3;
-    // (the launcher points absent tables at valid memory: has_keep / has_bias say whether the values count)
-    const uint8_t* keep_row = a.keep + (long)head * a.keep_head_stride + (long)row * a.ldkeep;
+    // (the launcher points absent tables at valid memory: vis.has_* / has_bias say whether the values count)
+    const SparseVis& vis = a.vis;
+    const uint8_t* keep_row = vis.allowed + (long)head * vis.allowed_head_stride + (long)row * vis.ldallowed;
+    const uint8_t* lay_row = vis.lay + (long)head * vis.lay_head_stride + (long)(row / vis.blk) * vis.nb;
     const float* bias_row = a.bias + (long)row * a.ldbias;
     float braw[BR];
-    uint8_t kraw[BR];
+    uint8_t kraw[BR], lraw[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {   // raw values, clamped addresses: nothing below touches them before the statistics are done (a use would wait for the loads)
         const int k = min(tid + 1024 * j, n - 1);
         braw[j] = bias_row[k];
         kraw[j] = keep_row[k];
+        lraw[j] = lay_row[k / vis.blk];
     }
+    // key-chunk list of this (head, block row): count, then the ascending ids of the 16-key chunks that hold a present block (<= Lpad / 16 <= 1024 entries)
+    const uint16_t* chunk_row = vis.chunks + (long)head * vis.chunks_head_stride + (long)(row / vis.blk) * vis.chunks_ld;
+    const int chunk_total = chunk_row[0];
+    const int chunk_id = chunk_row[min(1 + tid, max(vis.chunks_ld - 1, 0))];
 
     // ---- ln1, thread = column
     {
@@ -308,11 +322,18 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            if (tid + 1024 * j < n) bias_s[tid + 1024 * j] = (kraw[j] || !a.has_keep) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
+            if (tid + 1024 * j < n)
+                bias_s[tid + 1024 * j] = ((kraw[j] || !vis.has_allowed) && (lraw[j] || !vis.has_lay)) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
         for (int k = tid + 1024 * BR; k < n; k += 1024)   // sequences longer than 3072: the remainder the plain way
-            bias_s[k] = (keep_row[k] || !a.has_keep) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
+            bias_s[k] = ((keep_row[k] || !vis.has_allowed) && (lay_row[k / vis.blk] || !vis.has_lay)) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
+        if (vis.has_chunks && tid < chunk_total) list_s[tid] = (uint16_t)chunk_id;
         __syncthreads();
     }
+    // the walk: list positions [0, n_pos) hold chunks that start below n (the list is ascending); without a list position = chunk
+    const uint16_t* walk = vis.has_chunks ? list_s : nullptr;
+    const int n_pos = vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < n) : (n + 15) >> 4;
+    // shared prefix (G > 1): positions [0, p_pos) are the chunks of the K condition keys (prefix is a multiple of 16: launcher)
+    const int p_pos = G == 1 ? 0 : (vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n)) : min((min(a.prefix, n) + 15) >> 4, n_pos));
 
     AF_TRACE(1);
     // ---- q/k/v projection of this head
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
         for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[sub * DPL + i] * sl2; acc[0][i] = 0.f; }
         const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-        Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, 0, n, wave * KPI + kslot, NW * KPI, sub, bias_s, q, m, l, acc);
+        Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, 0, n_pos, wave, NW, kslot, n, sub, bias_s, q, m, l, acc);
         wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
         if (kslot == 0) {
             if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
@@ -397,7 +418,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
                 for (int i = 0; i < DPL; ++i) { q[g][i] = qkv_s[g * 192 + sub * DPL + i] * sl2; acc[g][i] = 0.f; }
             }
             const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-            Attend<DT, G, UP>::run(a.kcache, a.vcache, row0, 0, min(a.prefix, n), wave * KPI + kslot, NW * KPI, sub, bias_s, q, m, l, acc);
+            Attend<DT, G, UP>::run(a.kcache, a.vcache, row0, walk, 0, p_pos, wave, NW, kslot, min(a.prefix, n), sub, bias_s, q, m, l, acc);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 wave_merge<LPK, DPL>(m[g], l[g], acc[g]);
@@ -415,7 +436,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
             for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[g_own * 192 + sub * DPL + i] * sl2; acc[0][i] = 0.f; }
             const long row0 = ((long)(b0 + g_own) * a.H + head) * a.Lmax;
-            Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, min(a.prefix, n), n, wt * KPI + kslot, TW * KPI, sub, bias_s, q, m, l, acc);
+            Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, p_pos, n_pos, wt, TW, kslot, n, sub, bias_s, q, m, l, acc);
             wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
             if (kslot == 0) {
                 if (sub == 0) { my_red[G * 66] = m[0]; my_red[G * 66 + 1] = l[0]; }
@@ -460,7 +481,9 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #undef AF_TRACE
 }
 
-size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) { return ((size_t)Lpad + (size_t)G * D + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66 + (size_t)AF_WAVES * G) * sizeof(float); }
+size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) {
+    return ((size_t)Lpad + (size_t)G * D + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66 + (size_t)AF_WAVES * G) * sizeof(float) + ((size_t)Lpad / 16 + 2) * sizeof(uint16_t);
+}
 
 bool ar_attn_fused_supported(int B, int G, int D, int H) { return D == H * 64 && D % 4 == 0 && D <= 1024 && (G == 1 || G == 2 || G == 4) && B % G == 0; }
 
@@ -470,10 +493,11 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     BG_REQUIRE(a.x.ns <= ROWSRC_MAX_SPLITS, "fused decode attention: at most %d partial sums per row", ROWSRC_MAX_SPLITS);
     a.Lpad = (int)round_up(a.Lmax, 4);
     a.x = rowsrc_fix(a.x);
-    a.has_keep = a.keep != nullptr; a.has_bias = a.bias != nullptr;
-    if (!a.keep) { a.keep = reinterpret_cast<const uint8_t*>(a.x.base); a.keep_head_stride = 0; a.ldkeep = 0; }   // any readable memory of >= Lmax bytes
+    a.has_bias = a.bias != nullptr;
+    a.vis = vis_fix(a.vis, a.x.base);
     if (!a.bias) { a.bias = a.x.base; a.ldbias = 0; }
-    BG_REQUIRE(a.D >= 4 && (a.has_keep || a.D * (int)sizeof(float) >= 0), "fused decode attention: bad width");
+    BG_REQUIRE(a.G == 1 || a.prefix % 16 == 0, "fused decode attention: a shared prefix must be a multiple of 16 keys (prefix=%d)", a.prefix);
+    BG_REQUIRE(!a.vis.has_chunks || a.vis.chunks_ld <= 1025, "fused decode attention: at most 1024 key chunks per row");
     const size_t lds = ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
     dim3 grid(a.H, a.B / a.G);

@@ -134,6 +134,26 @@ void launch_muse_null_kv_prep(const float* null_kv, const float* k_scale, void* 
 void launch_muse_kv_prep_split(const float* kvraw, const float* null_kv, const float* k_scale, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nk,
                                int Nk_pad, hipStream_t s);
 
+// Route A visibility of key k for query row r of head h:  attention_mask[r][k] != 0  AND  layout[h][r / blk][k / blk] != 0
+// (sparse_self_attention.py:63-85: only the nonzero blocks of the layout are ever computed; :153-173: the element mask inside them).
+// Kept as its two factors - ONE [L, L] byte plane shared by all layers / heads and the block layout - plus, per block row, the ascending list of the
+// 16-key chunks that contain a present block: the decode attention walks that list and never touches the K/V rows of absent blocks (no dense
+// [layers][heads][L][L] plane exists any more: 2.15 GB at BASELINE config 4 / density 0.35, now ~31 MB).
+struct SparseVis {
+    const uint8_t* allowed = nullptr; int ldallowed = 0; long allowed_head_stride = 0;   // [(H)][L][ld] 1 = allowed; null = every (row, key)
+    const uint8_t* lay = nullptr; long lay_head_stride = 0; int nb = 0, blk = 1;          // [H or 1][nb][nb] 1 = block present; null = every block
+    const uint16_t* chunks = nullptr; long chunks_head_stride = 0; int chunks_ld = 0;     // [H or 1][nb][chunks_ld]: count, then ascending chunk ids; null = walk all chunks
+    int has_allowed = 0, has_lay = 0, has_chunks = 0;                                     // filled in by vis_fix (absent tables alias valid memory)
+};
+// kernels load table entries UNCONDITIONALLY (a predicated load is a serialised round trip, see decode_fused.hip): absent tables point at `any_valid` (>= 4 readable bytes)
+inline SparseVis vis_fix(SparseVis v, const void* any_valid) {
+    v.has_allowed = v.allowed != nullptr; v.has_lay = v.lay != nullptr; v.has_chunks = v.chunks != nullptr;
+    if (!v.allowed) { v.allowed = reinterpret_cast<const uint8_t*>(any_valid); v.ldallowed = 0; v.allowed_head_stride = 0; }
+    if (!v.lay) { v.lay = reinterpret_cast<const uint8_t*>(any_valid); v.lay_head_stride = 0; v.nb = 0; v.blk = 1 << 30; }
+    if (!v.chunks) { v.chunks = reinterpret_cast<const uint16_t*>(any_valid); v.chunks_head_stride = 0; v.chunks_ld = 0; }
+    return v;
+}
+
 // Decode attention (Route A, one new query row per sequence): see attention.hip
 struct DecodeAttnArgs {
     const float* q = nullptr;        // [B, H*64] this step's query rows (row stride ldq)
@@ -142,9 +162,7 @@ struct DecodeAttnArgs {
     const void* vcache = nullptr;
     const float* bias = nullptr;     // [L, ldbias] camera-bias matrix (unscaled; row = n-1 is used) or null
     int ldbias = 0;
-    const uint8_t* keep = nullptr;   // [H or 1][L][ldkeep] 1 = visible (allowed AND layout block present); null = all visible
-    long keep_head_stride = 0;
-    int ldkeep = 0;
+    SparseVis vis;                   // which keys the row sees (element mask x block layout); this kernel masks per key, it does not skip
     const float* append_k = nullptr; // this step's key / value rows [B, H*64] (row stride ldq): written into cache row n-1 by the kernel itself
     const float* append_v = nullptr; //   (fused KV append, saves one launch per layer); null = the cache already holds row n-1
     const float* R = nullptr;        // residual [B, H*64] (row stride ldr) or null
@@ -185,14 +203,14 @@ struct ArAttnFusedArgs {
     void* vcache = nullptr;
     int kv_dtype = 0;                  // 0 fp32, 1 fp16 storage
     const float* bias = nullptr; int ldbias = 0;                               // camera-bias matrix [L, ldbias] (unscaled) or null
-    const uint8_t* keep = nullptr; long keep_head_stride = 0; int ldkeep = 0;  // visibility [H or 1][L][ldkeep]
+    SparseVis vis;                     // visibility of the keys (element mask x block layout) + the chunk lists the key walk follows
     float* out = nullptr; int ldo = 0; // x2 [B, D] = ln1(x) + attention
     int B = 0, G = 1, H = 0, D = 0, Lmax = 0, Lpad = 0;
     int n = 0; const int* d_n = nullptr; int n_hint = 0;                        // context length incl. the new key = n (+ *d_n)
     int prefix = 0;                    // G > 1: leading keys shared by the G sequences of a group (read from the group's first cache slot)
     float scale = 0.125f;
     long long* trace = nullptr;        // diagnostics: [workgroup][8] device timestamps (100 MHz) at the phase boundaries, or null
-    int has_keep = 0, has_bias = 0;    // filled in by the launcher
+    int has_bias = 0;                  // filled in by the launcher
 };
 bool ar_attn_fused_supported(int B, int G, int D, int H);
 void launch_ar_attn_fused(const ArAttnFusedArgs& a, hipStream_t s);

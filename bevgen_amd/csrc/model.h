@@ -82,10 +82,23 @@ struct Ctx {
     // ---- Route A
     std::vector<ArLayer> ar;
     float* head_wp = nullptr;      // packed head.weight (fused decode path)
-    uint8_t* keep = nullptr;       // [keep_layers, Hk, L, L]
-    int keep_heads = 1, keep_layers = 1;   // planes per layer (1 = shared by all heads) / layers with their own planes (1 = shared)
-    float* prefill_bias = nullptr; // [keep_layers, Hk, K, Kpad]
+    // visibility = element mask x block layout (kernels.h SparseVis): one [L, L] byte plane + per layer (or shared) block layouts and key-chunk lists
+    uint8_t* allowed = nullptr;    // [L, L]
+    uint8_t* lay = nullptr;        // [keep_layers, Hk, nb, nb]
+    uint16_t* chunks = nullptr;    // [keep_layers, Hk, nb, chunks_ld] or null when no layer can skip anything (every block at or below the diagonal present)
+    int chunks_ld = 0;
+    int keep_heads = 1, keep_layers = 1;   // layouts per layer (1 = shared by all heads) / layers with their own layouts (1 = shared)
+    float* prefill_bias = nullptr; // [Hk, K, Kpad] when the layers share a layout; else built per layer in the prefill's workspace
     int Kpad = 0;
+    SparseVis vis_of_layer(int i) const {
+        SparseVis v;
+        const int nb = L / cfg.sparse_block_size;
+        const size_t li = keep_layers > 1 ? (size_t)i : 0;
+        v.allowed = allowed; v.ldallowed = L; v.allowed_head_stride = 0;
+        v.lay = lay + li * keep_heads * nb * nb; v.lay_head_stride = keep_heads > 1 ? (long)nb * nb : 0; v.nb = nb; v.blk = cfg.sparse_block_size;
+        if (chunks) { v.chunks = chunks + li * keep_heads * nb * chunks_ld; v.chunks_head_stride = keep_heads > 1 ? (long)nb * chunks_ld : 0; v.chunks_ld = chunks_ld; }
+        return v;
+    }
     // per-batch decode state (lives in `persist`)
     struct ArState {
         int B = 0, step = 0;        // step = number of image tokens already fed
@@ -178,9 +191,10 @@ void launch_vq_argmin(const float* dots, const float* zz, const float* ee, int64
 // tables.hip
 void launch_build_attn_bias(const float* tril_emb /*or null*/, const float* prob /*or null*/, float* out, int L, hipStream_t s);
 void launch_build_muse_bias(const float* attn_bias, int L, int K, int N, float* bias_self, int ldS, float* bias_cross, int ldC, hipStream_t s);
-void launch_build_keep(const float* allowed, const int64_t* layout, uint8_t* keep, int heads, int L, int block, hipStream_t s);
-void launch_build_masked_bias(const float* add /*[L,L] or null*/, const uint8_t* keep, long keep_head_stride, int ldkeep, float* out, int heads, int rows, int cols,
-                              int ldout, int ldadd, float scale, hipStream_t s);
+void launch_build_allowed(const float* mask, uint8_t* out, long n, hipStream_t s);
+void launch_build_layout(const int64_t* layout, uint8_t* lay, uint16_t* chunks, int heads, int nb, int blk, int L, int chunks_ld, hipStream_t s);
+void launch_build_masked_bias(const float* add /*[L,L] or null*/, const SparseVis& vis, float* out, int heads, int rows, int cols, int ldout, int ldadd, float scale,
+                              hipStream_t s);
 void launch_ar_step_embed(const int64_t* tok, const float* tok_emb, const float* img_embed, const float* pos_emb, const int64_t* fwd_idx, const int* d_step,
                           float* x, int B, int C, int T, int D, int vocab_rows, hipStream_t s);
 void launch_store_tokens(const int64_t* tok, const int64_t* fwd_idx, const int* d_step, int64_t* out, int B, int N, hipStream_t s);

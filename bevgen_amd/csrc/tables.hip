@@ -34,34 +34,51 @@ void launch_build_muse_bias(const float* ab, int L, int K, int N, float* bs, int
     LAUNCH_CHECK();
 }
 
-// Route A visibility: keep[h][r][c] = attention_mask[r][c] != 0  AND  layout[h][r/blk][c/blk] != 0   (sparse_self_attention.py:153-173)
-__global__ void build_keep_kernel(const float* __restrict__ allowed, const int64_t* __restrict__ layout, uint8_t* __restrict__ keep, int L, int block) {
-    const int h = blockIdx.y;
+// Route A visibility = element mask x block layout (sparse_self_attention.py:63-85, 153-173), kept as its factors (kernels.h SparseVis)
+__global__ void build_allowed_kernel(const float* __restrict__ mask, uint8_t* __restrict__ out, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)L * L) return;
-    const int r = (int)(i / L), c = (int)(i % L);
-    const int nb = L / block;
-    const bool present = layout[((long)h * nb + r / block) * nb + c / block] != 0;
-    keep[(long)h * L * L + i] = (present && allowed[i] != 0.f) ? 1 : 0;
+    if (i < n) out[i] = mask[i] != 0.f ? 1 : 0;
 }
-void launch_build_keep(const float* allowed, const int64_t* layout, uint8_t* keep, int heads, int L, int block, hipStream_t s) {
-    hipLaunchKernelGGL(build_keep_kernel, dim3(cdiv((long)L * L, 256), heads), dim3(256), 0, s, allowed, layout, keep, L, block);
+void launch_build_allowed(const float* mask, uint8_t* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(build_allowed_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, mask, out, n);
+    LAUNCH_CHECK();
+}
+// layout int64 [heads, nb, nb] -> lay uint8 [heads, nb, nb] and, per (head, block row), chunks[0] = count, chunks[1..] = ascending ids of the 16-key chunks that
+// overlap a present block (chunks_ld >= ceil(L / 16) + 1).  One thread per (head, block row): setup-time work.
+__global__ void build_layout_kernel(const int64_t* __restrict__ layout, uint8_t* __restrict__ lay, uint16_t* __restrict__ chunks, int heads, int nb, int blk, int L, int chunks_ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= heads * nb) return;
+    const int64_t* src = layout + (long)i * nb;
+    uint8_t* dst = lay + (long)i * nb;
+    for (int j = 0; j < nb; ++j) dst[j] = src[j] != 0 ? 1 : 0;
+    uint16_t* out = chunks + (long)i * chunks_ld;
+    int cnt = 0;
+    for (int c = 0; c * 16 < L; ++c) {
+        bool any = false;
+        for (int k = c * 16; k < min(L, c * 16 + 16) && !any; k += (blk < 16 ? blk : 16)) any = src[k / blk] != 0;
+        if (any) out[1 + cnt++] = (uint16_t)c;
+    }
+    out[0] = (uint16_t)cnt;
+}
+void launch_build_layout(const int64_t* layout, uint8_t* lay, uint16_t* chunks, int heads, int nb, int blk, int L, int chunks_ld, hipStream_t s) {
+    hipLaunchKernelGGL(build_layout_kernel, dim3(cdiv(heads * nb, 64)), dim3(64), 0, s, layout, lay, chunks, heads, nb, blk, L, chunks_ld);
     LAUNCH_CHECK();
 }
 
-// out[h][r][c] = keep ? scale * add[r][c] : -1e30   (c >= cols -> -1e30): bias operand of the flash kernel for Route A
-__global__ void build_masked_bias_kernel(const float* __restrict__ add, const uint8_t* __restrict__ keep, long keep_head_stride, int ldkeep, float* __restrict__ out,
-                                         int rows, int cols, int ldout, int ldadd, float scale) {
+// out[h][r][c] = visible(h, r, c) ? scale * add[r][c] : -1e30   (c >= cols -> -1e30): bias operand of the flash kernel for Route A (prefill, operator seam)
+__global__ void build_masked_bias_kernel(const float* __restrict__ add, SparseVis v, float* __restrict__ out, int rows, int cols, int ldout, int ldadd, float scale) {
     const int r = blockIdx.x, h = blockIdx.y;
+    const uint8_t* arow = v.allowed + (long)h * v.allowed_head_stride + (long)r * v.ldallowed;
+    const uint8_t* lrow = v.lay + (long)h * v.lay_head_stride + (long)(r / v.blk) * v.nb;
     for (int c = threadIdx.x; c < ldout; c += blockDim.x) {
-        float v = kNegBig;
-        if (c < cols && keep[h * keep_head_stride + (long)r * ldkeep + c]) v = add ? scale * add[(long)r * ldadd + c] : 0.f;
-        out[((long)h * rows + r) * ldout + c] = v;
+        float val = kNegBig;
+        if (c < cols && (!v.has_allowed || arow[c]) && (!v.has_lay || lrow[c / v.blk])) val = add ? scale * add[(long)r * ldadd + c] : 0.f;
+        out[((long)h * rows + r) * ldout + c] = val;
     }
 }
-void launch_build_masked_bias(const float* add, const uint8_t* keep, long keep_head_stride, int ldkeep, float* out, int heads, int rows, int cols, int ldout,
-                              int ldadd, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(build_masked_bias_kernel, dim3(rows, heads), dim3(256), 0, s, add, keep, keep_head_stride, ldkeep, out, rows, cols, ldout, ldadd, scale);
+void launch_build_masked_bias(const float* add, const SparseVis& v0, float* out, int heads, int rows, int cols, int ldout, int ldadd, float scale, hipStream_t s) {
+    const SparseVis v = vis_fix(v0, out);
+    hipLaunchKernelGGL(build_masked_bias_kernel, dim3(rows, heads), dim3(256), 0, s, add, v, out, rows, cols, ldout, ldadd, scale);
     LAUNCH_CHECK();
 }
 

@@ -401,6 +401,19 @@ class Context:
                                                          B, H, int(n), Lmax, float(scale), _ptr(out), self._s()))
         return out
 
+    def op_ar_attn_fused(self, x, ln_w, ln_b, wqkv, bqkv, kcache, vcache, n, *, partial=None, rbias=None, bias=None, attn_mask=None, layout=None, block=1, G=1, prefix=0,
+                         kv_dtype=0, w_f16=False):
+        """Attention half of a fused Route A decode layer (appends k/v to cache row n-1 in place) -> x2 [B, D]."""
+        B, D = x.shape
+        H = D // 64
+        Lmax = kcache.shape[2]
+        out = torch.empty((B, D), dtype=torch.float32, device=self.device)
+        ns = 0 if partial is None else partial.shape[0]
+        self._check(self.lib.bevgen_op_ar_attn_fused(self._h, _ptr(x), _ptr(partial), ns, _ptr(rbias), _ptr(ln_w), _ptr(ln_b), _ptr(wqkv), _ptr(bqkv), int(w_f16),
+                                                     _ptr(kcache), _ptr(vcache), int(kv_dtype), _ptr(bias), 0 if bias is None else bias.shape[-1], _ptr(attn_mask),
+                                                     _ptr(layout), int(block), B, int(G), H, int(n), Lmax, int(prefix), _ptr(out), self._s()))
+        return out
+
     def op_conv3x3(self, x_nhwc, w_ohwi, bias, residual=None, upsample=False):
         n, H, W, Cin = x_nhwc.shape
         Cout = w_ohwi.shape[0]

@@ -218,6 +218,16 @@ int bevgen_op_attention(bevgen_ctx* ctx, const float* d_q, const float* d_k, con
 int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* d_q, const void* d_kcache, const void* d_vcache, int kv_dtype,
                                const float* d_bias, int ldbias, const uint8_t* d_keep, int ldkeep, long keep_head_stride,
                                int B, int H, int n, int Lmax, float scale, float* d_out, void* stream);
+/* Attention half of one Route A decode layer as the fused path runs it (decode_fused.hip ar_attn_fused_kernel; Block.forward mingpt_sparse.py:240-253 +
+ * SparseSelfAttention.forward sparse_self_attention.py:150-176) for ONE new row per sequence:
+ *   row = d_x[b] (+ d_rbias + sum of the ns split-K partials d_partial [ns, B, D]) -> xn = ln1(row) -> q | k | v = Wqkv xn + bqkv (fused [3D, D]) ->
+ *   k, v written to cache row n-1 -> softmax(dh^-0.5 (q k^T + d_bias[n-1, :]) + mask) v over keys 0..n-1 -> d_out[b] = xn + attention.
+ * Visibility as the reference defines it: d_attn_mask [L, L] fp32 (0 = hidden) AND d_layout int64 [H, L/block, L/block] (0 = block absent, never read);
+ * either may be NULL.  G > 1: consecutive groups of G sequences share their first `prefix` keys, read from the group's first cache slot.
+ * kv_dtype 0 fp32 / 1 fp16 cache [B, H, Lmax, 64]; w_f16 != 0: the projection weights are rounded to fp16 and streamed as 2-byte values. */
+int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* d_x, const float* d_partial, int ns, const float* d_rbias, const float* d_ln_w, const float* d_ln_b,
+                            const float* d_wqkv, const float* d_bqkv, int w_f16, void* d_kcache, void* d_vcache, int kv_dtype, const float* d_bias, int ldbias,
+                            const float* d_attn_mask, const int64_t* d_layout, int block, int B, int G, int H, int n, int Lmax, int prefix, float* d_out, void* stream);
 int bevgen_op_conv3x3(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_w_ohwi, const float* d_bias, const float* d_residual,
                       float* d_y_nhwc, int n, int H, int W, int Cin, int Cout, int upsample2x, void* stream);
 int bevgen_op_groupnorm(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_gamma, const float* d_beta, float* d_y, int n, int hw, int C,

@@ -252,3 +252,124 @@ def test_gemm_split_precision_small_and_large_magnitudes(gpu_ctx, mode):
     da, dw = dev(a), dev(w)
     gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), None, None, _ptr(out), 256, 128, 256, 0, mode, _stream()))
     assert rel(out.cpu().double(), ref) < 2e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------- fused Route A decode kernels (operator level)
+def _ar_attn_reference(x, partial, rbias, ln_w, ln_b, wqkv, bqkv, kc, vc, n, bias, mask, layout, blk, G, prefix, scale=0.125):
+    """fp64 statement of one decode row through ln1 -> q/k/v -> cache append -> masked softmax attention -> + ln1(x) (gpt:240-253, ssa:150-176).
+    Returns (x2 [B, D], new k row [B, H, 64], new v row).  Groups of G sequences read keys [0, prefix) from the group's first cache slot."""
+    B, D = x.shape
+    H = D // 64
+    row = x.double()
+    if partial is not None:
+        row = row + (partial.double().sum(0) + (rbias.double() if rbias is not None else 0))
+    xn = F.layer_norm(row, (D,), ln_w.double(), ln_b.double(), 1e-5)
+    qkv = xn @ wqkv.double().t() + bqkv.double()
+    q, k, v = (t.reshape(B, H, 64) for t in qkv.split(D, dim=1))
+    kcd, vcd = kc.double().clone(), vc.double().clone()
+    kcd[:, :, n - 1], vcd[:, :, n - 1] = k, v
+    out = torch.empty(B, H, 64, dtype=torch.float64)
+    r = n - 1
+    for b in range(B):
+        src = torch.full((n,), b)
+        if G > 1:
+            src[: min(prefix, n)] = (b // G) * G
+        kk = kcd[src, :, torch.arange(n)].permute(1, 0, 2)   # [H, n, 64]
+        vv = vcd[src, :, torch.arange(n)].permute(1, 0, 2)
+        s = torch.einsum("hd,hjd->hj", q[b], kk)
+        if bias is not None:
+            s = s + bias[r, :n].double()
+        s = s * scale
+        vis = torch.ones(H, n, dtype=torch.bool)
+        if mask is not None:
+            vis &= (mask[r, :n] != 0)[None]
+        if layout is not None:
+            vis &= layout[:, r // blk, torch.arange(n) // blk] != 0
+        s = s.masked_fill(~vis, float("-inf"))
+        out[b] = torch.einsum("hj,hjd->hd", s.softmax(-1), vv)
+    return xn + out.reshape(B, D), k, v
+
+
+@pytest.mark.parametrize("kv", ["f32", "f16"])
+@pytest.mark.parametrize("B,G,H,n,Lmax,blk,sparse", [
+    (1, 1, 2, 1, 64, 16, False),        # first key only
+    (2, 1, 4, 77, 128, 4, True),        # ragged length, 4-key blocks (several blocks per 16-key chunk)
+    (3, 1, 16, 600, 640, 16, True),
+    (16, 1, 16, 2368, 2368, 16, True),  # BASELINE config 4 at the last position, n = L
+    (16, 1, 16, 1301, 2368, 16, False),
+    (4, 2, 4, 300, 512, 16, True),      # two sequences per layout sharing a 64-key prefix
+    (8, 4, 8, 333, 512, 32, True),      # four per layout, 32-key blocks (two chunks per block)
+    (8, 4, 8, 64, 512, 16, False),      # nothing beyond the shared prefix yet except the new key at n - 1 = 63 ... prefix 48
+])
+def test_ar_attn_fused_operator(gpu_ctx, B, G, H, n, Lmax, blk, sparse, kv):
+    """ar_attn_fused_kernel (ln1 + q/k/v + cache append + block-sparse decode attention + residual) against fp64, over batch sizes, context lengths incl. n = 1 and
+    n = L, layout groups G in {1, 2, 4}, both cache dtypes, with element mask + random per-head block layout (absent blocks are skipped, not masked)."""
+    D = H * 64
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    x = torch.randn(B, D, generator=g)
+    partial = torch.randn(3, B, D, generator=g) * 0.3
+    rbias = torch.randn(D, generator=g) * 0.1
+    ln_w, ln_b = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.1
+    wqkv = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bqkv = torch.randn(3 * D, generator=g) * 0.1
+    kc = torch.randn(B, H, Lmax, 64, generator=g)
+    vc = torch.randn(B, H, Lmax, 64, generator=g)
+    bias = torch.randn(Lmax, Lmax, generator=g)
+    prefix = 0 if G == 1 else (48 if n <= 64 else 64)
+    mask = layout = None
+    if sparse:
+        mask = (torch.rand(Lmax, Lmax, generator=g) > 0.2).float()
+        layout = (torch.rand(H, Lmax // blk, Lmax // blk, generator=g) < 0.4).long()
+        mask[:, 0] = 1
+        layout[:, :, 0] = 1   # every row keeps something
+    if kv == "f16":
+        kc, vc = kc.half().float(), vc.half().float()   # the cache holds fp16-representable values; the appended row is rounded by the kernel
+    ref, k_new, v_new = _ar_attn_reference(x, partial, rbias, ln_w, ln_b, wqkv, bqkv, kc, vc, n, bias, mask, layout, blk, G, prefix)
+    cdt = torch.float16 if kv == "f16" else torch.float32
+    dkc, dvc = dev(kc.to(cdt)), dev(vc.to(cdt))
+    out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dkc, dvc, n, partial=dev(partial), rbias=dev(rbias), bias=dev(bias),
+                                   attn_mask=None if mask is None else dev(mask), layout=None if layout is None else dev(layout), block=blk, G=G, prefix=prefix,
+                                   kv_dtype=1 if kv == "f16" else 0)
+    tol = 2e-3 if kv == "f16" else 2e-5   # f16: the new k/v row is stored rounded (11 bits) before it is read back
+    assert rel(out.cpu().double(), ref) < tol
+    # the appended rows
+    assert rel(dkc[:, :, n - 1].float().cpu().double(), k_new) < (1e-3 if kv == "f16" else 1e-5)
+    assert rel(dvc[:, :, n - 1].float().cpu().double(), v_new) < (1e-3 if kv == "f16" else 1e-5)
+    # nothing else in the cache was touched
+    keep = torch.ones(Lmax, dtype=torch.bool)
+    keep[n - 1] = False
+    assert torch.equal(dkc[:, :, keep].float().cpu(), kc[:, :, keep]) and torch.equal(dvc[:, :, keep].float().cpu(), vc[:, :, keep])
+
+
+def test_ar_attn_fused_operator_f16_weights(gpu_ctx):
+    B, H, n, Lmax = 16, 16, 700, 1024
+    D = H * 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, D, generator=g)
+    ln_w, ln_b = torch.ones(D), torch.zeros(D)
+    wqkv = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bqkv = torch.randn(3 * D, generator=g) * 0.1
+    kc, vc = torch.randn(B, H, Lmax, 64, generator=g), torch.randn(B, H, Lmax, 64, generator=g)
+    ref, _, _ = _ar_attn_reference(x, None, None, ln_w, ln_b, wqkv.half().float(), bqkv, kc, vc, n, None, None, None, 16, 1, 0)
+    out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dev(kc), dev(vc), n, w_f16=True)
+    assert rel(out.cpu().double(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,ln,gelu", [(16, 4096, 1024, True, True), (16, 1024, 4096, False, False), (64, 1024, 1024, True, False), (5, 1000, 1024, True, False),
+                                           (16, 256, 256, True, True), (33, 512, 2048, False, False)])
+def test_ln_gemm_operator(gpu_ctx, M, N, K, ln, gelu):
+    """skinny_fused_kernel through bevgen_op_ln_gemm: act(LayerNorm?(A) W^T + bias) for the decode-step shapes (ln2 + MLP-up + GELU, MLP-down split over K with the
+    partial sums added by the consumer, ln_f + head) against fp64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 1.7 + 0.3
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.2
+    lw, lb = torch.randn(K, generator=g) * 0.2 + 1, torch.randn(K, generator=g) * 0.1
+    h = F.layer_norm(a.double(), (K,), lw.double(), lb.double(), 1e-5) if ln else a.double()
+    ref = h @ w.double().t()
+    if ln:   # the split-K form carries neither bias nor activation (the consumer adds them)
+        ref = ref + b.double()
+        if gelu:
+            ref = F.gelu(ref)
+    out = gpu_ctx.op_ln_gemm(dev(a), dev(w), ln_w=dev(lw) if ln else None, ln_b=dev(lb) if ln else None, bias=dev(b) if ln else None, gelu=gelu and ln)
+    assert rel(out.cpu().double(), ref) < 6e-6

@@ -24,7 +24,7 @@ __device__ __forceinline__ void bar_sync(Bar& b) {
         const unsigned target = b.gen * b.nwg;
         unsigned spins = 0;
         while (__hip_atomic_load(b.counter, __ATOMIC_RELAXED, AG) < target) {
-            if (++spins > (1u << 20)) { __hip_atomic_store(b.error, 1u, __ATOMIC_RELAXED, AG); break; }
+            if (++spins > (1u << 16) || __hip_atomic_load(b.error, __ATOMIC_RELAXED, AG)) { __hip_atomic_store(b.error, 1u, __ATOMIC_RELAXED, AG); break; }
         }
     }
     __syncthreads();
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(1024) void xchg_kernel(float* X, unsigned long long
     const int ncols = nwg * 16;   // 4096 at 256 workgroups
     unsigned bad = 0;
     for (int r = 0; r < rounds; ++r) {
+        if (__hip_atomic_load(error, __ATOMIC_RELAXED, AG)) break;   // a timed-out barrier: drain
         float* Xr = X + (size_t)(r & 1) * 16 * ncols;
         unsigned long long* X2r = X2 + (size_t)(r & 1) * 16 * ncols;
         // ---- produce: 16 x 16 block, thread t < 256 -> (row t >> 4, col 16 wg + (t & 15))
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(1024) void xchg_kernel(float* X, unsigned long long
                     got[j] = __uint_as_float((unsigned)pk);
                     ok = ok && (unsigned)(pk >> 32) == (unsigned)(r + 1);
                 }
-                if (++spins > (1u << 16)) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, AG); break; }
+                if (++spins > (1u << 12) || __hip_atomic_load(error, __ATOMIC_RELAXED, AG)) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, AG); break; }
             }
             // a consumer must not run two rounds ahead of a producer that still has to read the buffer being overwritten: rounds alternate buffers and
             // every workgroup both produces and consumes each round, so a producer of round r+2 has consumed round r+1, which needs everyone's round r+1 block,
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(1024) void xchg_kernel(float* X, unsigned long long
 
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 1000;
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int nwg = prop.multiProcessorCount;
@@ -122,6 +124,7 @@ int main(int argc, char** argv) {
             unsigned herr, hm;
             CK(hipMemcpy(&herr, error, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hm, mism, 4, hipMemcpyDeviceToHost));
             printf("variant %d (%s): %.3f us / round, timeout=%u mismatches=%u\n", v, names[v], 1000.0 * ms / rounds, herr, hm);
+            fflush(stdout);
         }
     }
     return 0;
