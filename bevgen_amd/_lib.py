@@ -39,7 +39,7 @@ class bevgen_cfg(C.Structure):
         ("ff_inner", C.c_int32), ("max_batch", C.c_int32),
         ("vq_ch", C.c_int32), ("vq_num_res_blocks", C.c_int32), ("vq_z_channels", C.c_int32), ("vq_embed_dim", C.c_int32),
         ("vq_n_embed", C.c_int32), ("vq_resolution", C.c_int32), ("vq_out_ch", C.c_int32), ("vq_num_levels", C.c_int32),
-        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("vq_in_channels", C.c_int32), ("kv_cache_dtype", C.c_int32), ("decode_path", C.c_int32), ("decode_weight_dtype", C.c_int32), ("weight_dtype", C.c_int32), ("reserved", C.c_int32 * 11),
+        ("vq_ch_mult", C.c_int32 * 8), ("vq_attn_resolution", C.c_int32), ("vq_in_channels", C.c_int32), ("kv_cache_dtype", C.c_int32), ("decode_path", C.c_int32), ("decode_weight_dtype", C.c_int32), ("weight_dtype", C.c_int32), ("decode_chains", C.c_int32), ("reserved", C.c_int32 * 10),
     ]
 
 

@@ -273,32 +273,54 @@ void ar_logits(Ctx& c, float* logits, hipStream_t s) {
     head_logits(c, w, st.B, logits, s);
 }
 
-// Fused form of the step (decode_fused.hip): per layer {ln1 + qkv + attention, ln2 + MLP up + GELU, MLP down split over K}; the down-projection's
-// partial sums, bias and residual are folded into the next consumer's row fetch (RowSrc), the last layer's into the hidden-state write.
-static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipStream_t s) {
+// Number of independent sequence groups ("chains") the fused step is cut into.  A decode step is a chain of ~75 short, strictly dependent kernels; each one pays its ramp,
+// one cold weight burst and its tail alone (the weight-streaming projections reach ~2 TB/s while they run, the chip idles in between).  Sequences are independent, so
+// the batch is cut into chains enqueued on separate streams: the hardware then always has another chain's kernel to run - a projection's 16.8 MB weight burst under the
+// other chain's K/V stream.  The price: every chain streams the layer's projection weights (50 MB / layer with fp32 storage) itself; the second read of a matrix
+// follows the first within a layer and is served by the memory-side cache.  (A persistent single-launch layer was measured instead and rejected: a grid-wide
+// exchange between phases costs 7.9 us on this 8-XCD part, profiles/r03_xchg_probe.txt - more than a kernel boundary.)
+static int decode_chains(const Ctx& c, int B, int G) {
+    int n = c.cfg.decode_chains;
+    if (n <= 0) n = (B / G) >= 8 ? 2 : 1;   // two chains of >= 4 layout groups each; smaller batches keep one
+    n = std::min(n, 4);
+    while (n > 1 && ((B / G) % n != 0 || (B / G) / n < 1)) --n;
+    if (c.trace) n = 1;   // the phase-timestamp buffers are indexed by workgroup of ONE launch per kind
+    return n;
+}
+
+// One chain = the sequences [r0, r0 + Bc) through all layers.  Fused form of the step (decode_fused.hip): per layer {ln1 + qkv + attention, ln2 + MLP up + GELU,
+// MLP down split over K}; the down-projection's partial sums, bias and residual are folded into the next consumer's row fetch (RowSrc), the last layer's into
+// the hidden-state write.
+static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, int Bc, int* counter, hipStream_t s) {
     const auto& g = c.cfg;
     auto& st = c.ars;
     const int D = c.D, H = c.H, B = st.B, L = c.L;
-    launch_ar_step_embed(tok, c.pf("x_tok_emb.weight"), st.img_embed, c.pf("x_pos_emb"), c.fwd_idx, st.d_step, w.x, B, g.num_cams, c.T, D, g.vocab_size + 1, s);
-    const size_t layer_bytes = (size_t)B * H * L * 64 * cache_elem_bytes(c);
+    const size_t eb = cache_elem_bytes(c);
+    float* x = w.x + (size_t)r0 * D;
+    launch_ar_step_embed(tok + r0, c.pf("x_tok_emb.weight"), st.img_embed ? st.img_embed + (size_t)r0 * g.num_cams * c.T * D : nullptr, c.pf("x_pos_emb"), c.fwd_idx,
+                         st.d_step, x, Bc, g.num_cams, c.T, D, g.vocab_size + 1, s);
+    const size_t layer_bytes = (size_t)B * H * L * 64 * eb;
+    const size_t chain_off = (size_t)r0 * H * L * 64 * eb;    // this chain's first cache slot inside a layer
     const int ks = skinny_fused_ksplit(D, 4 * D);
     const int wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
+    float* part = w.part + (size_t)ks * r0 * D;               // [ks][Bc][D] per chain, chains back to back
+    float* m1 = w.m1 + (size_t)r0 * 4 * D;
     RowSrc src;
-    src.base = w.x; src.ld = D;
+    src.base = x; src.ld = D;
     for (int i = 0; i < g.num_layers; ++i) {
         const ArLayer& l = c.ar[i];
-        float* x2 = (i & 1) ? w.x2b : w.x2;
+        float* x2 = ((i & 1) ? w.x2b : w.x2) + (size_t)r0 * D;
         ArAttnFusedArgs a;
         a.x = src;
         a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;
         a.wqkv = l.wqkv; a.bqkv = l.bqkv; a.wqkv_h = l.wqkv_h;
-        a.kcache = reinterpret_cast<char*>(st.kcache) + i * layer_bytes;
-        a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes;
+        a.kcache = reinterpret_cast<char*>(st.kcache) + i * layer_bytes + chain_off;
+        a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes + chain_off;
         a.kv_dtype = cache_dtype(c);
         a.bias = c.attn_bias; a.ldbias = L;
         a.vis = c.vis_of_layer(i);
         a.out = x2; a.ldo = D;
-        a.B = B; a.G = st.G; a.H = H; a.D = D; a.Lmax = L;
+        a.B = Bc; a.G = st.G; a.H = H; a.D = D; a.Lmax = L;
         a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step;
         a.prefix = c.K; a.scale = 0.125f;
         a.trace = c.trace;
@@ -307,27 +329,59 @@ static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipS
         up.A = x2; up.lda = D;
         up.ln_w = l.ln2_w; up.ln_b = l.ln2_b; up.eps = 1e-5f;
         up.Wp = l.mlp0_wp; up.w_f16 = wf16; up.bias = l.mlp0_b;
-        up.C = w.m1; up.ldc = 4 * D;
-        up.M = B; up.N = 4 * D; up.K = D; up.ksplit = 1; up.act = ACT_GELU;
+        up.C = m1; up.ldc = 4 * D;
+        up.M = Bc; up.N = 4 * D; up.K = D; up.ksplit = 1; up.act = ACT_GELU;
         up.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
         launch_skinny_fused(up, s);
         SkinnyFusedArgs dn;
-        dn.A = w.m1; dn.lda = 4 * D;
+        dn.A = m1; dn.lda = 4 * D;
         dn.Wp = l.mlp2_wp; dn.w_f16 = wf16;
-        dn.M = B; dn.N = D; dn.K = 4 * D; dn.ksplit = ks;
+        dn.M = Bc; dn.N = D; dn.K = 4 * D; dn.ksplit = ks;
         dn.trace = c.trace ? c.trace + 2 * 4096 * 8 : nullptr;
         if (ks > 1) {
-            dn.C = w.part;
+            dn.C = part;
             src = RowSrc{};
-            src.base = x2; src.ld = D; src.partial = w.part; src.ns = ks; src.pstride = (long)B * D; src.pld = D; src.bias = l.mlp2_b;
+            src.base = x2; src.ld = D; src.partial = part; src.ns = ks; src.pstride = (long)Bc * D; src.pld = D; src.bias = l.mlp2_b;
         } else {   // narrow models: the whole K fits one workgroup; bias here, residual through the row source
-            dn.C = w.h; dn.ldc = D; dn.bias = l.mlp2_b;
+            float* hrow = w.h + (size_t)r0 * D;
+            dn.C = hrow; dn.ldc = D; dn.bias = l.mlp2_b;
             src = RowSrc{};
-            src.base = x2; src.ld = D; src.partial = w.h; src.ns = 1; src.pstride = 0; src.pld = D;
+            src.base = x2; src.ld = D; src.partial = hrow; src.ns = 1; src.pstride = 0; src.pld = D;
         }
         launch_skinny_fused(dn, s);
     }
-    launch_rowsrc_materialize(src, st.hidden, B, D, st.d_step, s);   // hidden state of the new row + the step counter
+    launch_rowsrc_materialize(src, st.hidden + (size_t)r0 * D, Bc, D, counter, s);   // hidden state of the chain's new rows (+ the step counter when this is the only chain)
+}
+
+static void decode_step_launch_fused(Ctx& c, StepWs& w, const int64_t* tok, hipStream_t s) {
+    auto& st = c.ars;
+    const int B = st.B;
+    const int nch = decode_chains(c, B, st.G);
+    if (nch == 1) {
+        decode_chain_launch(c, w, tok, 0, B, st.d_step, s);
+        return;
+    }
+    // fork: chains 1.. on side streams behind everything already enqueued on s; join before the step counter moves (every kernel of the step reads it)
+    while ((int)c.chain_streams.size() < nch - 1) {
+        hipStream_t q;
+        hipEvent_t e;
+        HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.chain_streams.push_back(q);
+        c.chain_join.push_back(e);
+    }
+    if (!c.chain_fork) HIP_CHECK(hipEventCreateWithFlags(&c.chain_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(c.chain_fork, s));
+    const int Bc = B / nch;
+    for (int k = 1; k < nch; ++k) {
+        hipStream_t q = c.chain_streams[k - 1];
+        HIP_CHECK(hipStreamWaitEvent(q, c.chain_fork, 0));
+        decode_chain_launch(c, w, tok, k * Bc, Bc, nullptr, q);
+        HIP_CHECK(hipEventRecord(c.chain_join[k - 1], q));
+    }
+    decode_chain_launch(c, w, tok, 0, Bc, nullptr, s);
+    for (int k = 1; k < nch; ++k) HIP_CHECK(hipStreamWaitEvent(s, c.chain_join[k - 1], 0));
+    launch_increment(st.d_step, s);
 }
 
 // one new row through all layers; position / bias row / cache slot are derived from the device-side step counter
@@ -420,7 +474,7 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     HIP_CHECK(hipEventRecord(c.graph_ev_in, s));
     HIP_CHECK(hipStreamWaitEvent(q, c.graph_ev_in, 0));
     Ctx::GraphKey key;
-    key.B = B; key.G = st.G; key.top_k = top_k; key.greedy = greedy; key.kv = cache_dtype(c); key.temperature = temperature;
+    key.B = B; key.G = st.G; key.chains = fused_path(c, B, st.G) ? decode_chains(c, B, st.G) : 1; key.top_k = top_k; key.greedy = greedy; key.kv = cache_dtype(c); key.temperature = temperature;
     key.noise = greedy ? nullptr : noise_u; key.forced = forced; key.out = out; key.arena = c.arena.base; key.persist = c.persist.base; key.trace = c.trace;
     if (!c.graph_exec || !(c.graph_key == key)) {
         if (c.graph_exec) c.retire_graph(c.graph_exec, c.graph);

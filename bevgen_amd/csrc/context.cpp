@@ -64,6 +64,9 @@ Ctx::~Ctx() {
     if (graph_ev_in) (void)hipEventDestroy(graph_ev_in);
     if (graph_ev_out) (void)hipEventDestroy(graph_ev_out);
     if (graph_stream) (void)hipStreamDestroy(graph_stream);
+    for (hipStream_t q : chain_streams) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+    if (chain_fork) (void)hipEventDestroy(chain_fork);
+    for (hipEvent_t e : chain_join) (void)hipEventDestroy(e);
     for (auto& kv : params)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (void* p : owned) (void)hipFree(p);

@@ -135,13 +135,17 @@ struct Ctx {
     // ---- hipGraph replay of the Route A decode step
     hipStream_t graph_stream = nullptr;
     hipEvent_t graph_ev_in = nullptr, graph_ev_out = nullptr;
+    // side streams of the chain-pipelined decode step (chains 1..n-1; chain 0 runs on the step's own stream) and their fork / join events
+    std::vector<hipStream_t> chain_streams;
+    hipEvent_t chain_fork = nullptr;
+    std::vector<hipEvent_t> chain_join;
     std::vector<std::pair<hipGraphExec_t, hipGraph_t>> retired_graphs;
     // the instantiated decode-step graph is kept and replayed by later bevgen_ar_sample calls that bake in the same pointers / parameters
     struct GraphKey {
-        int B = 0, G = 0, top_k = 0, greedy = 0, kv = 0; float temperature = 0.f;
+        int B = 0, G = 0, top_k = 0, greedy = 0, kv = 0, chains = 0; float temperature = 0.f;
         const void *noise = nullptr, *forced = nullptr, *out = nullptr, *arena = nullptr, *persist = nullptr, *trace = nullptr;
         bool operator==(const GraphKey& o) const {
-            return B == o.B && G == o.G && top_k == o.top_k && greedy == o.greedy && kv == o.kv && temperature == o.temperature && noise == o.noise &&
+            return B == o.B && G == o.G && chains == o.chains && top_k == o.top_k && greedy == o.greedy && kv == o.kv && temperature == o.temperature && noise == o.noise &&
                    forced == o.forced && out == o.out && arena == o.arena && persist == o.persist && trace == o.trace;
         }
     } graph_key;

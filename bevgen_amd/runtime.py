@@ -53,7 +53,7 @@ class Context:
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
                  device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "fused", decode_weights: str = "f32",
-                 weights: Optional[str] = None):
+                 weights: Optional[str] = None, decode_chains: Optional[int] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("bevgen_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU path in the product")
@@ -80,6 +80,8 @@ class Context:
         # step streams 2-byte weights
         c.decode_weight_dtype = {"f32": _lib.W_F32, "f16": _lib.W_F16}[decode_weights]
         self.decode_weights = decode_weights
+        # Route A fused decode step: number of independent sequence groups enqueued on separate streams (0 = the library's choice; $BEVGEN_DECODE_CHAINS)
+        c.decode_chains = int(os.environ.get("BEVGEN_DECODE_CHAINS", "0")) if decode_chains is None else int(decode_chains)
         # weights='f16' (or $BEVGEN_WEIGHTS): the GEMM / convolution matrices are rounded to f16 at finalize - two MFMAs per product instead of three
         weights = weights or os.environ.get("BEVGEN_WEIGHTS", "f32")
         c.weight_dtype = {"f32": _lib.W_F32, "f16": _lib.W_F16}[weights]

@@ -80,7 +80,11 @@ typedef struct bevgen_cfg {
                                                           every call: muse bf16 autocast, sparse_self_attention.py:127) - activations keep their hi + lo planes, a
                                                           product is two MFMAs, and the results are fp32-class results OF THE ROUNDED MODEL.  Route A: together with
                                                           decode_weight_dtype = BEVGEN_W_F16 only */
-    int32_t reserved[11];
+    int32_t decode_chains;                             /* Route A fused decode step: the batch is cut into this many independent sequence groups ("chains") whose
+                                                          layer kernels are enqueued on separate HIP streams (one fork / join per step inside the captured graph), so
+                                                          that one chain's weight-streaming projections run under another chain's K/V stream instead of every short
+                                                          dependent kernel paying its ramp alone.  0 = the library's choice for the batch, 1 = a single chain */
+    int32_t reserved[10];
 } bevgen_cfg;
 
 typedef struct bevgen_ctx bevgen_ctx;
