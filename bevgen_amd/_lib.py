@@ -17,7 +17,7 @@ ABI_VERSION = 3
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
-DECODE_FUSED, DECODE_PER_OP = 0, 1
+DECODE_FUSED, DECODE_PER_OP, DECODE_SPLIT = 0, 1, 2
 VQ_OUT_RAW, VQ_OUT_DENORM, VQ_OUT_U8 = 0, 1, 2
 W_F32, W_F16 = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_F64 = 0, 1, 2, 3
@@ -75,7 +75,7 @@ SIGNATURES = {
     "bevgen_op_geglu_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "bevgen_op_attention": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "bevgen_op_decode_attention": (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _i, _f, _p, _p]),
-    "bevgen_op_ar_attn_fused": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "bevgen_op_ar_attn_fused": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "bevgen_op_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "bevgen_op_groupnorm": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "bevgen_decode_attention_splits": (_i, [_i, _i, _i]),

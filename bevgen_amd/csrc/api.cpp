@@ -326,7 +326,7 @@ int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* q, const void* kc, 
 
 int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partial, int ns, const float* rbias, const float* ln_w, const float* ln_b, const float* wqkv,
                             const float* bqkv, int w_f16, void* kc, void* vc, int kv_dtype, const float* bias, int ldbias, const float* attn_mask, const int64_t* layout,
-                            int block, int B, int G, int H, int n, int Lmax, int prefix, float* out, void* stream) {
+                            int block, int B, int G, int H, int n, int Lmax, int prefix, int split, float* out, void* stream) {
     return guarded(ctx, [&] {
         hipStream_t s = (hipStream_t)stream;
         const int D = H * 64, L = Lmax;
@@ -334,7 +334,7 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
         BG_REQUIRE(ar_attn_fused_supported(B, G, D, H), "op_ar_attn_fused: unsupported shape B=%d G=%d D=%d H=%d", B, G, D, H);
         BG_REQUIRE(!layout || (block >= 1 && L % block == 0), "op_ar_attn_fused: Lmax %d is not a multiple of the block size %d", L, block);
         const int nb = layout ? L / block : 0, cld = (int)cdiv(L, 16) + 1;
-        ctx->arena.reserve((size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * cld * 2 + (size_t)3 * D * D * 2 + 8 * 256);
+        ctx->arena.reserve((size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * cld * 2 + (size_t)3 * D * D * 2 + (split ? skinny_packed_floats(3 * D, D) * 4 + (size_t)B * 4 * D * 4 : 0) + 12 * 256);
         ctx->arena.reset();
         ArAttnFusedArgs a;
         a.x.base = x; a.x.ld = D;
@@ -368,6 +368,22 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
         a.out = out; a.ldo = D;
         a.B = B; a.G = G; a.H = H; a.D = D; a.Lmax = Lmax; a.n = n; a.prefix = prefix; a.scale = 0.125f;
         a.trace = ctx->trace;
+        if (split) {
+            BG_REQUIRE(skinny_fused_supported(B, 3 * D, D, true) && (!w_f16 || skinny_fused_f16_ok(3 * D, D, true)), "op_ar_attn_fused: the split form does not support B=%d D=%d", B, D);
+            float* wp = ctx->arena.get<float>(skinny_packed_floats(3 * D, D));
+            float* qkv = ctx->arena.get<float>((size_t)B * 3 * D);
+            float* xn = ctx->arena.get<float>((size_t)B * D);
+            if (w_f16) launch_pack_skinny_weight_f16(wqkv, wp, 3 * D, D, s);   // rounds to fp16 while packing
+            else launch_pack_skinny_weight(wqkv, wp, 3 * D, D, s);
+            SkinnyFusedArgs pq;
+            const RowSrc src = a.x;
+            pq.a_src = &src;
+            pq.ln_w = ln_w; pq.ln_b = ln_b; pq.Wp = wp; pq.w_f16 = w_f16; pq.bias = bqkv;
+            pq.C = qkv; pq.ldc = 3 * D; pq.xn_out = xn; pq.ldxn = D;
+            pq.M = B; pq.N = 3 * D; pq.K = D; pq.ksplit = 1;
+            launch_skinny_fused(pq, s);
+            a.qkv = qkv; a.xn = xn;
+        }
         launch_ar_attn_fused(a, s);
     });
 }

@@ -34,8 +34,10 @@ struct StepWs {
 };
 
 bool fused_path(const Ctx& c, int B, int G) {
-    if (c.cfg.decode_path != BEVGEN_DECODE_FUSED) return false;
+    if (c.cfg.decode_path != BEVGEN_DECODE_FUSED && c.cfg.decode_path != BEVGEN_DECODE_SPLIT) return false;
     const int D = c.D;
+    if (c.cfg.decode_path == BEVGEN_DECODE_SPLIT && !(skinny_fused_supported(B, 3 * D, D, true) && (c.cfg.decode_weight_dtype != BEVGEN_W_F16 || skinny_fused_f16_ok(3 * D, D, true))))
+        return false;
     if (G > 1 && c.K % 16 != 0) return false;   // the shared condition prefix must end on a 16-key chunk boundary (the per-operator path replicates it instead)
     return ar_attn_fused_supported(B, G, D, c.H) && skinny_fused_supported(B, 4 * D, D, true) && skinny_fused_supported(B, D, 4 * D, false) &&
            skinny_fused_supported(B, c.V, D, true) && ar_attn_fused_lds_bytes(G, D, (int)round_up(c.L, 4)) <= 64 * 1024 &&
@@ -305,15 +307,30 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
     const int wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
     float* part = w.part + (size_t)ks * r0 * D;               // [ks][Bc][D] per chain, chains back to back
     float* m1 = w.m1 + (size_t)r0 * 4 * D;
+    const bool split = g.decode_path == BEVGEN_DECODE_SPLIT;
+    float* qkv = w.qkv + (size_t)r0 * 3 * D;
+    float* xn = w.xn + (size_t)r0 * D;
     RowSrc src;
     src.base = x; src.ld = D;
     for (int i = 0; i < g.num_layers; ++i) {
         const ArLayer& l = c.ar[i];
         float* x2 = ((i & 1) ? w.x2b : w.x2) + (size_t)r0 * D;
         ArAttnFusedArgs a;
-        a.x = src;
-        a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;
-        a.wqkv = l.wqkv; a.bqkv = l.bqkv; a.wqkv_h = l.wqkv_h;
+        if (split) {   // LayerNorm + QKV projection of the chain's rows in one MFMA kernel (the weight is read once), ln1(x) kept for the residual
+            SkinnyFusedArgs pq;
+            pq.a_src = &src;
+            pq.ln_w = l.ln1_w; pq.ln_b = l.ln1_b; pq.eps = 1e-5f;
+            pq.Wp = l.wqkv_wp; pq.w_f16 = wf16; pq.bias = l.bqkv;
+            pq.C = qkv; pq.ldc = 3 * D;
+            pq.xn_out = xn; pq.ldxn = D;
+            pq.M = Bc; pq.N = 3 * D; pq.K = D; pq.ksplit = 1;
+            launch_skinny_fused(pq, s);
+            a.qkv = qkv; a.xn = xn;
+        } else {
+            a.x = src;
+            a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;
+            a.wqkv = l.wqkv; a.bqkv = l.bqkv; a.wqkv_h = l.wqkv_h;
+        }
         a.kcache = reinterpret_cast<char*>(st.kcache) + i * layer_bytes + chain_off;
         a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes + chain_off;
         a.kv_dtype = cache_dtype(c);

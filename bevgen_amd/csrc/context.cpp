@@ -231,7 +231,8 @@ static void finalize_ar(Ctx& c) {
     expect_shape(c, "cond_pos_emb", {1, c.K, D});
     expect_shape(c, "head.weight", {g.vocab_size, D});
     const bool wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
-    BG_REQUIRE(!wf16 || (g.decode_path == BEVGEN_DECODE_FUSED && D % 256 == 0), "decode_weights = f16 needs the fused decode path and dim %% 256 == 0 (dim = %d)", D);
+    const bool fused_like = g.decode_path == BEVGEN_DECODE_FUSED || g.decode_path == BEVGEN_DECODE_SPLIT;
+    BG_REQUIRE(!wf16 || (fused_like && D % 256 == 0), "decode_weights = f16 needs the fused decode path and dim %% 256 == 0 (dim = %d)", D);
     BG_REQUIRE(g.weight_dtype != BEVGEN_W_F16 || wf16, "Route A: weight_dtype = f16 needs decode_weight_dtype = f16 as well (prefill and decode must run ONE rounded model)");
     c.ar.resize(g.num_layers);
     for (int i = 0; i < g.num_layers; ++i) {
@@ -254,8 +255,13 @@ static void finalize_ar(Ctx& c) {
             launch_round_to_f16(const_cast<float*>(l.mlp0_w), nullptr, 4L * D * D, 0);
             launch_round_to_f16(const_cast<float*>(l.mlp2_w), nullptr, 4L * D * D, 0);
         }
-        if (c.cfg.decode_path == BEVGEN_DECODE_FUSED) {
+        if (fused_like) {
             const size_t eb = wf16 ? sizeof(_Float16) : sizeof(float);
+            if (g.decode_path == BEVGEN_DECODE_SPLIT) {
+                l.wqkv_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(3 * D, D) * eb));
+                if (wf16) launch_pack_skinny_weight_f16(l.wqkv, l.wqkv_wp, 3 * D, D, 0);
+                else launch_pack_skinny_weight(l.wqkv, l.wqkv_wp, 3 * D, D, 0);
+            }
             l.mlp0_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(4 * D, D) * eb));
             l.mlp2_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(D, 4 * D) * eb));
             if (wf16) {
@@ -271,7 +277,7 @@ static void finalize_ar(Ctx& c) {
         c.split_weight(l.mlp2_w, 4L * D * D);
     }
     if (wf16) launch_round_to_f16(const_cast<float*>(c.pf("head.weight")), nullptr, (long)g.vocab_size * D, 0);
-    if (c.cfg.decode_path == BEVGEN_DECODE_FUSED) {
+    if (fused_like) {
         c.head_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(g.vocab_size, D) * (wf16 ? sizeof(_Float16) : sizeof(float))));
         if (wf16) launch_pack_skinny_weight_f16(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);
         else launch_pack_skinny_weight(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);

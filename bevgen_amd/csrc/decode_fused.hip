@@ -196,14 +196,126 @@ __device__ __forceinline__ void wave_merge(float& m, float& l, float (&acc)[DPL]
     m = m_all;
 }
 
+#define AF_TRACE(i) do { if (a.trace && tid == 0) a.trace[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+
+// Second half of both attention kernels: this step's k / v rows (qkv_s, LDS) go into the cache, the walk over the visible 16-key chunks, the merge of the
+// 16 waves, + residual (res_s[g * ldres + d], LDS) -> out.  Called by every thread of the workgroup after a barrier that made qkv_s / bias_s / the list visible.
+template <int DT, int G>
+__device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a, const float* bias_s, const float* qkv_s, float* red, const uint16_t* walk, int n_pos, int p_pos,
+                                                       int n, int head, int b0, const float* res_s, int ldres) {
+    using T = KvRow<DT>;
+    constexpr int LPK = T::LPK, DPL = T::DPL, NW = AF_WAVES, TW = NW / G;
+    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // key loads per lane group and pipeline step (fp16 rows: 3 or 4 measured no faster)
+    constexpr int UP = G >= 4 ? 1 : U;   // same for the shared-prefix phase (G queries' state lives in registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane % LPK, kslot = lane / LPK;
+    const int row = n - 1;
+    const float sl2 = a.scale * kLog2eF;
+    // ---- append this step's k / v rows to the cache (row n-1 of every sequence of the group); read back through the normal path below
+    if (tid < 128 * G) {
+        const int g = tid >> 7, is_v = (tid >> 6) & 1, d = tid & 63;
+        const float val = qkv_s[g * 192 + 64 + is_v * 64 + d];
+        void* cache = is_v ? a.vcache : a.kcache;
+        const long idx = ((((long)(b0 + g)) * a.H + head) * a.Lmax + row) * 64 + d;
+        if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
+        else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)val;
+    }
+    __syncthreads();
+
+    AF_TRACE(3);
+    // ---- attention
+    float* my_red = red + wave * (G + 1) * 66;
+    if (G == 1) {
+        float q[1][DPL], m[1] = {kNegBig}, l[1] = {0.f}, acc[1][DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[sub * DPL + i] * sl2; acc[0][i] = 0.f; }
+        const long row0 = ((long)b0 * a.H + head) * a.Lmax;
+        Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, 0, n_pos, wave, NW, kslot, n, sub, bias_s, q, m, l, acc);
+        wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
+        if (kslot == 0) {
+            if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) my_red[2 + sub * DPL + i] = acc[0][i];
+        }
+    } else {
+        // shared prefix [0, prefix): rows of the group's first sequence, every key row scored against the G queries
+        {
+            float q[G][DPL], m[G], l[G], acc[G][DPL];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                m[g] = kNegBig; l[g] = 0.f;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) { q[g][i] = qkv_s[g * 192 + sub * DPL + i] * sl2; acc[g][i] = 0.f; }
+            }
+            const long row0 = ((long)b0 * a.H + head) * a.Lmax;
+            Attend<DT, G, UP>::run(a.kcache, a.vcache, row0, walk, 0, p_pos, wave, NW, kslot, min(a.prefix, n), sub, bias_s, q, m, l, acc);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                wave_merge<LPK, DPL>(m[g], l[g], acc[g]);
+                if (kslot == 0) {
+                    if (sub == 0) { my_red[g * 66] = m[g]; my_red[g * 66 + 1] = l[g]; }
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) my_red[g * 66 + 2 + sub * DPL + i] = acc[g][i];
+                }
+            }
+        }
+        // private suffix [prefix, n): team of TW waves per sequence
+        {
+            const int g_own = wave / TW, wt = wave % TW;
+            float q[1][DPL], m[1] = {kNegBig}, l[1] = {0.f}, acc[1][DPL];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[g_own * 192 + sub * DPL + i] * sl2; acc[0][i] = 0.f; }
+            const long row0 = ((long)(b0 + g_own) * a.H + head) * a.Lmax;
+            Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, p_pos, n_pos, wt, TW, kslot, n, sub, bias_s, q, m, l, acc);
+            wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
+            if (kslot == 0) {
+                if (sub == 0) { my_red[G * 66] = m[0]; my_red[G * 66 + 1] = l[0]; }
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) my_red[G * 66 + 2 + sub * DPL + i] = acc[0][i];
+            }
+        }
+    }
+    __syncthreads();
+    AF_TRACE(4);
+
+    // ---- merge the waves (fixed order), normalise, add the ln1(x) residual (Block.forward: the residual is the NORMALISED row)
+    if (tid < 64 * G) {
+        const int g = tid >> 6, d = tid & 63;
+        float mm = kNegBig;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, red[(w * (G + 1) + g) * 66]);
+        if (G > 1) {
+#pragma unroll
+            for (int w = 0; w < TW; ++w) mm = fmaxf(mm, red[((g * TW + w) * (G + 1) + G) * 66]);
+        }
+        float l = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float* e = red + (w * (G + 1) + g) * 66;
+            const float f = __builtin_amdgcn_exp2f(e[0] - mm);
+            l += e[1] * f;
+            o += e[2 + d] * f;
+        }
+        if (G > 1) {
+#pragma unroll
+            for (int w = 0; w < TW; ++w) {
+                const float* e = red + ((g * TW + w) * (G + 1) + G) * 66;
+                const float f = __builtin_amdgcn_exp2f(e[0] - mm);
+                l += e[1] * f;
+                o += e[2 + d] * f;
+            }
+        }
+        a.out[(long)(b0 + g) * a.ldo + head * 64 + d] = o / l + res_s[g * ldres + d];
+    }
+    AF_TRACE(5);
+}
+
 // ----------------------------------------------------------------------------------------------------------------- ln1 + qkv + attention
 // grid (H, B / G), 1024 threads.  Dynamic LDS: bias row [Lpad] | xn [G][D] | qkv [G][192] | red [16][G+1][66] | stat [16][G] | chunk list [Lpad/16 + 2] (uint16)
 template <int DT, int G, int WT>   // KV-cache storage (0 fp32, 1 fp16), sequences per workgroup, decode-weight storage (0 fp32, 1 fp16)
 __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) {
     using T = KvRow<DT>;
-    constexpr int LPK = T::LPK, DPL = T::DPL, NW = AF_WAVES, TW = NW / G;
-    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // key loads per lane group and pipeline step (fp16 rows: 3 or 4 measured no faster)
-    constexpr int UP = G >= 4 ? 1 : U;   // same for the shared-prefix phase (G queries' state lives in registers)
+    constexpr int NW = AF_WAVES;
     extern __shared__ float smem[];
     const int D = a.D;
     float* bias_s = smem;
@@ -214,14 +326,12 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     uint16_t* list_s = reinterpret_cast<uint16_t*>(stat + NW * G);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int sub = lane % LPK, kslot = lane / LPK;
     const int head = blockIdx.x, grp = blockIdx.y;
     const int b0 = grp * G;
     const int n = a.d_n ? *a.d_n + a.n : a.n;   // context length incl. the new key
     const int row = n - 1;
     const float sl2 = a.scale * kLog2eF;        // scores live in the base-2 domain
 
-#define AF_TRACE(i) do { if (a.trace && tid == 0) a.trace[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     AF_TRACE(0);
     // ---- every load that does not depend on another load is requested up front, in the order the results are needed (vmcnt waits are in order):
     //      x rows and ln1 gamma / beta -> first q/k/v weight rows -> bias and visibility row of this step
@@ -381,105 +491,75 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     __syncthreads();
     AF_TRACE(2);
 
-    // ---- append this step's k / v rows to the cache (row n-1 of every sequence of the group); read back through the normal path below
-    if (tid < 128 * G) {
-        const int g = tid >> 7, is_v = (tid >> 6) & 1, d = tid & 63;
-        const float val = qkv_s[g * 192 + 64 + is_v * 64 + d];
-        void* cache = is_v ? a.vcache : a.kcache;
-        const long idx = ((((long)(b0 + g)) * a.H + head) * a.Lmax + row) * 64 + d;
-        if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
-        else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)val;
-    }
-    __syncthreads();
-
-    AF_TRACE(3);
-    // ---- attention
-    float* my_red = red + wave * (G + 1) * 66;
-    if (G == 1) {
-        float q[1][DPL], m[1] = {kNegBig}, l[1] = {0.f}, acc[1][DPL];
-#pragma unroll
-        for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[sub * DPL + i] * sl2; acc[0][i] = 0.f; }
-        const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-        Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, 0, n_pos, wave, NW, kslot, n, sub, bias_s, q, m, l, acc);
-        wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
-        if (kslot == 0) {
-            if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
-#pragma unroll
-            for (int i = 0; i < DPL; ++i) my_red[2 + sub * DPL + i] = acc[0][i];
-        }
-    } else {
-        // shared prefix [0, prefix): rows of the group's first sequence, every key row scored against the G queries
-        {
-            float q[G][DPL], m[G], l[G], acc[G][DPL];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                m[g] = kNegBig; l[g] = 0.f;
-#pragma unroll
-                for (int i = 0; i < DPL; ++i) { q[g][i] = qkv_s[g * 192 + sub * DPL + i] * sl2; acc[g][i] = 0.f; }
-            }
-            const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-            Attend<DT, G, UP>::run(a.kcache, a.vcache, row0, walk, 0, p_pos, wave, NW, kslot, min(a.prefix, n), sub, bias_s, q, m, l, acc);
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                wave_merge<LPK, DPL>(m[g], l[g], acc[g]);
-                if (kslot == 0) {
-                    if (sub == 0) { my_red[g * 66] = m[g]; my_red[g * 66 + 1] = l[g]; }
-#pragma unroll
-                    for (int i = 0; i < DPL; ++i) my_red[g * 66 + 2 + sub * DPL + i] = acc[g][i];
-                }
-            }
-        }
-        // private suffix [prefix, n): team of TW waves per sequence
-        {
-            const int g_own = wave / TW, wt = wave % TW;
-            float q[1][DPL], m[1] = {kNegBig}, l[1] = {0.f}, acc[1][DPL];
-#pragma unroll
-            for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[g_own * 192 + sub * DPL + i] * sl2; acc[0][i] = 0.f; }
-            const long row0 = ((long)(b0 + g_own) * a.H + head) * a.Lmax;
-            Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, p_pos, n_pos, wt, TW, kslot, n, sub, bias_s, q, m, l, acc);
-            wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
-            if (kslot == 0) {
-                if (sub == 0) { my_red[G * 66] = m[0]; my_red[G * 66 + 1] = l[0]; }
-#pragma unroll
-                for (int i = 0; i < DPL; ++i) my_red[G * 66 + 2 + sub * DPL + i] = acc[0][i];
-            }
-        }
-    }
-    __syncthreads();
-    AF_TRACE(4);
-
-    // ---- merge the waves (fixed order), normalise, add the ln1(x) residual (Block.forward: the residual is the NORMALISED row)
-    if (tid < 64 * G) {
-        const int g = tid >> 6, d = tid & 63;
-        float mm = kNegBig;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, red[(w * (G + 1) + g) * 66]);
-        if (G > 1) {
-#pragma unroll
-            for (int w = 0; w < TW; ++w) mm = fmaxf(mm, red[((g * TW + w) * (G + 1) + G) * 66]);
-        }
-        float l = 0.f, o = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float* e = red + (w * (G + 1) + g) * 66;
-            const float f = __builtin_amdgcn_exp2f(e[0] - mm);
-            l += e[1] * f;
-            o += e[2 + d] * f;
-        }
-        if (G > 1) {
-#pragma unroll
-            for (int w = 0; w < TW; ++w) {
-                const float* e = red + ((g * TW + w) * (G + 1) + G) * 66;
-                const float f = __builtin_amdgcn_exp2f(e[0] - mm);
-                l += e[1] * f;
-                o += e[2 + d] * f;
-            }
-        }
-        a.out[(long)(b0 + g) * a.ldo + head * 64 + d] = o / l + xn_s[g * D + head * 64 + d];
-    }
-    AF_TRACE(5);
-#undef AF_TRACE
+    af_append_attend_store<DT, G>(a, bias_s, qkv_s, red, walk, n_pos, p_pos, n, head, b0, xn_s + head * 64, D);
 }
+
+// ----------------------------------------------------------------------------------------------------------------- decode attention proper
+// decode_path = split: the row's q | k | v were projected for the whole batch by the LayerNorm + QKV kernel (skinny_fused_kernel<LN, RS>: the weight matrix is read from
+// HBM once per layer instead of once per sequence through L2), so this kernel is the K/V stream and nothing else: bias / visibility row and chunk list -> LDS,
+// k / v appended, the walk over the visible 16-key chunks, merge, + ln1(x) residual.  grid (H, B / G), 1024 threads.
+// Dynamic LDS: bias row [Lpad] | residual [G][64] | qkv [G][192] | red [16][G+1][66] | chunk list [Lpad/16 + 2] (uint16)
+template <int DT, int G>
+__global__ __launch_bounds__(1024) void ar_attn_kernel(ArAttnFusedArgs a) {
+    constexpr int NW = AF_WAVES;
+    extern __shared__ float smem[];
+    const int D = a.D;
+    float* bias_s = smem;
+    float* res_s = bias_s + a.Lpad;
+    float* qkv_s = res_s + G * 64;
+    float* red = qkv_s + G * 192;
+    uint16_t* list_s = reinterpret_cast<uint16_t*>(red + NW * (G + 1) * 66);
+
+    const int tid = threadIdx.x;
+    const int head = blockIdx.x, grp = blockIdx.y;
+    const int b0 = grp * G;
+    const int n = a.d_n ? *a.d_n + a.n : a.n;   // context length incl. the new key
+    const int row = n - 1;
+    const float sl2 = a.scale * kLog2eF;
+    AF_TRACE(0);
+    // all loads up front, unconditional on clamped addresses (see rowsrc_at)
+    const int tq = min(tid, 192 * G - 1), gq = tq / 192, jq = tq % 192;
+    const float qraw = a.qkv[(long)(b0 + gq) * 3 * D + (long)(jq >> 6) * D + head * 64 + (jq & 63)];
+    const int tr = min(tid, 64 * G - 1);
+    const float rraw = a.xn[(long)(b0 + (tr >> 6)) * D + head * 64 + (tr & 63)];
+    constexpr int BR = 3;
+    const SparseVis& vis = a.vis;
+    const uint8_t* keep_row = vis.allowed + (long)head * vis.allowed_head_stride + (long)row * vis.ldallowed;
+    const uint8_t* lay_row = vis.lay + (long)head * vis.lay_head_stride + (long)(row / vis.blk) * vis.nb;
+    const float* bias_row = a.bias + (long)row * a.ldbias;
+    float braw[BR];
+    uint8_t kraw[BR], lraw[BR];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int k = min(tid + 1024 * j, n - 1);
+        braw[j] = bias_row[k];
+        kraw[j] = keep_row[k];
+        lraw[j] = lay_row[k / vis.blk];
+    }
+    const uint16_t* chunk_row = vis.chunks + (long)head * vis.chunks_head_stride + (long)(row / vis.blk) * vis.chunks_ld;
+    const int chunk_total = chunk_row[0];
+    const int chunk_id = chunk_row[min(1 + tid, max(vis.chunks_ld - 1, 0))];
+
+    if (tid < 192 * G) qkv_s[tid] = qraw;
+    if (tid < 64 * G) res_s[tid] = rraw;
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+        if (tid + 1024 * j < n)
+            bias_s[tid + 1024 * j] = ((kraw[j] || !vis.has_allowed) && (lraw[j] || !vis.has_lay)) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
+    for (int k = tid + 1024 * BR; k < n; k += 1024)
+        bias_s[k] = ((keep_row[k] || !vis.has_allowed) && (lay_row[k / vis.blk] || !vis.has_lay)) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
+    if (vis.has_chunks && tid < chunk_total) list_s[tid] = (uint16_t)chunk_id;
+    __syncthreads();
+    const uint16_t* walk = vis.has_chunks ? list_s : nullptr;
+    const int n_pos = vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < n) : (n + 15) >> 4;
+    const int p_pos = G == 1 ? 0 : (vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n)) : min((min(a.prefix, n) + 15) >> 4, n_pos));
+    AF_TRACE(2);
+    af_append_attend_store<DT, G>(a, bias_s, qkv_s, red, walk, n_pos, p_pos, n, head, b0, res_s, 64);
+}
+
+#undef AF_TRACE
+
+size_t ar_attn_lds_bytes(int G, int Lpad) { return ((size_t)Lpad + (size_t)G * 64 + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66) * sizeof(float) + ((size_t)Lpad / 16 + 2) * sizeof(uint16_t); }
 
 size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) {
     return ((size_t)Lpad + (size_t)G * D + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66 + (size_t)AF_WAVES * G) * sizeof(float) + ((size_t)Lpad / 16 + 2) * sizeof(uint16_t);
@@ -492,23 +572,32 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     BG_REQUIRE(ar_attn_fused_supported(a.B, a.G, a.D, a.H), "fused decode attention: unsupported shape B=%d G=%d D=%d H=%d", a.B, a.G, a.D, a.H);
     BG_REQUIRE(a.x.ns <= ROWSRC_MAX_SPLITS, "fused decode attention: at most %d partial sums per row", ROWSRC_MAX_SPLITS);
     a.Lpad = (int)round_up(a.Lmax, 4);
+    const bool pre = a.qkv != nullptr;
+    BG_REQUIRE(!pre || a.xn, "decode attention: precomputed q/k/v rows need the ln1(x) rows for the residual");
+    if (pre) { a.x = RowSrc{}; a.x.base = a.qkv; a.x.ld = 3 * a.D; }
     a.x = rowsrc_fix(a.x);
     a.has_bias = a.bias != nullptr;
     a.vis = vis_fix(a.vis, a.x.base);
     if (!a.bias) { a.bias = a.x.base; a.ldbias = 0; }
     BG_REQUIRE(a.G == 1 || a.prefix % 16 == 0, "fused decode attention: a shared prefix must be a multiple of 16 keys (prefix=%d)", a.prefix);
     BG_REQUIRE(!a.vis.has_chunks || a.vis.chunks_ld <= 1025, "fused decode attention: at most 1024 key chunks per row");
-    const size_t lds = ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
+    const size_t lds = pre ? ar_attn_lds_bytes(a.G, a.Lpad) : ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
     dim3 grid(a.H, a.B / a.G);
     // algorithmic bytes of one launch: K and V rows of the context, once each; the shared prefix once per group
     const double n_host = a.d_n ? a.n + a.n_hint : a.n;
     const double eb = a.kv_dtype == 0 ? 4 : 2;
-    const double pre = a.G > 1 ? (double)a.prefix : 0.0;
-    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pre) + (double)(a.B / a.G) * pre), s);
+    const double pfx = a.G > 1 ? (double)a.prefix : 0.0;
+    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pfx) + (double)(a.B / a.G) * pfx), s);
 #define AF_LAUNCH(DT, GG, WW) hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG, WW>), grid, dim3(1024), lds, s, a)
 #define AF_LAUNCH_G(DT, WW) do { if (a.G == 1) AF_LAUNCH(DT, 1, WW); else if (a.G == 2) AF_LAUNCH(DT, 2, WW); else AF_LAUNCH(DT, 4, WW); } while (0)
-    if (a.wqkv_h) {
+    if (pre) {
+#define AP_LAUNCH(DT, GG) hipLaunchKernelGGL((ar_attn_kernel<DT, GG>), grid, dim3(1024), lds, s, a)
+#define AP_LAUNCH_G(DT) do { if (a.G == 1) AP_LAUNCH(DT, 1); else if (a.G == 2) AP_LAUNCH(DT, 2); else AP_LAUNCH(DT, 4); } while (0)
+        if (a.kv_dtype == 0) AP_LAUNCH_G(0); else AP_LAUNCH_G(1);
+#undef AP_LAUNCH_G
+#undef AP_LAUNCH
+    } else if (a.wqkv_h) {
         BG_REQUIRE(a.D % 8 == 0, "fused decode attention: fp16 weights need D %% 8 == 0");
         if (a.kv_dtype == 0) AF_LAUNCH_G(0, 1); else AF_LAUNCH_G(1, 1);
     } else {
@@ -533,7 +622,7 @@ __device__ __forceinline__ float4 ldg_nt4(const float* p) {
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <bool LN, int WT>   // WT: weight storage of the packed image, 0 fp32 ([K/16][64 lanes][4]), 1 fp16 ([K/32][64 lanes][8])
+template <bool LN, int WT, bool RS = false>   // WT: weight storage of the packed image, 0 fp32 ([K/16][64 lanes][4]), 1 fp16 ([K/32][64 lanes][8]); RS: A is a row source
 __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFusedArgs g) {
     __shared__ float4 As[256 * 16];
     __shared__ float red[SF_WAVES][4][64];
@@ -553,7 +642,25 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = min(q + 4 * wave + 32 * j, nch - 1);   // clamped, never predicated (see rowsrc_at); surplus chunks / rows are ignored below
-            v[j] = *reinterpret_cast<const float4*>(g.A + (long)min(m, g.M - 1) * g.lda + kbase + 4 * c);
+            const int mr = min(m, g.M - 1), col = kbase + 4 * c;
+            if (RS) {   // previous layer's split-K partials (index order), + bias, + residual: the order rowsrc_at uses
+                const RowSrc& r = g.src;
+                float4 p[ROWSRC_MAX_SPLITS];
+#pragma unroll
+                for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) p[k] = *reinterpret_cast<const float4*>(r.partial + (long)(k < r.ns ? k : 0) * r.pstride + (long)mr * r.pld + col);
+                const float4 b = *reinterpret_cast<const float4*>(r.bias + (r.has_bias ? col : 0));
+                const float4 x = *reinterpret_cast<const float4*>(r.base + (long)mr * r.ld + col);
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) {
+                    // absent partials alias valid memory (rowsrc_fix): they are loaded but do not count
+                    sum.x += k < r.ns ? p[k].x : 0.f; sum.y += k < r.ns ? p[k].y : 0.f; sum.z += k < r.ns ? p[k].z : 0.f; sum.w += k < r.ns ? p[k].w : 0.f;
+                }
+                v[j] = make_float4((sum.x + (r.has_bias ? b.x : 0.f)) + x.x, (sum.y + (r.has_bias ? b.y : 0.f)) + x.y, (sum.z + (r.has_bias ? b.z : 0.f)) + x.z,
+                                   (sum.w + (r.has_bias ? b.w : 0.f)) + x.w);
+            } else {
+                v[j] = *reinterpret_cast<const float4*>(g.A + (long)mr * g.lda + col);
+            }
         }
     };
     float4 v[8];
@@ -617,6 +724,14 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                 const float fb = g.has_ln_b ? 1.f : 0.f;
                 v[j] = make_float4(fmaf(bt[j].x, fb, (v[j].x - mean) * rstd * gm[j].x), fmaf(bt[j].y, fb, (v[j].y - mean) * rstd * gm[j].y),
                                    fmaf(bt[j].z, fb, (v[j].z - mean) * rstd * gm[j].z), fmaf(bt[j].w, fb, (v[j].w - mean) * rstd * gm[j].w));
+            }
+            // every workgroup holds the same normalised rows: workgroup i writes the chunks c with c % gridDim.x == i (each element once)
+            if (g.xn_out) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = q + 4 * wave + 32 * j, m = mc * 16 + r;
+                    if (c < nch && m < g.M && c % (int)gridDim.x == (int)blockIdx.x) *reinterpret_cast<float4*>(g.xn_out + (long)m * g.ldxn + 4 * c) = v[j];
+                }
             }
         }
 #pragma unroll
@@ -759,14 +874,21 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     BG_REQUIRE(!ln || g.ksplit == 1, "skinny_fused: LayerNorm needs the whole row in one workgroup");
     BG_REQUIRE(g.ksplit <= ROWSRC_MAX_SPLITS, "skinny_fused: at most %d K splits", ROWSRC_MAX_SPLITS);
     BG_REQUIRE(g.lda % 4 == 0 && g.Wp, "skinny_fused: A stride must be a multiple of 4, weights packed");
+    BG_REQUIRE(!g.a_src || (ln && g.a_src->ns <= ROWSRC_MAX_SPLITS), "skinny_fused: a row source needs the LayerNorm form and at most %d partial sums", ROWSRC_MAX_SPLITS);
+    BG_REQUIRE(!g.xn_out || ln, "skinny_fused: xn_out is the LayerNorm output");
+    if (g.a_src) { g.src = rowsrc_fix(*g.a_src); g.a_src = nullptr; }
+    const bool rs = g.src.base != nullptr;
+    BG_REQUIRE(rs || g.A, "skinny_fused: no A operand");
     dim3 grid(cdiv(g.N, 16), g.ksplit);
     ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);   // work = algorithmic bytes
     if (g.w_f16) {
         BG_REQUIRE((g.K / g.ksplit) % (SF_WAVES * 32) == 0, "skinny_fused: fp16 weights need a K slice that is a multiple of %d (K=%d, ksplit=%d)", SF_WAVES * 32, g.K, g.ksplit);
-        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (rs) hipLaunchKernelGGL((skinny_fused_kernel<true, 1, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
         else hipLaunchKernelGGL((skinny_fused_kernel<false, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
     } else {
-        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (rs) hipLaunchKernelGGL((skinny_fused_kernel<true, 0, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
         else hipLaunchKernelGGL((skinny_fused_kernel<false, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
     }
     LAUNCH_CHECK();

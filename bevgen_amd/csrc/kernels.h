@@ -196,6 +196,8 @@ void launch_rowsrc_materialize(const RowSrc& r, float* out, int M, int D, int* c
 struct ArAttnFusedArgs {
     RowSrc x;                          // rows entering the layer (before ln1), [B, D]
     const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;
+    const float* qkv = nullptr;        // non-null: q | k | v rows [B, 3D] already projected by the LN + QKV kernel (decode_path = split); `xn` then holds ln1(x) [B, D]
+    const float* xn = nullptr;         //   and x / ln_w / wqkv are not read
     const float* wqkv = nullptr;       // fused [3D, D] (q | k | v), bqkv [3D]
     const void* wqkv_h = nullptr;      // non-null: the same matrix stored as fp16 (decode_weights = f16), read instead of wqkv
     const float* bqkv = nullptr;
@@ -217,6 +219,8 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a, hipStream_t s);
 
 struct SkinnyFusedArgs {
     const float* A = nullptr; int lda = 0;   // [M, K]
+    const RowSrc* a_src = nullptr;           // non-null: A is this row source (previous layer's split-K partials + bias + residual, added while the tile is fetched)
+    float* xn_out = nullptr; int ldxn = 0;   // non-null (with LayerNorm): the normalised rows are also written out [M, K] (the residual Block.forward takes from ln1(x))
     const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;   // ln_w != null: LayerNorm over K fused in front of the product
     const float* Wp = nullptr;               // [N, K] weights in the packed operand layout (launch_pack_skinny_weight / _f16)
     int w_f16 = 0;                           // the packed image holds fp16 values
@@ -225,6 +229,7 @@ struct SkinnyFusedArgs {
     int M = 0, N = 0, K = 0, ksplit = 0 /* 0 = skinny_fused_ksplit(N, K) */, act = 0;
     long long* trace = nullptr;        // diagnostics, as above
     int has_ln_b = 0;                  // filled in by the launcher
+    RowSrc src;                        // filled in by the launcher from a_src
 };
 size_t skinny_packed_floats(int N, int K);
 void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStream_t s);
@@ -233,6 +238,7 @@ int skinny_fused_ksplit(int N, int K);
 bool skinny_fused_supported(int M, int N, int K, bool ln);
 bool skinny_fused_f16_ok(int N, int K, bool ln);   // fp16 weight image: K slice per wave a multiple of 32
 size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad);
+size_t ar_attn_lds_bytes(int G, int Lpad);   // the attention-only kernel (decode_path = split)
 void launch_skinny_fused(const SkinnyFusedArgs& g, hipStream_t s);
 
 // ---------------------------------------------------------------- embed.hip

@@ -73,8 +73,9 @@ class Context:
         # Route A KV-cache storage: 'f32' (bit-exact tokens) or 'f16' (fp16 storage / fp32 accumulate, BASELINE config 4: half the decode traffic)
         c.kv_cache_dtype = {"f32": _lib.KV_F32, "f16": _lib.KV_F16}[kv_cache]
         self.kv_cache = kv_cache
-        # Route A decode step: 'fused' (three launches per layer) or 'per_op' (one kernel per operator, the A/B reference)
-        c.decode_path = {"fused": _lib.DECODE_FUSED, "per_op": _lib.DECODE_PER_OP}[decode_path]
+        # Route A decode step: 'fused' (three launches per layer), 'split' (LayerNorm + QKV projection kernel, then the attention-only kernel: four launches)
+        # or 'per_op' (one kernel per operator, the A/B reference)
+        c.decode_path = {"fused": _lib.DECODE_FUSED, "per_op": _lib.DECODE_PER_OP, "split": _lib.DECODE_SPLIT}[decode_path]
         self.decode_path = decode_path
         # Route A projection weights: 'f32', or 'f16' = the model with fp16-representable q/k/v, MLP and head weights (rounded at finalize), whose decode
         # step streams 2-byte weights
@@ -404,7 +405,7 @@ class Context:
         return out
 
     def op_ar_attn_fused(self, x, ln_w, ln_b, wqkv, bqkv, kcache, vcache, n, *, partial=None, rbias=None, bias=None, attn_mask=None, layout=None, block=1, G=1, prefix=0,
-                         kv_dtype=0, w_f16=False):
+                         kv_dtype=0, w_f16=False, split=False):
         """Attention half of a fused Route A decode layer (appends k/v to cache row n-1 in place) -> x2 [B, D]."""
         B, D = x.shape
         H = D // 64
@@ -413,7 +414,7 @@ class Context:
         ns = 0 if partial is None else partial.shape[0]
         self._check(self.lib.bevgen_op_ar_attn_fused(self._h, _ptr(x), _ptr(partial), ns, _ptr(rbias), _ptr(ln_w), _ptr(ln_b), _ptr(wqkv), _ptr(bqkv), int(w_f16),
                                                      _ptr(kcache), _ptr(vcache), int(kv_dtype), _ptr(bias), 0 if bias is None else bias.shape[-1], _ptr(attn_mask),
-                                                     _ptr(layout), int(block), B, int(G), H, int(n), Lmax, int(prefix), _ptr(out), self._s()))
+                                                     _ptr(layout), int(block), B, int(G), H, int(n), Lmax, int(prefix), int(split), _ptr(out), self._s()))
         return out
 
     def op_conv3x3(self, x_nhwc, w_ohwi, bias, residual=None, upsample=False):

@@ -35,7 +35,7 @@ enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
  *         fp32 accumulation, up to 5x the fp32 MFMA rate.  Everything else (attention, norms, samplers, decode-step GEMMs) stays fp32. */
 enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 /* reserved */, BEVGEN_PRECISION_F16X3 = 2 };
 enum { BEVGEN_KV_F32 = 0, BEVGEN_KV_F16 = 1 };
-enum { BEVGEN_DECODE_FUSED = 0, BEVGEN_DECODE_PER_OP = 1 };
+enum { BEVGEN_DECODE_FUSED = 0, BEVGEN_DECODE_PER_OP = 1, BEVGEN_DECODE_SPLIT = 2 };
 enum { BEVGEN_W_F32 = 0, BEVGEN_W_F16 = 1 };
 enum { BEVGEN_DTYPE_F32 = 0, BEVGEN_DTYPE_I64 = 1, BEVGEN_DTYPE_U8 = 2, BEVGEN_DTYPE_F64 = 3 };
 
@@ -70,7 +70,9 @@ typedef struct bevgen_cfg {
     int32_t kv_cache_dtype;                            /* Route A KV-cache storage: BEVGEN_KV_F32 (default, bit-exact tokens) or BEVGEN_KV_F16 (fp16 storage,
                                                           fp32 accumulate: half the decode-attention HBM traffic; tokens no longer guaranteed identical) */
     int32_t decode_path;                               /* Route A decode step: BEVGEN_DECODE_FUSED (default: three launches per layer, decode_fused.hip) or
-                                                          BEVGEN_DECODE_PER_OP (one kernel per operator: the round-1 path, kept as the A/B reference) */
+                                                          BEVGEN_DECODE_PER_OP (one kernel per operator: the round-1 path, kept as the A/B reference) or
+                                                          BEVGEN_DECODE_SPLIT (four launches per layer: LayerNorm + QKV projection of the whole batch as one MFMA kernel that
+                                                          reads the weight once, then the decode-attention kernel proper = the K/V stream and nothing else) */
     int32_t decode_weight_dtype;                       /* Route A projection weights (q/k/v, MLP, head): BEVGEN_W_F32 (default) or BEVGEN_W_F16: bevgen_finalize rounds them to
                                                           fp16-representable values (prefill and decode then use the same model: the reference's Route A runs fp16,
                                                           sparse_self_attention.py:127) and the decode step streams the 2-byte copies: half the weight traffic */
@@ -228,10 +230,11 @@ int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* d_q, const void* d_
  *   k, v written to cache row n-1 -> softmax(dh^-0.5 (q k^T + d_bias[n-1, :]) + mask) v over keys 0..n-1 -> d_out[b] = xn + attention.
  * Visibility as the reference defines it: d_attn_mask [L, L] fp32 (0 = hidden) AND d_layout int64 [H, L/block, L/block] (0 = block absent, never read);
  * either may be NULL.  G > 1: consecutive groups of G sequences share their first `prefix` keys, read from the group's first cache slot.
- * kv_dtype 0 fp32 / 1 fp16 cache [B, H, Lmax, 64]; w_f16 != 0: the projection weights are rounded to fp16 and streamed as 2-byte values. */
+ * kv_dtype 0 fp32 / 1 fp16 cache [B, H, Lmax, 64]; w_f16 != 0: the projection weights are rounded to fp16 and streamed as 2-byte values.
+ * split != 0: the BEVGEN_DECODE_SPLIT form of the same computation (LayerNorm + QKV projection kernel, then the attention-only kernel). */
 int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* d_x, const float* d_partial, int ns, const float* d_rbias, const float* d_ln_w, const float* d_ln_b,
                             const float* d_wqkv, const float* d_bqkv, int w_f16, void* d_kcache, void* d_vcache, int kv_dtype, const float* d_bias, int ldbias,
-                            const float* d_attn_mask, const int64_t* d_layout, int block, int B, int G, int H, int n, int Lmax, int prefix, float* d_out, void* stream);
+                            const float* d_attn_mask, const int64_t* d_layout, int block, int B, int G, int H, int n, int Lmax, int prefix, int split, float* d_out, void* stream);
 int bevgen_op_conv3x3(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_w_ohwi, const float* d_bias, const float* d_residual,
                       float* d_y_nhwc, int n, int H, int W, int Cin, int Cout, int upsample2x, void* stream);
 int bevgen_op_groupnorm(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_gamma, const float* d_beta, float* d_y, int n, int hw, int C,

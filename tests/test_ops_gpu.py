@@ -290,6 +290,7 @@ def _ar_attn_reference(x, partial, rbias, ln_w, ln_b, wqkv, bqkv, kc, vc, n, bia
     return xn + out.reshape(B, D), k, v
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("kv", ["f32", "f16"])
 @pytest.mark.parametrize("B,G,H,n,Lmax,blk,sparse", [
     (1, 1, 2, 1, 64, 16, False),        # first key only
@@ -301,9 +302,10 @@ def _ar_attn_reference(x, partial, rbias, ln_w, ln_b, wqkv, bqkv, kc, vc, n, bia
     (8, 4, 8, 333, 512, 32, True),      # four per layout, 32-key blocks (two chunks per block)
     (8, 4, 8, 64, 512, 16, False),      # nothing beyond the shared prefix yet except the new key at n - 1 = 63 ... prefix 48
 ])
-def test_ar_attn_fused_operator(gpu_ctx, B, G, H, n, Lmax, blk, sparse, kv):
+def test_ar_attn_fused_operator(gpu_ctx, B, G, H, n, Lmax, blk, sparse, kv, split):
     """ar_attn_fused_kernel (ln1 + q/k/v + cache append + block-sparse decode attention + residual) against fp64, over batch sizes, context lengths incl. n = 1 and
-    n = L, layout groups G in {1, 2, 4}, both cache dtypes, with element mask + random per-head block layout (absent blocks are skipped, not masked)."""
+    n = L, layout groups G in {1, 2, 4}, both cache dtypes, with element mask + random per-head block layout (absent blocks are skipped, not masked).
+    split: the four-launch form (LayerNorm + QKV projection kernel with the row source folded into its A fetch, then ar_attn_kernel)."""
     D = H * 64
     g = torch.Generator().manual_seed(B * 1000 + n)
     x = torch.randn(B, D, generator=g)
@@ -329,7 +331,7 @@ def test_ar_attn_fused_operator(gpu_ctx, B, G, H, n, Lmax, blk, sparse, kv):
     dkc, dvc = dev(kc.to(cdt)), dev(vc.to(cdt))
     out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dkc, dvc, n, partial=dev(partial), rbias=dev(rbias), bias=dev(bias),
                                    attn_mask=None if mask is None else dev(mask), layout=None if layout is None else dev(layout), block=blk, G=G, prefix=prefix,
-                                   kv_dtype=1 if kv == "f16" else 0)
+                                   kv_dtype=1 if kv == "f16" else 0, split=split)
     tol = 2e-3 if kv == "f16" else 2e-5   # f16: the new k/v row is stored rounded (11 bits) before it is read back
     assert rel(out.cpu().double(), ref) < tol
     # the appended rows
@@ -341,7 +343,8 @@ def test_ar_attn_fused_operator(gpu_ctx, B, G, H, n, Lmax, blk, sparse, kv):
     assert torch.equal(dkc[:, :, keep].float().cpu(), kc[:, :, keep]) and torch.equal(dvc[:, :, keep].float().cpu(), vc[:, :, keep])
 
 
-def test_ar_attn_fused_operator_f16_weights(gpu_ctx):
+@pytest.mark.parametrize("split", [False, True])
+def test_ar_attn_fused_operator_f16_weights(gpu_ctx, split):
     B, H, n, Lmax = 16, 16, 700, 1024
     D = H * 64
     g = torch.Generator().manual_seed(5)
@@ -351,7 +354,7 @@ def test_ar_attn_fused_operator_f16_weights(gpu_ctx):
     bqkv = torch.randn(3 * D, generator=g) * 0.1
     kc, vc = torch.randn(B, H, Lmax, 64, generator=g), torch.randn(B, H, Lmax, 64, generator=g)
     ref, _, _ = _ar_attn_reference(x, None, None, ln_w, ln_b, wqkv.half().float(), bqkv, kc, vc, n, None, None, None, 16, 1, 0)
-    out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dev(kc), dev(vc), n, w_f16=True)
+    out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dev(kc), dev(vc), n, w_f16=True, split=split)
     assert rel(out.cpu().double(), ref) < 2e-5
 
 

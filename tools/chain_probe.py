@@ -13,13 +13,14 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 chains = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4").split(",")]
 modes = [m.split(":") for m in (sys.argv[4] if len(sys.argv) > 4 else "f32:f32,f16:f32,f16:f16").split(",")]
 S = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+paths = (sys.argv[6] if len(sys.argv) > 6 else "fused").split(",")
 cfg = presets.config4()
 sd = gpt_state_dict(cfg, 1234)
 bt = {k: v.repeat_interleave(S, dim=0).cuda() for k, v in synthetic.make_batch(cfg, B // S, seed=0).items()}
 for kv, wt in modes:
     ref = None
-    for nch in chains:
-        ctx = Context(cfg, route="ar", max_batch=B, kv_cache=kv, decode_weights=wt, decode_chains=nch)
+    for nch, path in [(n_, p_) for p_ in paths for n_ in chains]:
+        ctx = Context(cfg, route="ar", max_batch=B, kv_cache=kv, decode_weights=wt, decode_chains=nch, decode_path=path)
         ctx.load_state_dict(sd)
         ctx.set_tables()
         ctx.finalize()
@@ -36,6 +37,6 @@ for kv, wt in modes:
         if ref is None:
             ref = x
         import numpy as np
-        print(f"B={B} S={S} steps={steps} kv={kv} w={wt} chains={nch}: {dt * 1e3 / steps:.3f} ms/step incl. prefill; per replay median {np.median(st):.3f} p99 {np.percentile(st, 99):.3f} "
+        print(f"B={B} S={S} steps={steps} kv={kv} w={wt} path={path} chains={nch}: {dt * 1e3 / steps:.3f} ms/step incl. prefill; per replay median {np.median(st):.3f} p99 {np.percentile(st, 99):.3f} "
               f"first100 {st[:100].mean():.3f} last100 {st[-100:].mean():.3f}{same}", flush=True)
         ctx.close()
