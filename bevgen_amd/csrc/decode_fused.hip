@@ -639,27 +639,46 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
     // the statistics are computed while the 64 KB of weights are still in flight (vmcnt waits are in order per wave).
     auto load_a = [&](int mc, float4 (&v)[8]) {
         const int m = mc * 16 + r;
+        const int mr = min(m, g.M - 1);
+        if (RS) {
+            // previous layer's split-K partials (index order), + bias, + residual: the order rowsrc_at uses.  Six loads per element: fetched in four passes of
+            // two chunks (12 x 16 B in flight per thread) - all eight at once need 192 registers and spill next to the weight slice already in flight
+            const RowSrc& rs = g.src;
+            constexpr int PJ = 2;
+            // wave-uniform bases + ONE 32-bit element offset per chunk (48 full 64-bit lane addresses kept live across the row-chunk loop were the spill)
+            const float* pb[ROWSRC_MAX_SPLITS];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = min(q + 4 * wave + 32 * j, nch - 1);   // clamped, never predicated (see rowsrc_at); surplus chunks / rows are ignored below
-            const int mr = min(m, g.M - 1), col = kbase + 4 * c;
-            if (RS) {   // previous layer's split-K partials (index order), + bias, + residual: the order rowsrc_at uses
-                const RowSrc& r = g.src;
-                float4 p[ROWSRC_MAX_SPLITS];
+            for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) pb[k] = rs.partial + (long)(k < rs.ns ? k : 0) * rs.pstride;
 #pragma unroll
-                for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) p[k] = *reinterpret_cast<const float4*>(r.partial + (long)(k < r.ns ? k : 0) * r.pstride + (long)mr * r.pld + col);
-                const float4 b = *reinterpret_cast<const float4*>(r.bias + (r.has_bias ? col : 0));
-                const float4 x = *reinterpret_cast<const float4*>(r.base + (long)mr * r.ld + col);
-                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int half = 0; half < 8 / PJ; ++half) {
+                float4 p[PJ][ROWSRC_MAX_SPLITS], b[PJ], x[PJ];
 #pragma unroll
-                for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) {
-                    // absent partials alias valid memory (rowsrc_fix): they are loaded but do not count
-                    sum.x += k < r.ns ? p[k].x : 0.f; sum.y += k < r.ns ? p[k].y : 0.f; sum.z += k < r.ns ? p[k].z : 0.f; sum.w += k < r.ns ? p[k].w : 0.f;
+                for (int jj = 0; jj < PJ; ++jj) {
+                    const int c = min(q + 4 * wave + 32 * (half * PJ + jj), nch - 1);   // clamped, never predicated (see rowsrc_at)
+                    const unsigned col = (unsigned)(kbase + 4 * c);
+                    const unsigned po = (unsigned)mr * (unsigned)rs.pld + col, xo = (unsigned)mr * (unsigned)rs.ld + col;
+#pragma unroll
+                    for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) p[jj][k] = *reinterpret_cast<const float4*>(pb[k] + po);
+                    b[jj] = *reinterpret_cast<const float4*>(rs.bias + (rs.has_bias ? col : 0u));
+                    x[jj] = *reinterpret_cast<const float4*>(rs.base + xo);
                 }
-                v[j] = make_float4((sum.x + (r.has_bias ? b.x : 0.f)) + x.x, (sum.y + (r.has_bias ? b.y : 0.f)) + x.y, (sum.z + (r.has_bias ? b.z : 0.f)) + x.z,
-                                   (sum.w + (r.has_bias ? b.w : 0.f)) + x.w);
-            } else {
-                v[j] = *reinterpret_cast<const float4*>(g.A + (long)mr * g.lda + col);
+#pragma unroll
+                for (int jj = 0; jj < PJ; ++jj) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) {   // absent partials alias valid memory (rowsrc_fix): loaded, not counted
+                        sum.x += k < rs.ns ? p[jj][k].x : 0.f; sum.y += k < rs.ns ? p[jj][k].y : 0.f; sum.z += k < rs.ns ? p[jj][k].z : 0.f; sum.w += k < rs.ns ? p[jj][k].w : 0.f;
+                    }
+                    v[half * PJ + jj] = make_float4((sum.x + (rs.has_bias ? b[jj].x : 0.f)) + x[jj].x, (sum.y + (rs.has_bias ? b[jj].y : 0.f)) + x[jj].y,
+                                                   (sum.z + (rs.has_bias ? b[jj].z : 0.f)) + x[jj].z, (sum.w + (rs.has_bias ? b[jj].w : 0.f)) + x[jj].w);
+                }
+                asm volatile("" ::: "memory");   // keep the next pass's loads behind this pass's sums (the scheduler would otherwise issue all 48 at once)
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = min(q + 4 * wave + 32 * j, nch - 1);   // clamped, never predicated (see rowsrc_at); surplus chunks / rows are ignored below
+                v[j] = *reinterpret_cast<const float4*>(g.A + (long)mr * g.lda + kbase + 4 * c);
             }
         }
     };
@@ -688,7 +707,9 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
         for (int u = 0; u < 8; ++u) wv[u] = ldg_nt4(wp + (long)min(u, (kper >> 4) - 1) * 256);   // u >= kper / 16: a repeat, not used
     }
 
-    for (int mc = 0; mc * 16 < g.M; ++mc) {
+    // (row-source form: one row chunk per launch - the launcher loops - so that no fold address has to live across a loop)
+    const int n_mc = RS ? 1 : (g.M + 15) / 16;
+    for (int mc = 0; mc < n_mc; ++mc) {
         if (mc > 0) load_a(mc, v);
         if (LN) {
             float s = 0.f;
@@ -792,7 +813,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                 }
             }
         }
-        if ((mc + 1) * 16 < g.M) __syncthreads();   // As / red are rewritten by the next row chunk
+        if (mc + 1 < n_mc) __syncthreads();   // As / red are rewritten by the next row chunk
     }
     SF_TRACE(3);
 #undef SF_TRACE
@@ -881,14 +902,24 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     BG_REQUIRE(rs || g.A, "skinny_fused: no A operand");
     dim3 grid(cdiv(g.N, 16), g.ksplit);
     ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);   // work = algorithmic bytes
-    if (g.w_f16) {
-        BG_REQUIRE((g.K / g.ksplit) % (SF_WAVES * 32) == 0, "skinny_fused: fp16 weights need a K slice that is a multiple of %d (K=%d, ksplit=%d)", SF_WAVES * 32, g.K, g.ksplit);
-        if (rs) hipLaunchKernelGGL((skinny_fused_kernel<true, 1, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
-        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
+    if (g.w_f16) BG_REQUIRE((g.K / g.ksplit) % (SF_WAVES * 32) == 0, "skinny_fused: fp16 weights need a K slice that is a multiple of %d (K=%d, ksplit=%d)", SF_WAVES * 32, g.K, g.ksplit);
+    if (rs) {   // 16 rows per launch
+        const int M = g.M;
+        for (int m0 = 0; m0 < M; m0 += 16) {
+            SkinnyFusedArgs h = g;
+            h.M = std::min(16, M - m0);
+            h.src.base += (long)m0 * g.src.ld;
+            h.src.partial += (long)m0 * g.src.pld;   // (aliases base when there are no partials: any valid address will do)
+            h.C = g.C + (long)m0 * g.ldc;
+            if (g.xn_out) h.xn_out = g.xn_out + (long)m0 * g.ldxn;
+            if (g.w_f16) hipLaunchKernelGGL((skinny_fused_kernel<true, 1, true>), grid, dim3(SF_WAVES * 64), 0, s, h);
+            else hipLaunchKernelGGL((skinny_fused_kernel<true, 0, true>), grid, dim3(SF_WAVES * 64), 0, s, h);
+        }
+    } else if (g.w_f16) {
+        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
         else hipLaunchKernelGGL((skinny_fused_kernel<false, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
     } else {
-        if (rs) hipLaunchKernelGGL((skinny_fused_kernel<true, 0, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
-        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
         else hipLaunchKernelGGL((skinny_fused_kernel<false, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
     }
     LAUNCH_CHECK();
