@@ -187,6 +187,9 @@ def cpu_baseline(cams, timesteps, mode):
     t_fwd = t_gen / n_meas
     scene = t_fwd * n_fwd + t_dec
     out = {"value": 1.0 / scene, "unit": "scenes/s", "cores": threads, "kind": "port",
+           "kind_note": ("the repo's CPU restatement of the reference algorithm (oracle/restate.py, PyTorch CPU fp32), same schedule as the GPU path (35 forwards); "
+                         + ("all iterations measured" if its == timesteps else f"BOUNDED SAMPLE: {its} of the {timesteps} MaskGit iterations measured and scaled linearly")
+                         + "; `reference_schedule_value` (72 forwards) is DERIVED from the measured per-forward time, not run"),
            "sample": (f"1 whole scene ({cams}x256x256) measured end to end: MaskGit generate with {its} iterations = {n_meas} transformer forwards ({t_gen:.1f} s) + VQGAN decode of {cams} images "
                       f"({t_dec:.1f} s)" + ("" if its == timesteps else f"; scaled to {timesteps} iterations = {n_fwd} forwards of the same cost")),
            "host": {"cpu_model": model, "logical_cores": cores, "threads_used": threads, "threads_note": "fastest of 8..128 torch threads on two transformer layers of this workload"},
@@ -363,7 +366,7 @@ def main():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.profile_begin()
+        # the timed region runs CLEAN: K steps, nothing but the product path and four stream events per step
         t0 = time.perf_counter()
         for i in range(steps):
             one_step(ev[i])
@@ -371,7 +374,17 @@ def main():
         if dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        # ... and the per-kernel roofline comes from a SEPARATE pass of the same step with a HIP-event pair around every GEMM / convolution / attention launch
+        # (two extra hipEventRecords per launch would otherwise sit inside the headline number)
+        prof_steps = min(steps, 2)
+        ctx.profile_begin()
+        tp0 = time.perf_counter()
+        for i in range(prof_steps):
+            one_step()
+        torch.cuda.synchronize()
+        prof_elapsed = time.perf_counter() - tp0
         prof = ctx.profile_end()
+        prof["_pass"] = {"steps": prof_steps, "ms": prof_elapsed * 1e3, "launches": 0}
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -410,7 +423,8 @@ def main():
             peak, kern, note = MFMA_FP32_PEAK_TF, "gemm_f32_kernel<MODE_PLAIN>", "v_mfma_f32_32x32x2_f32, exact fp32"
         else:
             peak, kern, note = MFMA_F16_PEAK_TF / 3.0, "gemm_split_glds_kernel<MODE_PLAIN, 4, 3>", "3 v_mfma_f32_32x32x16_f16 per fp32 product (hi/lo split): ceiling = f16 dense peak / 3"
-        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": pmc_traffic(kern), "kernel": kern, "note": note,
+        tr = pmc_traffic(kern)
+        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr, "kernel": kern, "note": note,
                 "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1)}
 
     import numpy as np
@@ -427,8 +441,10 @@ def main():
         "vqgan_decode_ms_per_scene": float(np.mean(parts["vq_decode"])) / args.batch,
         "gather_ms_per_step": float(np.mean(parts["gather"])),
         "roofline": roof(prof, args.precision),
-        "kernel_time_share": {k: v["ms"] / (elapsed * 1e3) for k, v in prof.items() if v["launches"]},
+        "kernel_time_share": {k: v["ms"] / prof["_pass"]["ms"] for k, v in prof.items() if v["launches"]},
         "kernel_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12) for k, v in prof.items() if v["launches"] and k in ("gemm", "conv3x3", "attention")},
+        "profiled_pass": {"steps": prof["_pass"]["steps"], "ms_per_step": prof["_pass"]["ms"] / prof["_pass"]["steps"],
+                          "note": "roofline / kernel_time_share / kernel_tflops come from this separate pass of the same step with a HIP-event pair around every hot launch; `value` is timed without it"},
     }
     if strong is not None:
         line["strong_scaling"] = strong
@@ -445,7 +461,7 @@ def main():
                                     "roofline": {"bound": "mfma", "achieved": ach4, "peak": MFMA_F16_PEAK_TF / 2.0, "unit": "TFLOP/s", "frac": ach4 / (MFMA_F16_PEAK_TF / 2.0),
                                                  "kernel": "gemm_split_glds_kernel<MODE_PLAIN, 4, 3, W16>", "launches": int(g4["launches"]), "avg_us": g4["ms"] * 1e3 / max(g4["launches"], 1),
                                                  "note": "2 v_mfma_f32_32x32x16_f16 per product (activations hi + lo, weights one f16 plane): ceiling = f16 dense peak / 2"},
-                                    "kernel_time_share": {k: v["ms"] / (e4 * 1e3) for k, v in p4.items() if v["launches"]},
+                                    "kernel_time_share": {k: v["ms"] / p4["_pass"]["ms"] for k, v in p4.items() if v["launches"]},
                                     "note": "Context(weights='f16'): every GEMM / convolution matrix rounded to f16 once at load (the reference's bf16 autocast rounds them to 8 bits on "
                                             "every call), activations and attention operands keep their hi + lo planes; same workload, 2 steps.  A different (rounded) model: the "
                                             "headline above is the fp32-weights model"}
