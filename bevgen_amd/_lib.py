@@ -59,6 +59,7 @@ SIGNATURES = {
     "bevgen_finalize": (_i, [_p]),
     "bevgen_muse_forward": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "bevgen_maskgit_generate": (_i, [_p, _p, _p, _p, _i, _i, C.POINTER(C.c_int32), _f, _i, _f, _p, _p, _p, _p, C.c_uint64, _p]),
+    "bevgen_maskgit_generate_ex": (_i, [_p, _p, _p, _p, _i, _i, C.POINTER(C.c_int32), _f, _i, _f, _p, _p, _p, _p, C.c_uint64, _i, _i, _p]),
     "bevgen_op_philox_uniform": (_i, [_p, C.c_uint64, C.c_uint, C.c_uint, _i, _l, _p, _p]),
     "bevgen_sparse_self_attention": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "bevgen_ar_prefill": (_i, [_p, _p, _p, _p, _i, _p]),

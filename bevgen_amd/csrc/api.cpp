@@ -106,6 +106,12 @@ int bevgen_muse_forward(bevgen_ctx* ctx, const int64_t* ids, const int64_t* cond
 int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
                             int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out,
                             unsigned long long noise_seed, void* stream) {
+    return bevgen_maskgit_generate_ex(ctx, cond, I_inv, E_inv, B, timesteps, sched, temperature, topk_k, critic_noise_scale, gumbel_u, critic_u, init_ids, out, noise_seed, 0, 1, stream);
+}
+
+int bevgen_maskgit_generate_ex(bevgen_ctx* ctx, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
+                               int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out,
+                               unsigned long long noise_seed, int score_mode, int samples_per_layout, void* stream) {
     return guarded(ctx, [&] {
         need_final(ctx);
         BG_REQUIRE(cond && I_inv && E_inv && out && sched, "maskgit_generate: null argument");
@@ -113,7 +119,9 @@ int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* cond, const float* I
         BG_REQUIRE(topk_k >= 1 && topk_k <= ctx->cfg.vocab_size, "maskgit_generate: topk_k=%d out of range", topk_k);
         for (int i = 0; i < timesteps; ++i)
             BG_REQUIRE(sched[i] >= 1 && sched[i] <= ctx->cfg.cam_latent_h * ctx->cfg.cam_latent_w, "maskgit_generate: mask_schedule[%d]=%d out of range", i, sched[i]);
-        maskgit_generate(*ctx, cond, I_inv, E_inv, B, timesteps, sched, temperature, topk_k, critic_noise_scale, gumbel_u, critic_u, init_ids, out, (hipStream_t)stream, noise_seed);
+        BG_REQUIRE(samples_per_layout >= 1 && B % samples_per_layout == 0, "maskgit_generate: batch %d is not a multiple of samples_per_layout %d", B, samples_per_layout);
+        maskgit_generate(*ctx, cond, I_inv, E_inv, B, timesteps, sched, temperature, topk_k, critic_noise_scale, gumbel_u, critic_u, init_ids, out, (hipStream_t)stream, noise_seed,
+                         score_mode, samples_per_layout);
     });
 }
 

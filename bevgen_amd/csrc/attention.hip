@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs a) {
     const int qclamped = qvalid ? qrow : a.Nq - 1;
 
     const float* Qp = a.Q + (long)b * a.q_bstride + (long)head * a.q_hstride + (long)qclamped * 64 + 32 * h;
-    const float* Kp = a.K + (long)b * a.kv_bstride + (long)head * a.kv_hstride;
-    const float* Vp = a.V + (long)b * a.kv_bstride + (long)head * a.kv_hstride;
+    const float* Kp = a.K + (long)(b / a.kv_group) * a.kv_bstride + (long)head * a.kv_hstride;
+    const float* Vp = a.V + (long)(b / a.kv_group) * a.kv_bstride + (long)head * a.kv_hstride;
     const float* Bp = a.bias ? a.bias + (long)head * a.bias_head_stride + (long)qclamped * a.ldbias + 4 * h : nullptr;
 
     float qf[32];

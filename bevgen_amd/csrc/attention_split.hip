@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     const int qc = qvalid ? qrow : a.Nq - 1;
 
     const long qoff = ((long)b * a.H + head) * a.Nq * 64 + (long)qc * 64 + 8 * h;
-    const long koff = ((long)b * a.H + head) * (long)a.Nk_pad * 64;
+    const long koff = ((long)(b / a.kv_group) * a.H + head) * (long)a.Nk_pad * 64;
     // (no bias: the launcher points bias_pk at a zero block with both steps 0 - unconditional loads, no select in the loop)
     const float* Bp = a.bias_pk + (long)head * a.bias_head_stride + (long)(qblk * 8 + wave) * a.bias_pk_qb_stride + lane * 4;
     const int bstep = a.bias_pk_tile_step;

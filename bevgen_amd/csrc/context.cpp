@@ -154,8 +154,10 @@ static void finalize_muse(Ctx& c) {
     expect_shape(c, p + "cond_pos_emb.weight", {c.K, D});
     expect_shape(c, p + "to_logits.weight", {g.vocab_size, D});
     expect_shape(c, p + "transformer_blocks.norm.gamma", {D});
-    expect_shape(c, "token_critic.to_pred.weight", {1, D});
-    expect_shape(c, "token_critic.to_pred.bias", {1});
+    if (c.find("token_critic.to_pred.weight")) {   // absent for a MaskGit built without a token critic (scores then come from the softmax confidence, muse_net:611-622)
+        expect_shape(c, "token_critic.to_pred.weight", {1, D});
+        expect_shape(c, "token_critic.to_pred.bias", {1});
+    }
     const int inner = H * 64;
     c.Fpad = (int)round_up(F, 32);
     c.muse.resize(g.num_layers);

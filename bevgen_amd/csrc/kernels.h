@@ -103,6 +103,7 @@ struct AttnArgs {
     int ldbias; long bias_head_stride;
     float scale;
     long o_bstride, o_qstride, o_hstride;  // O (and R) element index = b*o_bstride + q*o_qstride + head*o_hstride + d
+    int kv_group = 1;             // consecutive groups of kv_group batches read the K / V of batch b / kv_group (samples of one BEV layout share the condition's cross-attention K / V)
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -123,6 +124,7 @@ struct AttnSplitArgs {
     const float* bias_pk = nullptr;   // packed bias image (launch_pack_attn_bias) of the [Nq, Nk_pad] bias, or null; bias_head_stride applies to it
     int bias_pk_tile_step = 0;        // set by the launcher
     long bias_pk_qb_stride = 0;
+    int kv_group = 1;                 // as AttnArgs::kv_group
 };
 long attn_bias_packed_floats(int Nq, int Nk_pad);
 void launch_pack_attn_bias(const float* bias, int ld, int Nq, int Nk_pad, float* out, hipStream_t s);
@@ -270,7 +272,8 @@ void launch_ar_kv_append(const float* qkv, void* kcache, void* vcache, int kv_dt
 void launch_remask(int64_t* ids, const float* scores, const int64_t* init_ids /*or null*/, int rows, int T, int n_mask, int64_t mask_id, hipStream_t s);
 // MaskGit token pick (muse_net:587-599): top-k filter, /max(temp,1e-10), + gumbel(u), argmax; only masked positions are overwritten
 void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float* gumbel_u /*or null*/, int rows, int V, int k, float temperature,
-                         int64_t mask_id, hipStream_t s, unsigned long long seed = 0 /* != 0 and gumbel_u null: uniforms from Philox(seed, iter) */, unsigned iter = 0);
+                         int64_t mask_id, hipStream_t s, unsigned long long seed = 0 /* != 0 and gumbel_u null: uniforms from Philox(seed, iter) */, unsigned iter = 0,
+                         float* conf_scores = nullptr, int conf_mode = 0 /* scores without a token critic (muse_net:611-622): 1 = masked positions only, 2 = everywhere */);
 // Self-critic scores (muse_net:392-396, 602-611): scores = embed . w + b + ((u - 0.5) * noise_scale) * frac
 void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u /*or null*/, float noise_scale, float frac,
                           float* scores, int rows, int D, hipStream_t s, unsigned long long seed = 0, unsigned iter = 0);

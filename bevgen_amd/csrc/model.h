@@ -174,7 +174,7 @@ void ctx_finalize(Ctx& c);
 void muse_forward(Ctx& c, const int64_t* ids, const int64_t* cond, const float* I_inv, const float* E_inv, int B, float* logits, float* embed, hipStream_t s);
 void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
                       int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, hipStream_t s,
-                      unsigned long long noise_seed = 0);
+                      unsigned long long noise_seed = 0, int score_mode = 0 /* 0 token critic, 1 / 2 softmax confidence (muse_net:611-622) */, int samples_per_layout = 1);
 // ar.cpp
 void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const float* v, const int64_t* layout, const float* mask, const float* add, int B, int H,
                               int L, int block, float* out, hipStream_t s);

@@ -17,6 +17,8 @@ namespace {
 
 struct MuseWs {
     int B = 0;
+    int S = 1;   // samples per BEV layout: consecutive groups of S scenes share their condition, whose cross-attention K / V exist once per layout
+
     long rows = 0;
     float *img = nullptr, *c_embed = nullptr, *context = nullptr;
     std::vector<float*> crossK, crossV;
@@ -29,7 +31,7 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
     size_t f = 0;
     f += rows * c.D * 2;                 // img, x
     f += (size_t)B * c.cfg.num_cams * c.D + crows * c.D;
-    f += (size_t)c.cfg.num_layers * 2 * B * c.H * c.NkC_pad * 64;
+    f += (size_t)c.cfg.num_layers * 2 * B * c.H * c.NkC_pad * 64 + (size_t)B * c.K * 2 + (size_t)B * c.cfg.num_cams * c.D;
     f += rows * c.D * 3;                 // xn, qraw, att
     f += std::max(rows, crows) * 2 * c.D; // kvraw
     f += rows * c.D;                     // Q
@@ -70,9 +72,13 @@ void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_
 }
 
 // per-batch constants: embeddings + cross-attention K/V
-void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s) {
+void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s, int samples_per_layout = 1) {
     const auto& g = c.cfg;
     const std::string p = "transformer.";
+    const int S = samples_per_layout < 1 ? 1 : samples_per_layout;
+    BG_REQUIRE(B % S == 0, "batch %d is not a multiple of samples_per_layout %d", B, S);
+    const int G = B / S;   // BEV layouts: the condition side (context embedding, cross-attention K / V of every layer) is built once per layout
+    w.S = S;
     w.B = B;
     w.rows = (long)B * c.N;
     Arena& a = c.arena;
@@ -81,7 +87,7 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     const int D = c.D, H = c.H;
     w.img = g.image_embed ? a.get<float>((size_t)w.rows * D) : nullptr;
     w.c_embed = g.image_embed ? a.get<float>((size_t)B * g.num_cams * D) : nullptr;
-    w.context = a.get<float>((size_t)B * c.K * D);
+    w.context = a.get<float>((size_t)G * c.K * D);
     w.x = a.get<float>((size_t)w.rows * D);
     w.xn = a.get<float>((size_t)w.rows * D);
     w.qraw = a.get<float>((size_t)w.rows * D);
@@ -98,12 +104,24 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
 
     if (g.image_embed)
         launch_camera_embed(I_inv, E_inv, c.image_plane, c.pf(p + "img_embed.weight"), c.pf(p + "cam_embed.weight"), w.img, w.c_embed, B, g.num_cams, c.T, D, s);
-    launch_cond_embed(cond, c.pf(p + "cond_token_emb.weight"), c.pf(p + "cond_pos_emb.weight"), g.bev_embed ? c.pf(p + "bev_grid") : nullptr,
+    const int64_t* cond_g = cond;
+    const float* c_embed_g = w.c_embed;
+    if (S > 1) {   // the first scene of every group -> contiguous [G, ...] inputs of the condition side
+        int64_t* cg = a.get<int64_t>((size_t)G * c.K);
+        HIP_CHECK(hipMemcpy2DAsync(cg, (size_t)c.K * 8, cond, (size_t)S * c.K * 8, (size_t)c.K * 8, G, hipMemcpyDeviceToDevice, s));
+        cond_g = cg;
+        if (w.c_embed) {
+            float* eg = a.get<float>((size_t)G * g.num_cams * D);
+            HIP_CHECK(hipMemcpy2DAsync(eg, (size_t)g.num_cams * D * 4, w.c_embed, (size_t)S * g.num_cams * D * 4, (size_t)g.num_cams * D * 4, G, hipMemcpyDeviceToDevice, s));
+            c_embed_g = eg;
+        }
+    }
+    launch_cond_embed(cond_g, c.pf(p + "cond_token_emb.weight"), c.pf(p + "cond_pos_emb.weight"), g.bev_embed ? c.pf(p + "bev_grid") : nullptr,
                       g.bev_embed ? c.pf(p + "bev_embed.weight") : nullptr, g.bev_embed ? c.pf(p + "bev_embed.bias") : nullptr,
-                      g.bev_embed ? c.pf(p + "bev_cam_pos_emb") : nullptr, w.c_embed, w.context, B, g.num_cams, c.K, D, g.cond_vocab_size, s);
+                      g.bev_embed ? c.pf(p + "bev_cam_pos_emb") : nullptr, c_embed_g, w.context, G, g.num_cams, c.K, D, g.cond_vocab_size, s);
 
     // cross-attention keys/values: to_kv(context) (context is NOT layer-normed, muse_net:128-132), null kv prepended, k l2-normalised
-    const size_t kvC = (size_t)B * H * c.NkC_pad * 64;
+    const size_t kvC = (size_t)G * H * c.NkC_pad * 64;
     w.crossK.resize(g.num_layers);
     w.crossV.resize(g.num_layers);
     for (int i = 0; i < g.num_layers; ++i) {
@@ -112,13 +130,13 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
         HIP_CHECK(hipMemsetAsync(w.crossK[i], 0, kvC * sizeof(float), s));
         HIP_CHECK(hipMemsetAsync(w.crossV[i], 0, kvC * sizeof(float), s));
         const MuseLayer& l = c.muse[i];
-        gemm(w.context, D, l.to_kv[1], D, w.kvraw, 2 * D, B * c.K, 2 * D, D, nullptr, 0, s);
+        gemm(w.context, D, l.to_kv[1], D, w.kvraw, 2 * D, G * c.K, 2 * D, D, nullptr, 0, s);
         if (c.cfg.precision == BEVGEN_PRECISION_F16X3) {  // each fp32-sized buffer holds the (hi, lo) f16 planes back to back
             _Float16* kh = reinterpret_cast<_Float16*>(w.crossK[i]);
             _Float16* vh = reinterpret_cast<_Float16*>(w.crossV[i]);
-            launch_muse_kv_prep_split(w.kvraw, l.null_kv[1], l.k_scale[1], kh, kh + kvC, vh, vh + kvC, B, H, c.K, c.NkC_pad, s);
+            launch_muse_kv_prep_split(w.kvraw, l.null_kv[1], l.k_scale[1], kh, kh + kvC, vh, vh + kvC, G, H, c.K, c.NkC_pad, s);
         } else {
-            launch_muse_kv_prep(w.kvraw, l.null_kv[1], l.k_scale[1], w.crossK[i], w.crossV[i], B, H, c.K, c.NkC_pad, s);
+            launch_muse_kv_prep(w.kvraw, l.null_kv[1], l.k_scale[1], w.crossK[i], w.crossV[i], G, H, c.K, c.NkC_pad, s);
         }
     }
 }
@@ -154,7 +172,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             gemm(w.xn, D, l.to_q[0], D, w.qraw, D, rows, D, D, nullptr, 0, s);
             gemm(w.xn, D, l.to_kv[0], D, w.kvraw, 2 * D, rows, 2 * D, D, nullptr, 0, s);
         }
-        const size_t qN = (size_t)rows * D, kvS = (size_t)B * H * c.NkS_pad * 64, kvC = (size_t)B * H * c.NkC_pad * 64;
+        const size_t qN = (size_t)rows * D, kvS = (size_t)B * H * c.NkS_pad * 64, kvC = (size_t)(B / w.S) * H * c.NkC_pad * 64;
         _Float16 *Qh = reinterpret_cast<_Float16*>(w.Q), *Ksh = reinterpret_cast<_Float16*>(w.Ks), *VTsh = reinterpret_cast<_Float16*>(w.Vs);
         AttnSplitArgs sa{};
         if (split) {
@@ -190,12 +208,14 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             _Float16 *ckh = reinterpret_cast<_Float16*>(w.crossK[i]), *cvh = reinterpret_cast<_Float16*>(w.crossV[i]);
             sa.Kh = ckh; sa.Kl = ckh + kvC; sa.VTh = cvh; sa.VTl = cvh + kvC;
             sa.bias = c.bias_cross; sa.bias_pk = c.bias_cross_pk; sa.Nk_pad = c.NkC_pad; sa.ldbias = c.ldC;
+            sa.kv_group = w.S;   // the samples of a layout read the layout's cross-attention K / V
             launch_attention_split(sa, s);
         } else {
             launch_muse_q_prep(w.qraw, l.q_scale[1], w.Q, B, H, N, s);
             a.K = w.crossK[i]; a.V = w.crossV[i]; a.bias = c.bias_cross; a.Nk_pad = c.NkC_pad;
             a.kv_bstride = (long)H * c.NkC_pad * 64; a.kv_hstride = (long)c.NkC_pad * 64;
             a.ldbias = c.ldC;
+            a.kv_group = w.S;
             launch_attention(a, s);
         }
         // ---- feed forward
@@ -243,11 +263,13 @@ void muse_forward(Ctx& c, const int64_t* ids, const int64_t* cond, const float* 
 
 void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,
                       int topk_k, float critic_noise_scale, const float* gumbel_u, const float* critic_u, const int64_t* init_ids, int64_t* out, hipStream_t s,
-                      unsigned long long noise_seed) {
+                      unsigned long long noise_seed, int score_mode, int samples_per_layout) {
     BG_REQUIRE(c.cfg.route == BEVGEN_ROUTE_MASKGIT, "context was not created for the MaskGit route");
     BG_REQUIRE(B >= 1 && timesteps >= 1 && sched, "bad generate arguments");
+    BG_REQUIRE(score_mode != 0 || c.find("token_critic.to_pred.weight"), "maskgit_generate: the context holds no token critic (token_critic.to_pred.*): use score_mode 1 / 2");
+    BG_REQUIRE(score_mode >= 0 && score_mode <= 2, "score_mode %d: 0 token critic, 1 softmax confidence, 2 softmax confidence with re-masking of earlier tokens", score_mode);
     MuseWs w;
-    muse_prepare(c, w, cond, I_inv, E_inv, B, s);
+    muse_prepare(c, w, cond, I_inv, E_inv, B, s, samples_per_layout);
     const int rows = (int)w.rows;            // B*C*T token rows
     const int seqs = B * c.cfg.num_cams;     // rows of the [B*C, T] id matrix
     const int T = c.T, V = c.V, D = c.D;
@@ -263,9 +285,11 @@ void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const flo
         launch_remask(ids, scores, init_ids, seqs, T, sched[step], mask_id, s);
         muse_blocks(c, w, ids, s);
         gemm(w.xn, D, c.pf("transformer.to_logits.weight"), D, logits, V, rows, V, D, nullptr, 0, s);
+        // score_mode 1 / 2 (force_not_use_token_critic, muse_net:611-622): the scores come out of the pick itself (1 - softmax(logits)[pred]) and the critic forward
+        // is not run at all - 18 transformer forwards per call instead of 35
         launch_maskgit_pick(ids, logits, V, gumbel_u ? gumbel_u + (size_t)step * rows * V : nullptr, rows, V, topk_k, (float)((double)temperature * frac), mask_id, s,
-                            noise_seed, (unsigned)step);
-        if (step + 1 < timesteps) {  // the critic scores only select what the NEXT iteration re-masks
+                            noise_seed, (unsigned)step, score_mode ? scores : nullptr, score_mode);
+        if (score_mode == 0 && step + 1 < timesteps) {  // the critic scores only select what the NEXT iteration re-masks
             muse_blocks(c, w, ids, s);
             launch_critic_scores(w.xn, D, c.pf("token_critic.to_pred.weight"), c.pf("token_critic.to_pred.bias"),
                                  critic_u ? critic_u + (size_t)step * rows : nullptr, critic_noise_scale, (float)frac, scores, rows, D, s, noise_seed, (unsigned)step);

@@ -69,12 +69,19 @@ void launch_remask(int64_t* ids, const float* scores, const int64_t* init_ids, i
 }
 
 // ---------------------------------------------------------------------------------------------- MaskGit token pick
+// conf_mode (scores without a token critic, muse_net:611-622): 0 = off; 1 = scores[row] = 1 - softmax(logits)[pred] at the positions that were masked, -1e5 elsewhere
+// (can_remask_prev_masked = False); 2 = 1 - softmax(logits)[pred] everywhere, pred drawn for EVERY position (can_remask_prev_masked = True)
 __global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__ ids, const float* __restrict__ logits, int ldl, const float* __restrict__ gumbel_u,
-                                                           long rows, int V, int k, float temp_div, int64_t mask_id, unsigned long long seed, unsigned iter) {
+                                                           long rows, int V, int k, float temp_div, int64_t mask_id, unsigned long long seed, unsigned iter,
+                                                           float* __restrict__ conf_scores, int conf_mode) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    if (ids[row] != mask_id) return;  // only masked positions are replaced (muse_net:593-599)
+    const bool was_mask = ids[row] == mask_id;
+    if (!was_mask) {  // only masked positions are replaced (muse_net:593-599)
+        if (conf_mode == 1 && lane == 0) conf_scores[row] = -1e5f;
+        if (conf_mode != 2) return;
+    }
     const float* lr = logits + row * ldl;
     float x[VPL_MAX];
     uint32_t key[VPL_MAX];
@@ -107,14 +114,33 @@ __global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__
         if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
     }
     wave_argmax(best, bidx);
-    if (lane == 0) ids[row] = bidx;
+    if (lane == 0 && was_mask) ids[row] = bidx;
+    if (conf_mode) {   // probs_without_temperature = logits.softmax(-1) over the UNfiltered logits; score = 1 - p[pred] (muse_net:612-615)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < VPL_MAX; ++j)
+            if (valid[j]) mx = fmaxf(mx, x[j]);
+        mx = wave_max(mx);
+        float sum = 0.f, xp = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL_MAX; ++j) {
+            if (!valid[j]) continue;
+            sum += expf(x[j] - mx);
+            if (lane + 64 * j == bidx) xp = x[j];
+        }
+        sum = wave_sum(sum);
+        xp = wave_sum(xp);   // exactly one lane holds the picked logit
+        if (lane == 0) conf_scores[row] = 1.f - expf(xp - mx) / sum;
+    }
 }
 
 void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float* gumbel_u, int rows, int V, int k, float temperature, int64_t mask_id, hipStream_t s,
-                         unsigned long long seed, unsigned iter) {
+                         unsigned long long seed, unsigned iter, float* conf_scores, int conf_mode) {
     BG_REQUIRE(V <= 64 * VPL_MAX, "maskgit_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
+    BG_REQUIRE(conf_mode == 0 || conf_scores, "maskgit_pick: confidence scores requested without an output buffer");
     const float temp_div = fmaxf(temperature, 1e-10f);
-    hipLaunchKernelGGL(maskgit_pick_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, logits, ldl, gumbel_u, (long)rows, V, k, temp_div, mask_id, seed, iter);
+    hipLaunchKernelGGL(maskgit_pick_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, logits, ldl, gumbel_u, (long)rows, V, k, temp_div, mask_id, seed, iter, conf_scores,
+                       conf_mode);
     LAUNCH_CHECK();
 }
 

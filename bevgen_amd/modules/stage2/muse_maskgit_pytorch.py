@@ -96,8 +96,8 @@ class MaskGit(nn.Module):
         self.noise_schedule = noise_schedule
         assert not (self_token_critic and token_critic is not None)
         self.token_critic = SelfCritic(transformer) if self_token_critic else token_critic
-        if self.token_critic is None or not isinstance(self.token_critic, SelfCritic):
-            raise NotImplementedError("only the self token critic of the shipped configuration (self_token_critic: True) is implemented")
+        if self.token_critic is not None and not isinstance(self.token_critic, SelfCritic):
+            raise NotImplementedError("a separate TokenCritic network is not implemented: the shipped configuration uses self_token_critic (or none: confidence scores)")
         self.critic_loss_weight = critic_loss_weight
         self.self_cond_prob = self_cond_prob
         self.no_mask_token_prob = no_mask_token_prob
@@ -133,11 +133,12 @@ class MaskGit(nn.Module):
     @torch.no_grad()
     def generate(self, init_ids: Optional[torch.Tensor] = None, cond_images: Optional[torch.Tensor] = None, fmap_size=None, temperature=1.0,
                  topk_filter_thres=0.9, can_remask_prev_masked=False, force_not_use_token_critic=False, timesteps=12, cond_scale=3,
-                 critic_noise_scale=1, batch=None, noise=None):
+                 critic_noise_scale=1, batch=None, noise=None, samples_per_layout=1):
         """muse_net:511-627.  ``noise``: None -> stochastic like the reference (uniforms drawn in the sampler kernels, seeded from torch's generator);
         an int -> that seed; 'greedy' -> gumbel noise 0 / critic uniform 0.5; or {'gumbel_u','critic_u'} explicit uniforms."""
-        if force_not_use_token_critic or can_remask_prev_masked:
-            raise NotImplementedError("only the token-critic scoring path of the shipped configuration is implemented")
+        use_token_critic = self.token_critic is not None and not force_not_use_token_critic   # muse_net:553
+        if not use_token_critic and can_remask_prev_masked:
+            assert self.no_mask_token_prob > 0., 'without training with some of the non-masked tokens forced to predict, not sure if the logits will be meaningful for these token'   # muse_net:621
         cfg = self.transformer.cfg
         ctx = self.context()
         if fmap_size is not None and tuple(fmap_size) != (cfg.cam_latent_h, cfg.cam_latent_w):
@@ -158,7 +159,7 @@ class MaskGit(nn.Module):
             gu, cu = noise["gumbel_u"], noise["critic_u"]
         return ctx.maskgit_generate(cond_images, batch["intrinsics_inv"], batch["extrinsics_inv"], timesteps=timesteps, temperature=temperature,
                                     topk_filter_thres=topk_filter_thres, critic_noise_scale=critic_noise_scale, gumbel_u=gu, critic_u=cu, init_ids=init_ids,
-                                    noise_seed=seed)
+                                    noise_seed=seed, use_token_critic=use_token_critic, can_remask_prev_masked=can_remask_prev_masked, samples_per_layout=samples_per_layout)
 
     @torch.no_grad()
     def transformer_forward(self, x, conditioning_token_ids, batch, return_embed=False):

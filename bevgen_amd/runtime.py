@@ -187,8 +187,10 @@ class Context:
         return logits, embed
 
     def maskgit_generate(self, cond_ids, I_inv, E_inv, *, timesteps=18, temperature=1.0, topk_filter_thres=0.9, critic_noise_scale=1.0,
-                         gumbel_u=None, critic_u=None, init_ids=None, noise_seed=0):
-        """gumbel_u / critic_u: explicit uniforms (parity tests); else noise_seed != 0: the samplers draw them in registers (Philox); else deterministic."""
+                         gumbel_u=None, critic_u=None, init_ids=None, noise_seed=0, use_token_critic=True, can_remask_prev_masked=False, samples_per_layout=1):
+        """gumbel_u / critic_u: explicit uniforms (parity tests); else noise_seed != 0: the samplers draw them in registers (Philox); else deterministic.
+        use_token_critic=False: scores = 1 - softmax(logits)[pred] (muse_net:611-622; no critic forwards), can_remask_prev_masked as the reference's flag.
+        samples_per_layout S: consecutive groups of S scenes share their condition (cross-attention K / V built once per layout)."""
         cfg = self.cfg
         d = self.device
         cond_ids = _req(cond_ids, torch.int64, d, "cond_ids")
@@ -208,9 +210,10 @@ class Context:
         if init_ids is not None:
             init_ids = _req(init_ids, torch.int64, d, "init_ids").reshape(rows, T)
         out = torch.empty((rows, T), dtype=torch.int64, device=d)
-        self._check(self.lib.bevgen_maskgit_generate(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, timesteps, sched_c, float(temperature),
-                                                      topk_count(topk_filter_thres, cfg.vocab_size), float(critic_noise_scale), _ptr(gumbel_u), _ptr(critic_u),
-                                                      _ptr(init_ids), _ptr(out), C.c_uint64(int(noise_seed) & 0xFFFFFFFFFFFFFFFF), self._s()))
+        score_mode = 0 if use_token_critic else (2 if can_remask_prev_masked else 1)
+        self._check(self.lib.bevgen_maskgit_generate_ex(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, timesteps, sched_c, float(temperature),
+                                                         topk_count(topk_filter_thres, cfg.vocab_size), float(critic_noise_scale), _ptr(gumbel_u), _ptr(critic_u),
+                                                         _ptr(init_ids), _ptr(out), C.c_uint64(int(noise_seed) & 0xFFFFFFFFFFFFFFFF), score_mode, int(samples_per_layout), self._s()))
         return out.reshape(rows, cfg.cam_latent_h, cfg.cam_latent_w)
 
     def philox_uniform(self, seed, it, stream_id, n, V=0):

@@ -147,6 +147,19 @@ int bevgen_maskgit_generate(bevgen_ctx* ctx, const int64_t* d_cond_ids, const fl
                             const float* d_gumbel_u, const float* d_critic_u, const int64_t* d_init_ids, int64_t* d_out_ids,
                             unsigned long long noise_seed, void* stream);
 
+/* The remaining branches of MaskGit.generate (stage2/muse_maskgit_pytorch.py:511-627) and BASELINE config 5's sample sharing:
+ *   score_mode 0  the token critic (above);
+ *              1  force_not_use_token_critic = True (:611-619): scores = 1 - softmax(logits)[pred], -1e5 at positions that were not masked in the iteration;
+ *                 no critic forward is run (18 transformer forwards per call instead of 35); d_critic_u / critic_noise_scale are not used;
+ *              2  ... with can_remask_prev_masked = True (:620-622): the same scores at EVERY position (the prediction is drawn everywhere)
+ *   samples_per_layout S > 1: consecutive groups of S scenes share their BEV layout and cameras (all B = layouts * S rows of d_cond_ids / matrices are
+ *                 passed; the flag enables the reuse): the condition embedding and the cross-attention K / V of every layer are built once per
+ *                 LAYOUT and read by the S samples of the group. */
+int bevgen_maskgit_generate_ex(bevgen_ctx* ctx, const int64_t* d_cond_ids, const float* d_I_inv, const float* d_E_inv, int B,
+                               int timesteps, const int32_t* h_mask_schedule, float temperature, int topk_k, float critic_noise_scale,
+                               const float* d_gumbel_u, const float* d_critic_u, const int64_t* d_init_ids, int64_t* d_out_ids,
+                               unsigned long long noise_seed, int score_mode, int samples_per_layout, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Route A - autoregressive sparse-causal transformer with camera bias (prefill + KV-cache decode)                 */
 

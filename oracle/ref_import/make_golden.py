@@ -126,6 +126,35 @@ def golden_route_m(case: cases.Case, full: bool):
     save("route_m_" + case.name, **out)
 
 
+def golden_route_m_branches(case: cases.Case):
+    """The remaining branches of the reference's MaskGit.generate on a tiny case, each run by the imported reference and asserted against the restatement:
+    force_not_use_token_critic (muse_net:611-619), + can_remask_prev_masked (:620-622; the reference asserts no_mask_token_prob > 0, a training-time knob the
+    generate path reads nowhere else), and BASELINE config 5's top-k threshold 0.96875 with the token critic - greedy and with explicit noise."""
+    cfg = case.make_cfg()
+    sd = cases.maskgit_state_dict(cfg, case.weight_seed)
+    mg, _ = RM.build_ref_maskgit(cfg, sd)
+    mg.no_mask_token_prob = 0.1
+    bt = cases.inputs(case, cfg)
+    batch = {"intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
+    noise = cases.maskgit_noise(case, cfg, seed=13)
+    out = dict(cond_ids=bt["cond_ids"].to(torch.int16), I_inv=bt["intrinsics_inv"], E_inv=bt["extrinsics_inv"])
+    variants = {"nocritic": dict(force_not_use_token_critic=True), "nocritic_remask": dict(force_not_use_token_critic=True, can_remask_prev_masked=True),
+                "topk096875": dict(topk_filter_thres=0.96875)}
+    for tag, kw in variants.items():
+        okw = dict(use_token_critic=not kw.get("force_not_use_token_critic", False), can_remask_prev_masked=kw.get("can_remask_prev_masked", False),
+                   topk_filter_thres=kw.get("topk_filter_thres", 0.9))
+        for ntag, nz in (("greedy", None), ("noisy", noise)):
+            with RM.deterministic_maskgit_noise(nz), torch.no_grad():
+                ref = mg.generate(cond_images=bt["cond_ids"], fmap_size=cfg.cam_latent_res, batch=batch, timesteps=case.timesteps, **kw)
+            mine = R.maskgit_generate(sd, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], depth=cfg.num_layers, heads=cfg.num_heads,
+                                      timesteps=case.timesteps, noise=nz, **okw)
+            assert torch.equal(ref, mine), f"oracle generate != reference generate ({tag}, {ntag})"
+            out[f"gen_{tag}_{ntag}"] = ref.to(torch.int16)
+    assert not torch.equal(out["gen_nocritic_noisy"], out["gen_nocritic_remask_noisy"]) or not torch.equal(out["gen_nocritic_greedy"], out["gen_nocritic_remask_greedy"]), \
+        "the re-masking variant must differ somewhere"
+    save("route_m_branches_" + case.name, **out)
+
+
 # ------------------------------------------------------------------------------------------------ Route A
 class _RefSampler:
     """Drives the reference's OWN sampling loop, `Net2NetTransformer.sample` (ar_lm:154-227: mask-id initialisation, decode order from a fresh
@@ -461,6 +490,9 @@ def main():
     if (args.only is not None and "vq_full" in args.only) or (args.only is None and not args.skip_full) or args.vq_full:
         print("vq_full")
         golden_vq_full()
+    if want("m_branches"):
+        print("m_branches")
+        golden_route_m_branches(cases.CASES["m_tiny_rays"])
     for name, case in cases.CASES.items():
         full = name in ("a_config1", "m_full_3cam", "m_full_6cam", "a_config4_head", "a_config4_d035_head")
         if not want(name) or (full and args.skip_full):

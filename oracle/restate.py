@@ -184,8 +184,10 @@ def gumbel_from_uniform(u: Tensor) -> Tensor:
 def maskgit_generate(sd, cfg, cond_ids: Tensor, I_inv: Tensor, E_inv: Tensor, *, depth: int, heads: int, timesteps: int = 18,
                      temperature: float = 1.0, topk_filter_thres: float = 0.9, critic_noise_scale: float = 1.0,
                      noise: Optional[Mapping[str, Tensor]] = None, init_ids: Optional[Tensor] = None,
-                     redundant_forwards: bool = False, trace: Optional[List[Dict[str, Tensor]]] = None) -> Tensor:
-    """MaskGit.generate with the self token critic (muse_net:511-627) -> ids [(B*C), h, w].
+                     redundant_forwards: bool = False, trace: Optional[List[Dict[str, Tensor]]] = None,
+                     use_token_critic: bool = True, can_remask_prev_masked: bool = False) -> Tensor:
+    """MaskGit.generate (muse_net:511-627) -> ids [(B*C), h, w]: with the self token critic, or (``use_token_critic=False`` = the reference's
+    ``force_not_use_token_critic`` / a model without critic, muse_net:611-622) with scores = 1 - softmax(logits)[pred].
 
     ``noise``: {'gumbel_u': [timesteps,(B*C),T,V], 'critic_u': [timesteps,(B*C),T]} uniforms in [0,1) replacing the
     reference's ``uniform_`` draws (torch RNG streams cannot be matched across devices); ``None`` = the deterministic
@@ -218,12 +220,17 @@ def maskgit_generate(sd, cfg, cond_ids: Tensor, I_inv: Tensor, E_inv: Tensor, *,
         pred = (filtered / max(temp, 1e-10) + g).argmax(dim=-1)
         is_mask = ids == mask_id
         ids = torch.where(is_mask, pred, ids)
-        _, embed = fwd(ids)
-        if redundant_forwards:
-            fwd(ids)
-        crit = F.linear(embed, sd["token_critic.to_pred.weight"], sd["token_critic.to_pred.bias"])[..., 0]
-        u = torch.full_like(crit, 0.5) if noise is None else noise["critic_u"][step]
-        scores = crit + (u - 0.5) * critic_noise_scale * (steps_until_x0 / timesteps)
+        if use_token_critic:
+            _, embed = fwd(ids)
+            if redundant_forwards:
+                fwd(ids)
+            crit = F.linear(embed, sd["token_critic.to_pred.weight"], sd["token_critic.to_pred.bias"])[..., 0]
+            u = torch.full_like(crit, 0.5) if noise is None else noise["critic_u"][step]
+            scores = crit + (u - 0.5) * critic_noise_scale * (steps_until_x0 / timesteps)
+        else:   # muse_net:611-622
+            scores = 1 - logits.softmax(dim=-1).gather(2, pred[..., None])[..., 0]
+            if not can_remask_prev_masked:
+                scores = scores.masked_fill(~is_mask, -1e5)
         if trace is not None:
             trace.append({"ids": ids.clone(), "scores": scores.clone(), "logits": logits.clone()})
     return ids.reshape(B * C, cfg.cam_latent_h, cfg.cam_latent_w)

@@ -208,3 +208,38 @@ def test_gpt_dropin_keeps_every_layers_master_layout(name):
     else:   # full-size model: the golden holds the first `steps` tokens only
         x = gpt.context().ar_sample(cond, batch["intrinsics_inv"], batch["extrinsics_inv"], greedy=True, steps=case.steps).cpu()
     assert torch.equal(x, want), f"{(x != want).sum().item()} tokens differ from the reference's (per-layer layouts lost?)"
+
+
+def test_maskgit_dropin_generate_without_token_critic():
+    """MaskGit.generate(force_not_use_token_critic=True[, can_remask_prev_masked=True]) and a MaskGit built without any critic (muse_net:553, 611-622) through the
+    drop-in module: tokens = what the imported reference generated."""
+    from conftest import golden
+    from bevgen_amd.modules.stage2.muse_maskgit_pytorch import MaskGit, MaskGitTransformerMultiView
+    from oracle import cases
+
+    case = cases.CASES["m_tiny_rays"]
+    g = golden("route_m_branches_m_tiny_rays")
+    cfg = case.make_cfg()
+    sd = cases.maskgit_state_dict(cfg, case.weight_seed)
+    cond = torch.from_numpy(g["cond_ids"]).long().cuda()
+    batch = {"intrinsics_inv": torch.from_numpy(g["I_inv"]).cuda(), "extrinsics_inv": torch.from_numpy(g["E_inv"]).cuda()}
+
+    def build(self_critic, **kw):
+        tr = MaskGitTransformerMultiView(num_tokens=cfg.vocab_size, dim=cfg.num_embed, seq_len=cfg.cam_latent_res, depth=cfg.num_layers, dim_head=64, heads=cfg.num_heads,
+                                         ff_mult=4, cfg=cfg)
+        mg = MaskGit(image_size=cfg.cam_latent_res, transformer=tr, self_token_critic=self_critic, **kw)
+        want = {k: v for k, v in sd.items() if self_critic or not k.startswith("token_critic.")}
+        missing, unexpected = mg.load_state_dict(want, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        return mg.to("cuda")
+
+    mg = build(True, no_mask_token_prob=0.1)
+    for tag, kw in (("nocritic", dict(force_not_use_token_critic=True)), ("nocritic_remask", dict(force_not_use_token_critic=True, can_remask_prev_masked=True))):
+        x = mg.generate(cond_images=cond, fmap_size=cfg.cam_latent_res, batch=batch, timesteps=case.timesteps, noise="greedy", **kw).cpu()
+        assert torch.equal(x, torch.from_numpy(g[f"gen_{tag}_greedy"]).long()), tag
+    with pytest.raises(AssertionError, match="non-masked tokens"):
+        build(True).generate(cond_images=cond, fmap_size=cfg.cam_latent_res, batch=batch, timesteps=case.timesteps, noise="greedy", force_not_use_token_critic=True,
+                             can_remask_prev_masked=True)
+    bare = build(False)   # no critic at all: use_token_critic is False without the flag (muse_net:553)
+    x = bare.generate(cond_images=cond, fmap_size=cfg.cam_latent_res, batch=batch, timesteps=case.timesteps, noise="greedy").cpu()
+    assert torch.equal(x, torch.from_numpy(g["gen_nocritic_greedy"]).long())
