@@ -15,6 +15,11 @@ static int guarded(bevgen_ctx* ctx, F&& f) {
         if (!ctx) return BEVGEN_ERR_INVALID;
         HIP_CHECK(hipSetDevice(ctx->device));
         split_registry_set(ctx->cfg.precision == BEVGEN_PRECISION_F16X3 ? &ctx->split : nullptr);
+        struct CurrentProf {   // this context's profiler receives the launch records of this call (restored on every exit path)
+            Profiler* old;
+            explicit CurrentProf(Profiler* p) : old(prof_set_current(p)) {}
+            ~CurrentProf() { prof_set_current(old); }
+        } cur(&ctx->prof);
         f();
         return BEVGEN_OK;
     } catch (const Error& e) {
@@ -423,13 +428,13 @@ int bevgen_op_groupnorm(bevgen_ctx* ctx, const float* x, const float* gamma, con
 int bevgen_decode_attention_splits(int B, int H, int n) { return decode_attention_splits(B, H, n); }
 
 int bevgen_profile_begin(bevgen_ctx* ctx) {
-    return guarded(ctx, [&] { prof_begin(); });
+    return guarded(ctx, [&] { ctx->prof.begin(); });
 }
 
 int bevgen_profile_end(bevgen_ctx* ctx, double* out) {
     return guarded(ctx, [&] {
         BG_REQUIRE(out, "profile_end: null output");
-        prof_end(out);
+        ctx->prof.end(out);
     });
 }
 

@@ -9,6 +9,7 @@
 #include "../../include/bevgen_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include "profiler.h"
 
 namespace bevgen {
 
@@ -132,6 +133,8 @@ struct Ctx {
     // ---- split-precision mode (BEVGEN_PRECISION_F16X3): (hi, lo) f16 planes of every GEMM / conv weight, keyed by its fp32 device pointer
     std::unordered_map<const float*, SplitPlanes> split;
     void split_weight(const float* w, long n);
+
+    Profiler prof;   // per-launch HIP-event timing (bevgen_profile_begin / _end) of THIS context
 
     // ---- hipGraph replay of the Route A decode step
     hipStream_t graph_stream = nullptr;

@@ -1,23 +1,39 @@
 // Optional per-launch timing of the hot kernels with HIP events recorded on the launch stream (bench.py's roofline leg).
-// Disabled by default: when off, the wrappers cost one branch.
+// Disabled by default: when off, the wrappers cost one branch.  The state is PER CONTEXT (Ctx::prof): the C-ABI entry points make their context's profiler
+// the calling thread's current one for the duration of the call, so two contexts in one process never interleave their records.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <vector>
 
 namespace bevgen {
 
 enum ProfKind { PROF_GEMM = 0, PROF_CONV3 = 1, PROF_ATTN = 2, PROF_DECODE_ATTN = 3, PROF_GEMM_SKINNY = 4, PROF_KINDS = 5 };
 
+struct Profiler {
+    struct Rec { int kind; double work; hipEvent_t a, b; };
+    bool on = false;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t pool_used = 0;
+    ~Profiler();
+    void begin();
+    // out[kind*3 + {0,1,2}] = launches, total milliseconds, total work (flops or bytes); synchronises the device
+    void end(double* out);
+};
+
+// the profiler the launch wrappers of THIS thread report to (null = none); returns the previous one
+Profiler* prof_set_current(Profiler* p);
+
 struct ProfScope {
-    // records an event pair around the enclosed launch(es) when profiling is enabled
+    // records an event pair around the enclosed launch(es) when the calling thread's current profiler is enabled
     ProfScope(int kind, double work, hipStream_t s);
     ~ProfScope();
+    Profiler* p;
     int idx;
     hipStream_t stream;
 };
 
-void prof_begin();
-// out[kind*3 + {0,1,2}] = launches, total milliseconds, total work (flops or bytes); synchronises the device
-void prof_end(double* out);
 bool prof_enabled();
 
 }  // namespace bevgen

@@ -376,3 +376,22 @@ def test_ln_gemm_operator(gpu_ctx, M, N, K, ln, gelu):
             ref = F.gelu(ref)
     out = gpu_ctx.op_ln_gemm(dev(a), dev(w), ln_w=dev(lw) if ln else None, ln_b=dev(lb) if ln else None, bias=dev(b) if ln else None, gelu=gelu and ln)
     assert rel(out.cpu().double(), ref) < 6e-6
+
+
+def test_profiler_state_is_per_context(gpu_ctx):
+    """bevgen_profile_begin / _end time the launches of THEIR context only: another context's calls in between are not recorded (and do not disturb the records)."""
+    from bevgen_amd.runtime import Context
+
+    other = Context(None)
+    a, w = dev(torch.randn(256, 128)), dev(torch.randn(128, 128))
+    gpu_ctx.profile_begin()
+    gpu_ctx.op_gemm(a, w)
+    other.op_gemm(a, w)          # not profiled: `other` never called profile_begin
+    other.profile_begin()
+    other.op_gemm(a, w)
+    gpu_ctx.op_gemm(a, w)
+    po = other.profile_end()
+    pa = gpu_ctx.profile_end()
+    assert pa["gemm"]["launches"] == 2 and po["gemm"]["launches"] == 1, (pa["gemm"], po["gemm"])
+    assert pa["gemm"]["ms"] > 0 and po["gemm"]["ms"] > 0
+    other.close()
