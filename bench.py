@@ -59,11 +59,55 @@ def parse():
     return ap.parse_args()
 
 
+# Control-flow dry run (tests/test_bench_cpu.py): BEVGEN_BENCH_DRYRUN=1 swaps the library context for a shape-only stub and RCCL for gloo so that the N > 1 paths of this
+# file (rank sharding, barrier / max-over-ranks timing, the gather, the strong-scaling leg, rank-0 reporting) can be executed on a CPU box before the first real multi-GPU
+# run.  The line it prints carries "dry_run": true and no performance meaning; nothing in the product path reads this variable.
+DRY_RUN = os.environ.get("BEVGEN_BENCH_DRYRUN") == "1"
+
+
+class _CpuEvent:
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class _StubContext:
+    """Shape-only stand-in for bevgen_amd.runtime.Context (dry run): token ids / pixels of the right shape and dtype, no arithmetic."""
+
+    def __init__(self, cfg):
+        import torch
+        self.cfg, self.device = cfg, torch.device("cpu")
+
+    def maskgit_generate(self, cond_ids, I_inv, E_inv, timesteps=18, noise_seed=0, **kw):
+        import torch
+        B = cond_ids.shape[0]
+        g = torch.Generator().manual_seed(int(noise_seed) % (2 ** 31))
+        return torch.randint(0, self.cfg.vocab_size, (B * self.cfg.num_cams, self.cfg.cam_latent_h, self.cfg.cam_latent_w), generator=g)
+
+    def vq_decode(self, ids, latent_hw=None, uint8=False, **kw):
+        import torch
+        return (ids.reshape(ids.shape[0], -1)[:, :1, None, None] % 256).to(torch.uint8).expand(ids.shape[0], 3, 16 * latent_hw[0], 16 * latent_hw[1]).contiguous()
+
+    def profile_begin(self):
+        pass
+
+    def profile_end(self):
+        return {k: {"launches": 0.0, "ms": 0.0, "work": 0.0} for k in ("gemm", "conv3x3", "attention", "decode_attention", "gemm_skinny")}
+
+    def close(self):
+        pass
+
+
 def self_launch(args):
     """--gpus N without a launcher: become `torch.distributed.run` with N ranks on this node."""
     import torch
 
-    have = torch.cuda.device_count()
+    have = args.gpus if DRY_RUN else torch.cuda.device_count()
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
@@ -107,10 +151,13 @@ def cached(key, make):
 
 def build_route_m(cams, batch, device, precision="fp32", weights="f32"):
     from bevgen_amd import presets
+
+    cfg = presets.config2(cams)
+    if DRY_RUN:
+        return cfg, _StubContext(cfg), None
     from bevgen_amd.runtime import Context
     from bevgen_amd.weights import maskgit_state_dict, vq_state_dict
 
-    cfg = presets.config2(cams)
     sd = cached(("maskgit", cams), lambda: maskgit_state_dict(cfg, 1234))
     dd = presets.VQ_DDCONFIG_F16
     ctx = Context(cfg, route="maskgit", vq_ddconfig=dd, vq_n_embed=1024, vq_embed_dim=256, device=device, max_batch=batch, precision=precision, weights=weights)
@@ -324,16 +371,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    assert DRY_RUN or torch.cuda.is_available(), "bench.py needs an MI355X"
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
-    torch.cuda.set_device(local_rank)
+    sync = (lambda: None) if DRY_RUN else torch.cuda.synchronize
+    Event = _CpuEvent if DRY_RUN else torch.cuda.Event
+    if not DRY_RUN:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world)  # backend "nccl" is RCCL on ROCm
+        dist_mod.init_process_group("gloo" if DRY_RUN else "nccl", rank=rank, world_size=world)  # backend "nccl" is RCCL on ROCm
         dist = dist_mod
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: RCCL world size {dist.get_world_size()} != --gpus {args.gpus}")
@@ -346,7 +396,7 @@ def main():
         cfg, ctx, _ = build_route_m(cams, batch, local_rank, precision, weights)
         bt = synthetic.make_batch(cfg, batch, seed=1000 + rank)  # each rank: its own shard of scenes
         bt = {k: v.to(ctx.device) for k, v in bt.items()}
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+        ev = [[Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
         seeds = []
 
         def one_step(e=None):
@@ -365,12 +415,12 @@ def main():
             one_step()
         if dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         # the timed region runs CLEAN: K steps, nothing but the product path and four stream events per step
         t0 = time.perf_counter()
         for i in range(steps):
             one_step(ev[i])
-        torch.cuda.synchronize()
+        sync()
         if dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -381,7 +431,7 @@ def main():
         tp0 = time.perf_counter()
         for i in range(prof_steps):
             one_step()
-        torch.cuda.synchronize()
+        sync()
         prof_elapsed = time.perf_counter() - tp0
         prof = ctx.profile_end()
         prof["_pass"] = {"steps": prof_steps, "ms": prof_elapsed * 1e3, "launches": 0}
@@ -400,6 +450,8 @@ def main():
         e_s, _, _ = run_route_m(args.precision, s_steps, 1, args.cams, 16 // world)   # 16 scenes in total, sharded
         strong = {"scaling": "strong", "global_batch": 16, "scenes_per_gpu": 16 // world, "steps": s_steps, "value": 16 * s_steps / e_s, "unit": "scenes/s", "ms_per_step": e_s * 1e3 / s_steps}
     exact = None
+    if DRY_RUN:
+        args.no_extra_legs = args.no_decode_leg = args.no_cpu_baseline = args.no_exact_leg = True
     if world == 1 and args.precision != "fp32" and not args.no_exact_leg:
         e2, p2, _ = run_route_m("fp32", 1, 1, args.cams, args.batch)   # the exact-fp32 parity mode on the same workload (one step)
         exact = (e2, p2)
@@ -434,7 +486,7 @@ def main():
         "ms_per_step": elapsed * 1e3 / args.steps, "ms_per_step_median": pct(parts["step"], 50), "ms_per_step_p99": pct(parts["step"], 99),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM/conv/attention products as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; everything else fp32)",
-        "data": "synthetic",
+        "data": "synthetic" if not DRY_RUN else "DRY RUN: stub context on CPU, control flow only - no performance meaning",
         "config": {"workload": f"BASELINE configs[1]: Route M MaskGit (14 layers, D=1024, 18 iterations, top-k 0.9 + gumbel / critic noise, self-critic) {args.cams}x256x256, batch {args.batch} scenes/GPU, + VQGAN f16 decode to uint8",
                    "global_batch": n_gpus * args.batch, "parallelism": f"scene-parallel x{n_gpus} (RCCL gather of uint8 pixels)", "precision_mode": args.precision},
         "ms_per_maskgit_iteration": float(np.mean(parts["generate"])) / args.timesteps,
@@ -446,6 +498,8 @@ def main():
         "profiled_pass": {"steps": prof["_pass"]["steps"], "ms_per_step": prof["_pass"]["ms"] / prof["_pass"]["steps"],
                           "note": "roofline / kernel_time_share / kernel_tflops come from this separate pass of the same step with a HIP-event pair around every hot launch; `value` is timed without it"},
     }
+    if DRY_RUN:
+        line["dry_run"] = True
     if strong is not None:
         line["strong_scaling"] = strong
     if exact is not None:
