@@ -121,6 +121,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g, const fl
     g.C[(long)m * g.ldc + col] = v;
 }
 
+void launch_splitk_reduce(const GemmArgs& g, const float* partial, int ksplit, hipStream_t s) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((long)g.M * g.N, 256)), dim3(256), 0, s, g, partial, ksplit);
+    LAUNCH_CHECK();
+}
+
 int gemm_skinny_ksplit(int M, int N, int K) {
     (void)M;
     const int blocks = cdiv(N, SK_NT);

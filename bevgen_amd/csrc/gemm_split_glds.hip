@@ -98,8 +98,11 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
             a_img[j] = img; a_yx[j] = (y << 16) | (rem - y * g.conv_w);
         }
     }
+    // split-K (gridDim.z slices, small-M problems): this block owns k-tiles [kt_first, kt_first + nk)
+    const int nk_all = g.K / GBK, ksl = (int)gridDim.z, kz = (int)blockIdx.z;
+    const int kt_first = kz * (nk_all / ksl) + min(kz, nk_all % ksl);
     // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order)
-    int k_issue = 0;
+    int k_issue = kt_first * GBK;
     const int n_img = MODE == MODE_CONV3 ? g.M / (g.conv_h * g.conv_w) : 0;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ap), 0, MODE == MODE_CONV3 ? g.a_bytes : -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bp), 0, -1, 0x00020000);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
             for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], accC[i][j], 0, 0, 0);
     };
 
-    const int nk = g.K / GBK;
+    const int nk = nk_all / ksl + (kz < nk_all % ksl ? 1 : 0);
     // ---- prologue: tiles 0..2 in flight, tile 0 landed, F0 of tile 0 on its way
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -390,6 +393,24 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         }
         return;
     }
+    if (ksl > 1) {   // raw tile sums of this k slice; launch_splitk_reduce adds the slices in order and applies the epilogue
+        float* P = g.kpart + (long)kz * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int n = n0 + wn * 64 + j * 32 + 8 * qq + 4 * h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < g.N) P[(long)m * g.N + n + e] = accM[i][j][qq * 4 + e] + accC[i][j][qq * 4 + e] * kGLoInv;
+                }
+        }
+        return;
+    }
     float* C = g.C;
     const float* Rp = g.R;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
@@ -464,7 +485,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     const int wm = force_wm ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
     const int tbm = wm * 64;
     const int stages = wm == 4 ? 3 : 2;
-    dim3 grid(cdiv(g.N, GBN), cdiv(g.M, tbm), 1);
+    BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
+               "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
+    dim3 grid(cdiv(g.N, GBN), cdiv(g.M, tbm), g.ksplit);
     const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -496,6 +519,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     }
 #undef BG_LAUNCH
     LAUNCH_CHECK();
+    if (g.ksplit > 1) launch_splitk_reduce(g, g.kpart, g.ksplit, stream);
 }
 
 }  // namespace bevgen

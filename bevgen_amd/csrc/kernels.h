@@ -56,6 +56,10 @@ struct GemmArgs {
     const void* epi_aux = nullptr;
     int epi_ld = 0;
     float epi_post = 1.f;             // EPI_MUSE_Q: extra factor on the prepared query (the attention kernel's score scale, folded in here)
+    // LDS-DMA path, small-M problems (low-latency B = 1 scenes): the k range is cut into `ksplit` slices on gridDim.z, every slice leaves its raw fp32 tile sums in
+    // kpart [ksplit][M][N] and splitk_reduce adds them in slice order (deterministic) before alpha / bias / activation / residual.  Plain epilogue only.
+    int ksplit = 1;
+    float* kpart = nullptr;
     int a_bytes = 0;                  // MODE_CONV3: size of the activation plane image (buffer-resource bound), filled in by the launcher
     int tile_band = 0;                // tile-order band height (0 = row-major); filled in by the launcher
 };
@@ -106,6 +110,7 @@ struct AttnArgs {
     int kv_group = 1;             // consecutive groups of kv_group batches read the K / V of batch b / kv_group (samples of one BEV layout share the condition's cross-attention K / V)
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
+void launch_splitk_reduce(const GemmArgs& g, const float* partial, int ksplit, hipStream_t s);   // gemm_skinny.hip: C = act(alpha * sum_k partial[k] + bias) + R
 
 // Split-precision flash attention (attention_split.hip): operands pre-split into (hi, lo) f16 planes by the preparation kernels.
 //   The softmax is evaluated in the base-2 domain: `bias` must arrive PRE-MULTIPLIED by log2(e) (kLog2e below) and the score scale (x log2 e) must

@@ -23,7 +23,21 @@ struct MuseWs {
     float *img = nullptr, *c_embed = nullptr, *context = nullptr;
     std::vector<float*> crossK, crossV;
     float *x = nullptr, *xn = nullptr, *qraw = nullptr, *kvraw = nullptr, *Q = nullptr, *Ks = nullptr, *Vs = nullptr, *att = nullptr, *h = nullptr, *g = nullptr;
+    float* kpart = nullptr;   // split-K partial tiles of the narrow (N = D) projections when the batch is too small to fill the chip (low-latency path)
 };
+
+// Low-latency path (one or two scenes per call, scripts/interactive_editing.py:273-277): a [rows, D] x [D, D] projection is only cdiv(rows, 128) * D / 128 tiles -
+// 96 workgroups at one six-view scene, on 256 CUs.  Its k range is cut into slices until the grid covers the chip; the slices' partial tiles are added in a fixed
+// order (tokens stay identical run to run, and identical to the unsplit path up to fp32 summation order - checked against the B = 16 path in the tests).
+constexpr int KSPLIT_MAX = 4;
+int pick_ksplit(long rows, int N, int K) {
+    if ((long)cdiv(rows, 256) * cdiv(N, 128) >= 256) return 1;          // the 256-row tiling already fills the chip
+    const long tiles = (long)cdiv(rows, 128) * cdiv(N, 128);
+    if (tiles >= 160) return 1;
+    int s = (int)std::min<long>(KSPLIT_MAX, (256 + tiles - 1) / tiles);
+    while (s > 1 && K / 32 < 2 * s) --s;
+    return s;
+}
 
 size_t muse_ws_bytes(const Ctx& c, int B) {
     const size_t rows = (size_t)B * c.N;
@@ -38,6 +52,7 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
     f += (size_t)2 * B * c.H * c.NkS_pad * 64;
     f += rows * 2 * c.F + rows * c.Fpad;
     f += rows * (c.V + 1);               // logits, scores (generate)
+    if (pick_ksplit((long)rows, c.D, c.D) > 1) f += (size_t)KSPLIT_MAX * rows * c.D;   // split-K partial tiles (small batches only)
     return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256;
 }
 
@@ -50,17 +65,25 @@ void gemm(const float* A, int lda, const float* W, int ldb, float* C, int ldc, i
 }
 
 // same with A given as interleaved (hi, lo) f16 planes [M][lda/32][2][32] (split-precision mode: the producer kernel wrote them)
-void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s) {
+void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s, float* kpart = nullptr) {
     GemmArgs g;
     g.A_hi = reinterpret_cast<const uint16_t*>(Aplanes); g.A_lo = g.A_hi + 32;
     g.B = W; g.C = C; g.R = R;
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    if (kpart && N <= 1024) { g.ksplit = pick_ksplit(M, N, K); g.kpart = kpart; }   // the workspace holds KSPLIT_MAX slices of [rows, D]
     launch_gemm(g, s);
 }
 
 // to_q projection with the query preparation (l2norm, q_scale, hi/lo split, head-major layout) fused into the GEMM epilogue
-void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, int D, hipStream_t s) {
+void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, int D, hipStream_t s, float* kpart = nullptr,
+                   float* qraw = nullptr) {
+    if (kpart && qraw && H * 64 <= 1024 && pick_ksplit((long)B * Nq, H * 64, D) > 1) {
+        // small batch: the projection split over K into qraw, then the query preparation as its own (tiny) kernel
+        gemm_planes(Aplanes, lda, W, D, qraw, H * 64, B * Nq, H * 64, D, nullptr, 0, s, kpart);
+        launch_muse_q_prep_split(qraw, q_scale, Qh, Ql, B, H, Nq, 8.0f * kLog2e, s);
+        return;
+    }
     GemmArgs g;
     g.A_hi = reinterpret_cast<const uint16_t*>(Aplanes); g.A_lo = g.A_hi + 32;
     g.B = W;
@@ -99,6 +122,7 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.Vs = a.get<float>(kvS);
     w.h = a.get<float>((size_t)w.rows * 2 * c.F);
     w.g = a.get<float>((size_t)w.rows * c.Fpad);
+    w.kpart = pick_ksplit(w.rows, D, D) > 1 ? a.get<float>((size_t)KSPLIT_MAX * w.rows * D) : nullptr;
     HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
     HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
 
@@ -155,7 +179,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         const bool split = g.precision == BEVGEN_PRECISION_F16X3;
         if (split) {
             launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s);
+            gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw);
             {   // to_kv with the key / value preparation in its epilogue: k planes [B, H, NkS_pad, 64], v planes transposed [B, H, 64, NkS_pad]
                 const size_t kvS_ = (size_t)B * H * c.NkS_pad * 64;
                 _Float16 *Kp = reinterpret_cast<_Float16*>(w.Ks), *Vp = reinterpret_cast<_Float16*>(w.Vs);
@@ -194,12 +218,12 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         a.ldbias = c.ldS; a.bias_head_stride = 0; a.scale = 8.0f;
         a.o_bstride = (long)N * D; a.o_qstride = D; a.o_hstride = 64;
         if (!split) launch_attention(a, s);
-        if (split) gemm_planes(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);
+        if (split) gemm_planes(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s, w.kpart);
         else gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);  // x = to_out(att) + x
         // ---- cross attention
         if (split) {
             launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            gemm_planes_q(w.xn, D, l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s);
+            gemm_planes_q(w.xn, D, l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw);
         } else {
             launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
             gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
@@ -220,7 +244,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         }
         // ---- feed forward
         if (split) {
-            gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
+            gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s, w.kpart);
             launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
             if (l.ff_w1_geglu) {
                 // GEGLU in the up-projection's epilogue: h = gate * gelu(x) as [rows, Fpad] (pad columns exactly 0), then the LayerNorm half on its own
@@ -236,7 +260,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
                 gemm_planes(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
                 launch_geglu_layernorm_planes(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
             }
-            gemm_planes(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s);
+            gemm_planes(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s, w.kpart);
         } else {
             gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
             launch_layernorm(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);

@@ -395,3 +395,24 @@ def test_profiler_state_is_per_context(gpu_ctx):
     assert pa["gemm"]["launches"] == 2 and po["gemm"]["launches"] == 1, (pa["gemm"], po["gemm"])
     assert pa["gemm"]["ms"] > 0 and po["gemm"]["ms"] > 0
     other.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(1536, 1024, 1024), (768, 1024, 2752), (200, 136, 352)])
+def test_gemm_split_precision_split_k(gpu_ctx, M, N, K):
+    """Low-latency path of small batches: the LDS-DMA GEMM with its k range cut into three slices on gridDim.z (partial tiles added in slice order by splitk_reduce,
+    then bias / GELU / residual) - same accuracy class as the unsplit kernel, and bit-identical run to run."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 3.0
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
+    from bevgen_amd.runtime import _ptr, _stream
+    da, dw, db, dr = dev(a), dev(w), dev(b), dev(r)
+    outs = []
+    for _ in range(2):
+        out = torch.empty(M, N, device="cuda")
+        gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), _ptr(db), _ptr(dr), _ptr(out), M, N, K, 1, 5, _stream()))
+        outs.append(out.cpu())
+    assert rel(outs[0].double(), ref) < 2e-6
+    assert torch.equal(outs[0], outs[1])
