@@ -29,12 +29,18 @@ struct MuseWs {
 // Low-latency path (one or two scenes per call, scripts/interactive_editing.py:273-277): a [rows, D] x [D, D] projection is only cdiv(rows, 128) * D / 128 tiles -
 // 96 workgroups at one six-view scene, on 256 CUs.  Its k range is cut into slices until the grid covers the chip; the slices' partial tiles are added in a fixed
 // order (tokens stay identical run to run, and identical to the unsplit path up to fp32 summation order - checked against the B = 16 path in the tests).
-constexpr int KSPLIT_MAX = 4;
+// How many slices: measured at one six-view scene (rows = 1536, profiles/r03_b1_*): a [1536, 1024] x [1024, 1024] projection costs 12 us of fixed time (dispatch,
+// pipeline fill from cold operands, store tail) + 0.62 us per k-tile; every extra slice shortens the loop but adds its share of a 7 us reduce launch, so two
+// slices are the optimum (step 257 -> 241 ms; 3..5 slices 253-256, 6 slices 287) - the small-batch step is bound by the fixed cost of its ~280 dependent
+// kernels per forward, not by occupancy.
+constexpr int KSPLIT_MAX = 6;
+int ksplit_env() { static const int v = getenv("BEVGEN_KSPLIT") ? atoi(getenv("BEVGEN_KSPLIT")) : 0; return v; }
 int pick_ksplit(long rows, int N, int K) {
     if ((long)cdiv(rows, 256) * cdiv(N, 128) >= 256) return 1;          // the 256-row tiling already fills the chip
     const long tiles = (long)cdiv(rows, 128) * cdiv(N, 128);
     if (tiles >= 160) return 1;
-    int s = (int)std::min<long>(KSPLIT_MAX, (256 + tiles - 1) / tiles);
+    int s = 2;
+    if (ksplit_env() > 0) s = std::min(KSPLIT_MAX, ksplit_env());
     while (s > 1 && K / 32 < 2 * s) --s;
     return s;
 }
