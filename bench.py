@@ -285,17 +285,39 @@ def route_a_bytes(cfg, B, steps, kv_bytes, G=1, w_bytes_per=4):
     return kv, w
 
 
-def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic=False, weights="f32"):
+def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic=False, weights="f32", density=1.0, path="fused"):
     """Route A (BASELINE config 4: nuScenes 6-view 224x400, 24 layers, L=2368, blk 16, camera bias): decode of `steps` tokens for `batch` sequences through
-    the product path (hipGraph replay of the fused decode step).  S > 1 = BASELINE config 5: groups of S samples share their BEV layout."""
+    the product path (hipGraph replay of the fused decode step).  S > 1 = BASELINE config 5: groups of S samples share their BEV layout.
+    density < 1 = SURVEY 8(d) config 4 variant: every attention layer gets its own random per-head block layouts (drawn like the reference does at construction,
+    gpt:176, maskgen:217-228) - absent blocks are never read.  path = 'split': LayerNorm + QKV projection kernel, then the attention-only kernel."""
     import torch
-    from bevgen_amd import presets, synthetic
+    from bevgen_amd import presets, synthetic, tables
     from bevgen_amd.runtime import Context
     from bevgen_amd.weights import gpt_state_dict
 
-    cfg = presets.config4()
-    ctx = Context(cfg, route="ar", device=device, max_batch=batch, kv_cache=kv_cache, decode_weights=weights)
-    ctx.load_state_dict(cached(("gpt", "config4"), lambda: gpt_state_dict(cfg, 1234)))
+    cfg = presets.config4(density=density) if density < 1.0 else presets.config4()
+    ctx = Context(cfg, route="ar", device=device, max_batch=batch, kv_cache=kv_cache, decode_weights=weights, decode_path=path)
+    sd = dict(cached(("gpt", "config4"), lambda: gpt_state_dict(presets.config4(), 1234)))
+    visible_frac = 1.0
+    if density < 1.0:
+        torch.manual_seed(4242)
+        pat = tables.attention_patterns(cfg)
+        lays = [tables.head_layouts(cfg, pat) for _ in range(cfg.num_layers)]
+        for i, lay in enumerate(lays):
+            sd[f"blocks.{i}.attention.sparse_self_attention.master_layout"] = lay.to(torch.int64)
+        # fraction of the causal (row, key) pairs of the decode rows that sit in a present block, averaged over layers and heads: the algorithmic K/V bytes scale with it
+        blk, K, N = cfg.sparse_block_size, cfg.num_cond_tokens, cfg.num_img_tokens
+        allowed = cfg.attention_mask != 0
+        tot = vis = 0.0
+        for lay in lays[:4]:
+            for h in range(0, cfg.num_heads, 4):
+                full = lay[h].bool().repeat_interleave(blk, 0).repeat_interleave(blk, 1) & allowed
+                rows = slice(K, K + (steps or N))
+                causal = torch.tril(torch.ones_like(allowed))
+                tot += float((causal[rows] & allowed[rows]).sum())
+                vis += float((causal[rows] & full[rows]).sum())
+        visible_frac = vis / tot
+    ctx.load_state_dict(sd)
     ctx.set_tables()
     ctx.finalize()
     bt = synthetic.make_batch(cfg, batch // S, seed=0)
@@ -337,11 +359,13 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     kvb = 4 if kv_cache == "f32" else 2
     phase_us = float((tr[:, 4] - tr[:, 3]).mean()) if tr.numel() else None
     K = cfg.num_cond_tokens
-    phase_bytes = 2.0 * cfg.num_heads * 64 * kvb * (batch * (n_last - (K if S > 1 else 0)) + (batch // S) * (K if S > 1 else 0))
+    phase_bytes = visible_frac * 2.0 * cfg.num_heads * 64 * kvb * (batch * (n_last - (K if S > 1 else 0)) + (batch // S) * (K if S > 1 else 0))
     ctx.close()
     da, gs = prof["decode_attention"], prof["gemm_skinny"]
     ach = da["work"] / (da["ms"] * 1e-3) / 1e9 if da["ms"] > 0 else 0.0
     kv_bytes, w_bytes = route_a_bytes(cfg, batch, steps, kvb, S, 2 if weights == "f16" else 4)
+    kv_bytes *= visible_frac     # block-sparse layouts: only the rows of present blocks are algorithmic traffic
+    ach *= visible_frac
     step_ach = (kv_bytes + w_bytes) / wall / 1e9
     out = {
         "ms_per_decode_step": wall * 1e3 / steps, "ms_per_decode_step_median": pct(st, 50), "ms_per_decode_step_p99": pct(st, 99), "decode_prefill_ms": prefill_ms,
@@ -357,7 +381,10 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
                                  "bytes_per_step": {"kv": kv_bytes / steps, "weights": w_bytes / steps}, "note": f"(K/V rows of the context + every {weights} weight matrix once) per step / wall time per step"},
         "decode_sequences_per_s": batch / wall, "decode_scenes_per_s": batch / wall,
         "decode_weight_stream": {"achieved_GBs": gs["work"] / (gs["ms"] * 1e-3) / 1e9 if gs["ms"] > 0 else 0.0, "launches": int(gs["launches"])},
+        "visible_fraction_of_causal_keys": visible_frac, "decode_path": path,
     }
+    if path == "split":
+        out["roofline_decode_attention"]["kernel"] = "ar_attn_kernel (decode_path = split: the attention-only kernel; q/k/v come from the LayerNorm + QKV projection kernel)"
     return out
 
 
@@ -531,6 +558,15 @@ def main():
         # ... and the all-fp16-storage model (projection weights rounded to fp16 at load, tokens bit-exact vs the oracle on the rounded weights; fp32 arithmetic)
         h16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16")
         line["decode_f16_kv_cache_f16_weights"] = {k: h16[k] for k in ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline")}
+        keys = ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline", "visible_fraction_of_causal_keys")
+        if not args.no_extra_legs:
+            # SURVEY 8(d) config 4 variant: density 0.35, every layer with its own random per-head block layouts - the key walk follows the chunk lists of present blocks
+            d35 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", density=0.35)
+            line["decode_density_035_f16_kv_cache"] = {k: d35[k] for k in keys}
+            # the four-launch form: the decode-attention kernel proper (K/V stream only) with the projection as its own MFMA kernel - slower per step than the fused
+            # form (a 14.6 us projection kernel + an 8.9 us attention kernel vs 19.0 us fused at context ~556), reported for its attention-kernel roofline
+            sp = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16", path="split")
+            line["decode_split_path_f16_kv_cache_f16_weights"] = {k: sp[k] for k in keys}
         if not args.no_extra_legs:
             c5 = decode_leg(local_rank, 64, args.decode_steps, kv_cache="f32", S=4, top_k=32, stochastic=True)
             line["config5_topk32_4_samples_per_layout"] = {"sequences": 64, "layouts": 16, "ms_per_decode_step": c5["ms_per_decode_step"], "ms_per_decode_step_median": c5["ms_per_decode_step_median"],
