@@ -283,7 +283,7 @@ void ar_logits(Ctx& c, float* logits, hipStream_t s) {
 // exchange between phases costs 7.9 us on this 8-XCD part, profiles/r03_xchg_probe.txt - more than a kernel boundary.)
 static int decode_chains(const Ctx& c, int B, int G) {
     int n = c.cfg.decode_chains;
-    if (n <= 0) n = (B / G) >= 8 ? 2 : 1;   // two chains of >= 4 layout groups each; smaller batches keep one
+    if (n <= 0) n = 1;   // measured (profiles/r03_chain_probe.txt, B = 16): 1 chain 1.41 ms/step, 2 chains 1.60, 4 chains 1.96 - the option stays for experiments
     n = std::min(n, 4);
     while (n > 1 && ((B / G) % n != 0 || (B / G) / n < 1)) --n;
     if (c.trace) n = 1;   // the phase-timestamp buffers are indexed by workgroup of ONE launch per kind

@@ -45,7 +45,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // W16: the B operand (a weight matrix) is f16-representable, its low plane is zero: the product is  b_hi a_hi + 2^-11 b_hi a_lo  - TWO MFMAs per
 // k-step pair instead of three, and no low-plane fragment reads (weight_dtype = f16 contexts)
-template <int MODE, int WM, int S, bool W16 = false>
+// KS: the k range is cut into gridDim.z slices (small-M problems; a template flag so that the throughput instantiations carry none of it - the 256-row convolution
+// variant sits at the register limit and spilled 300 VGPRs with the slice arithmetic compiled in)
+template <int MODE, int WM, int S, bool W16 = false, bool KS = false>
 __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
     constexpr int TBM = WM * 64;                 // block rows
     constexpr int NW = WM * 2;                   // waves
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         }
     }
     // split-K (gridDim.z slices, small-M problems): this block owns k-tiles [kt_first, kt_first + nk)
-    const int nk_all = g.K / GBK, ksl = (int)gridDim.z, kz = (int)blockIdx.z;
+    const int nk_all = g.K / GBK, ksl = KS ? (int)gridDim.z : 1, kz = KS ? (int)blockIdx.z : 0;
     const int kt_first = kz * (nk_all / ksl) + min(kz, nk_all % ksl);
     // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order)
     int k_issue = kt_first * GBK;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         }
         return;
     }
-    if (ksl > 1) {   // raw tile sums of this k slice; launch_splitk_reduce adds the slices in order and applies the epilogue
+    if (KS && ksl > 1) {   // raw tile sums of this k slice; launch_splitk_reduce adds the slices in order and applies the epilogue
         float* P = g.kpart + (long)kz * g.M * g.N;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -500,6 +502,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), 2 * 256 * 2 * GBK * 2);
 #undef BG_SET
         attr_set = true;
     }
@@ -510,7 +514,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, true>), grid, dim3(THREADS), lds, stream, g);    \
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, false>), grid, dim3(THREADS), lds, stream, g);               \
     } while (0)
-    if (wm == 2) {
+    if (g.ksplit > 1) {
+        if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), grid, dim3(256), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), grid, dim3(256), lds, stream, g);
+    } else if (wm == 2) {
         if (conv) BG_LAUNCH(MODE_CONV3, 2, 2, 256);
         else BG_LAUNCH(MODE_PLAIN, 2, 2, 256);
     } else {

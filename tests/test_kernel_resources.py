@@ -1,0 +1,52 @@
+"""Register budget of the hot kernels (cross-compiled for gfx950, no GPU needed).  The throughput kernels sit at the 256-VGPR limit of two waves per SIMD: a
+harmless-looking edit (round 3: slice arithmetic for a split-K variant) made the 256-row convolution kernel spill 300 VGPRs and cost 12 % of the headline step before
+anything failed.  This test pins the spill counts the round's measurements were taken with."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bevgen_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# mangled-name fragment -> maximum VGPR spill count
+LIMITS = {
+    "gemm_split_glds.hip": {"gemm_split_glds_kernelILi0ELi4ELi3ELb0ELb0E": 0, "gemm_split_glds_kernelILi1ELi4ELi3ELb0ELb0E": 16, "gemm_split_glds_kernelILi0ELi2ELi2ELb0ELb1E": 0,
+                            "gemm_split_glds_kernelILi0ELi4ELi3ELb1ELb0E": 0},
+    # (the fused attention kernels hold a q/k/v weight batch + the step's bias / visibility / chunk-list loads across the LayerNorm: a dozen registers are parked in
+    # scratch once, outside the key walk; the attention-only kernel and the projection kernels must not spill at all)
+    "decode_fused.hip": {"ar_attn_fused_kernelILi0ELi1ELi0E": 16, "ar_attn_fused_kernelILi1ELi1ELi1E": 0, "ar_attn_kernelILi1ELi1E": 0, "ar_attn_kernelILi0ELi1E": 0,
+                         "skinny_fused_kernelILb1ELi0ELb0E": 0,
+                         "skinny_fused_kernelILb1ELi0ELb1E": 0, "skinny_fused_kernelILb0ELi0ELb0E": 0},
+    "attention_split.hip": {"attention_split_kernelILb0E": 0},
+}
+
+
+def _usage(src):
+    r = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+                       cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        m = re.search(r"(VGPRs Spill|VGPRs|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name:
+            out[name][m.group(1)] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hot_kernels_do_not_spill():
+    with ThreadPoolExecutor(3) as ex:
+        results = dict(zip(LIMITS, ex.map(_usage, LIMITS)))
+    for src, limits in LIMITS.items():
+        for frag, max_spill in limits.items():
+            hits = {k: v for k, v in results[src].items() if frag in k}
+            assert hits, f"{src}: no kernel matching {frag} (renamed? update tests/test_kernel_resources.py)"
+            for k, v in hits.items():
+                assert v.get("VGPRs Spill", 0) <= max_spill, f"{k}: {v.get('VGPRs Spill')} VGPRs spilled (limit {max_spill}): {v}"
