@@ -314,6 +314,20 @@ static void finalize_ar(Ctx& c) {
         for (int h = 0; h < c.H && !skippable; ++h)
             for (int r = 0; r < nb && !skippable; ++r)
                 for (int j = 0; j <= r && !skippable; ++j) skippable = hl[i][((size_t)h * nb + r) * nb + j] == 0;
+    // does any layout hide an element the mask allows?  (density 1.0: no - the layout is the block cover of the mask - and the kernels then skip the layout row)
+    bool lay_hides = false;
+    {
+        std::vector<float> hm((size_t)c.L * c.L);
+        HIP_CHECK(hipMemcpy(hm.data(), c.pf("table.attention_mask"), hm.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> any((size_t)nb * nb, 0);   // block (rb, cb) holds an allowed element
+        for (int r = 0; r < c.L; ++r)
+            for (int k = 0; k < c.L; ++k)
+                if (hm[(size_t)r * c.L + k] != 0.f) any[(size_t)(r / blk) * nb + k / blk] = 1;
+        for (int i = 0; i < g.num_layers && !lay_hides; ++i)
+            for (int h = 0; h < c.H && !lay_hides; ++h)
+                for (size_t b = 0; b < (size_t)nb * nb && !lay_hides; ++b) lay_hides = any[b] && hl[i][(size_t)h * nb * nb + b] == 0;
+    }
+    c.lay_hides = lay_hides;
     c.allowed = reinterpret_cast<uint8_t*>(c.own((size_t)c.L * c.L));
     launch_build_allowed(c.pf("table.attention_mask"), c.allowed, (long)c.L * c.L, 0);
     const size_t lay_plane = (size_t)c.keep_heads * nb * nb;

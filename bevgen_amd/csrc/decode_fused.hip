@@ -110,20 +110,22 @@ struct Attend {
     static constexpr int KPI = 64 / LPK, KPS = U * KPI, SPC = 16 / KPS;
     static_assert(KPS <= 16 && 16 % KPS == 0, "a pipeline step must tile a 16-key chunk");
 
+    template <int USTRIDE>
     __device__ static __forceinline__ void load(Buf& b, const void* kc, const void* vc, long row0, int key0, int k_end, int sub) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int kcl = min(key0 + u * KPI, k_end - 1);   // clamped address, masked in compute()
+            const int kcl = min(key0 + u * USTRIDE, k_end - 1);   // clamped address, masked in compute()
             b.k[u] = T::load(kc, row0 + kcl, sub);
             b.v[u] = T::load(vc, row0 + kcl, sub);
         }
     }
+    template <int USTRIDE>
     __device__ static __forceinline__ void compute(const Buf& b, int key0, int k_end, const float* bias_s, const float (&q)[NQ][DPL], float (&m)[NQ],
                                                    float (&l)[NQ], float (&acc)[NQ][DPL]) {
         float sc[NQ][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int key = key0 + u * KPI;
+            const int key = key0 + u * USTRIDE;
             const float bv = key < k_end ? bias_s[min(key, k_end - 1)] : kNegBig;
 #pragma unroll
             for (int qi = 0; qi < NQ; ++qi) {
@@ -153,26 +155,38 @@ struct Attend {
             m[qi] = mx;
         }
     }
-    // The walk covers list positions [lo, hi): position p stands for chunk list_s[p] (block-sparse layouts: only chunks with a present block are listed)
-    // or for chunk p itself (list_s == null).  Wave `slot` of a team of `nslots` takes positions lo + slot, lo + slot + nslots, ...; step j of its walk
-    // reads keys 16 c + (j % SPC) KPS + u KPI + kslot.  Two register buffers: the loads of step j + 1 are in flight while step j is scored.
-    __device__ static __forceinline__ int key_of(const uint16_t* list_s, int lo, int slot, int nslots, int j, int kslot) {
-        const int p = lo + slot + (j / SPC) * nslots;
-        const int c = list_s ? (int)list_s[p] : p;
-        return 16 * c + (j % SPC) * KPS + kslot;
-    }
-    __device__ static __forceinline__ void run(const void* kc, const void* vc, long row0, const uint16_t* list_s, int lo, int hi, int slot, int nslots, int kslot, int k_end,
-                                               int sub, const float* bias_s, const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL]) {
-        const int mine = hi - lo - slot;
-        const int steps = mine > 0 ? ((mine + nslots - 1) / nslots) * SPC : 0;   // wave-uniform
+    // The walk covers list positions [lo, hi).  With a chunk list (block-sparse layouts: only chunks that hold a present block are listed) position p stands for
+    // chunk list_s[p]: wave `slot` of a team of `nslots` takes positions lo + slot, lo + slot + nslots, ...; step j of its walk reads keys
+    // 16 c + (j % SPC) KPS + u KPI + kslot - KPI consecutive keys = 1 KiB per load.  Without a list (every block at or below the diagonal present) the range
+    // [16 lo, min(16 hi, k_end)) is walked in the interleaved order the dense kernel always used: at step j, load u of wave `slot` covers keys
+    // 16 lo + (j U + u) nslots KPI + slot KPI + kslot, so that the team's waves read ONE contiguous nslots KiB per load instruction (measured: the per-wave chunk
+    // order costs 5 % of the K/V rate at density 1).  Two register buffers: the loads of step j + 1 are in flight while step j is scored.
+    // (LIST and the team size are compile-time: every stride of the walk is then a constant, as in the dense kernel of round 2 - with run-time strides the
+    // address arithmetic of the eight loads per step cost 1.8 us of the 27 us K/V phase)
+    template <bool LIST, int NSLOTS>
+    __device__ static __forceinline__ void run_as(const void* kc, const void* vc, long row0, const uint16_t* list_s, int lo, int hi, int slot, int kslot, int k_end,
+                                                  int sub, const float* bias_s, const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL]) {
+        constexpr int USTRIDE = LIST ? KPI : NSLOTS * KPI, SPAN = U * NSLOTS * KPI;
+        int steps;
+        if (LIST) {
+            const int mine = hi - lo - slot;
+            steps = mine > 0 ? ((mine + NSLOTS - 1) / NSLOTS) * SPC : 0;   // wave-uniform
+        } else {
+            const int len = min(16 * hi, k_end) - 16 * lo;
+            steps = len > 0 ? (len + SPAN - 1) / SPAN : 0;
+        }
         if (steps == 0) return;
+        auto key_of = [&](int j) {
+            if (LIST) return 16 * (int)list_s[lo + slot + (j / SPC) * NSLOTS] + (j % SPC) * KPS + kslot;
+            return 16 * lo + j * SPAN + slot * KPI + kslot;
+        };
         Buf b0, b1;
-        load(b0, kc, vc, row0, key_of(list_s, lo, slot, nslots, 0, kslot), k_end, sub);
+        load<USTRIDE>(b0, kc, vc, row0, key_of(0), k_end, sub);
         for (int j = 0; j < steps; j += 2) {
-            if (j + 1 < steps) load(b1, kc, vc, row0, key_of(list_s, lo, slot, nslots, j + 1, kslot), k_end, sub);
-            compute(b0, key_of(list_s, lo, slot, nslots, j, kslot), k_end, bias_s, q, m, l, acc);
-            if (j + 2 < steps) load(b0, kc, vc, row0, key_of(list_s, lo, slot, nslots, j + 2, kslot), k_end, sub);
-            if (j + 1 < steps) compute(b1, key_of(list_s, lo, slot, nslots, j + 1, kslot), k_end, bias_s, q, m, l, acc);
+            if (j + 1 < steps) load<USTRIDE>(b1, kc, vc, row0, key_of(j + 1), k_end, sub);
+            compute<USTRIDE>(b0, key_of(j), k_end, bias_s, q, m, l, acc);
+            if (j + 2 < steps) load<USTRIDE>(b0, kc, vc, row0, key_of(j + 2), k_end, sub);
+            if (j + 1 < steps) compute<USTRIDE>(b1, key_of(j + 1), k_end, bias_s, q, m, l, acc);
         }
     }
 };
@@ -200,7 +214,7 @@ __device__ __forceinline__ void wave_merge(float& m, float& l, float (&acc)[DPL]
 
 // Second half of both attention kernels: this step's k / v rows (qkv_s, LDS) go into the cache, the walk over the visible 16-key chunks, the merge of the
 // 16 waves, + residual (res_s[g * ldres + d], LDS) -> out.  Called by every thread of the workgroup after a barrier that made qkv_s / bias_s / the list visible.
-template <int DT, int G>
+template <int DT, int G, bool SP>   // SP: the walk follows a chunk list (block-sparse layout); false = the dense interleaved walk with every stride a constant
 __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a, const float* bias_s, const float* qkv_s, float* red, const uint16_t* walk, int n_pos, int p_pos,
                                                        int n, int head, int b0, const float* res_s, int ldres) {
     using T = KvRow<DT>;
@@ -230,7 +244,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
 #pragma unroll
         for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[sub * DPL + i] * sl2; acc[0][i] = 0.f; }
         const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-        Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, 0, n_pos, wave, NW, kslot, n, sub, bias_s, q, m, l, acc);
+        Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, 0, n_pos, wave, kslot, n, sub, bias_s, q, m, l, acc);
         wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
         if (kslot == 0) {
             if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
@@ -248,7 +262,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
                 for (int i = 0; i < DPL; ++i) { q[g][i] = qkv_s[g * 192 + sub * DPL + i] * sl2; acc[g][i] = 0.f; }
             }
             const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-            Attend<DT, G, UP>::run(a.kcache, a.vcache, row0, walk, 0, p_pos, wave, NW, kslot, min(a.prefix, n), sub, bias_s, q, m, l, acc);
+            Attend<DT, G, UP>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, 0, p_pos, wave, kslot, min(a.prefix, n), sub, bias_s, q, m, l, acc);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 wave_merge<LPK, DPL>(m[g], l[g], acc[g]);
@@ -266,7 +280,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
 #pragma unroll
             for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[g_own * 192 + sub * DPL + i] * sl2; acc[0][i] = 0.f; }
             const long row0 = ((long)(b0 + g_own) * a.H + head) * a.Lmax;
-            Attend<DT, 1, U>::run(a.kcache, a.vcache, row0, walk, p_pos, n_pos, wt, TW, kslot, n, sub, bias_s, q, m, l, acc);
+            Attend<DT, 1, U>::template run_as<SP, TW>(a.kcache, a.vcache, row0, walk, p_pos, n_pos, wt, kslot, n, sub, bias_s, q, m, l, acc);
             wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
             if (kslot == 0) {
                 if (sub == 0) { my_red[G * 66] = m[0]; my_red[G * 66 + 1] = l[0]; }
@@ -312,7 +326,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
 
 // ----------------------------------------------------------------------------------------------------------------- ln1 + qkv + attention
 // grid (H, B / G), 1024 threads.  Dynamic LDS: bias row [Lpad] | xn [G][D] | qkv [G][192] | red [16][G+1][66] | stat [16][G] | chunk list [Lpad/16 + 2] (uint16)
-template <int DT, int G, int WT>   // KV-cache storage (0 fp32, 1 fp16), sequences per workgroup, decode-weight storage (0 fp32, 1 fp16)
+template <int DT, int G, int WT, bool SP>   // KV-cache storage (0 fp32, 1 fp16), sequences per workgroup, decode-weight storage (0 fp32, 1 fp16), block-sparse layout
 __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) {
     using T = KvRow<DT>;
     constexpr int NW = AF_WAVES;
@@ -372,18 +386,16 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     const uint8_t* lay_row = vis.lay + (long)head * vis.lay_head_stride + (long)(row / vis.blk) * vis.nb;
     const float* bias_row = a.bias + (long)row * a.ldbias;
     float braw[BR];
-    uint8_t kraw[BR], lraw[BR];
+    uint8_t kraw[BR];
 #pragma unroll
     for (int j = 0; j < BR; ++j) {   // raw values, clamped addresses: nothing below touches them before the statistics are done (a use would wait for the loads)
         const int k = min(tid + 1024 * j, n - 1);
         braw[j] = bias_row[k];
         kraw[j] = keep_row[k];
-        lraw[j] = lay_row[k / vis.blk];
     }
-    // key-chunk list of this (head, block row): count, then the ascending ids of the 16-key chunks that hold a present block (<= Lpad / 16 <= 1024 entries)
+    // (the block-layout row and the key-chunk list are only fetched when the layout actually hides something - density < 1 - and only after the projection:
+    // held across it they push the fp32 variants over the 128-register budget of a 16-wave workgroup)
     const uint16_t* chunk_row = vis.chunks + (long)head * vis.chunks_head_stride + (long)(row / vis.blk) * vis.chunks_ld;
-    const int chunk_total = chunk_row[0];
-    const int chunk_id = chunk_row[min(1 + tid, max(vis.chunks_ld - 1, 0))];
 
     // ---- ln1, thread = column
     {
@@ -433,17 +445,11 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
         for (int j = 0; j < BR; ++j)
             if (tid + 1024 * j < n)
-                bias_s[tid + 1024 * j] = ((kraw[j] || !vis.has_allowed) && (lraw[j] || !vis.has_lay)) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
+                bias_s[tid + 1024 * j] = (kraw[j] || !vis.has_allowed) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
         for (int k = tid + 1024 * BR; k < n; k += 1024)   // sequences longer than 3072: the remainder the plain way
-            bias_s[k] = ((keep_row[k] || !vis.has_allowed) && (lay_row[k / vis.blk] || !vis.has_lay)) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
-        if (vis.has_chunks && tid < chunk_total) list_s[tid] = (uint16_t)chunk_id;
+            bias_s[k] = (keep_row[k] || !vis.has_allowed) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
         __syncthreads();
     }
-    // the walk: list positions [0, n_pos) hold chunks that start below n (the list is ascending); without a list position = chunk
-    const uint16_t* walk = vis.has_chunks ? list_s : nullptr;
-    const int n_pos = vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < n) : (n + 15) >> 4;
-    // shared prefix (G > 1): positions [0, p_pos) are the chunks of the K condition keys (prefix is a multiple of 16: launcher)
-    const int p_pos = G == 1 ? 0 : (vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n)) : min((min(a.prefix, n) + 15) >> 4, n_pos));
 
     AF_TRACE(1);
     // ---- q/k/v projection of this head
@@ -490,8 +496,24 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     }
     __syncthreads();
     AF_TRACE(2);
-
-    af_append_attend_store<DT, G>(a, bias_s, qkv_s, red, walk, n_pos, p_pos, n, head, b0, xn_s + head * 64, D);
+    // block layout (kernel-uniform branches): keys of absent blocks are hidden, and the walk follows the list of chunks that hold a present block.  List positions
+    // [0, n_pos) are the chunks that start below n (ascending list); without a list position = chunk
+    int n_pos, p_pos;
+    if (SP) {   // (the dense instantiation carries none of this: the launcher picks SP only when a layout hides something)
+        if (vis.has_lay)
+            for (int k = tid; k < n; k += 1024)
+                if (!lay_row[k / vis.blk]) bias_s[k] = kNegBig;
+        const int chunk_total = chunk_row[0];
+        const int chunk_id = chunk_row[min(1 + tid, vis.chunks_ld - 1)];
+        if (tid < chunk_total) list_s[tid] = (uint16_t)chunk_id;
+        n_pos = __syncthreads_count(tid < chunk_total && chunk_id * 16 < n);
+        // shared prefix (G > 1): positions [0, p_pos) are the chunks of the K condition keys (prefix is a multiple of 16: launcher)
+        p_pos = G == 1 ? 0 : __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n));
+    } else {
+        n_pos = (n + 15) >> 4;
+        p_pos = G == 1 ? 0 : min((min(a.prefix, n) + 15) >> 4, n_pos);
+    }
+    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, xn_s + head * 64, D);
 }
 
 // ----------------------------------------------------------------------------------------------------------------- decode attention proper
@@ -499,7 +521,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 // HBM once per layer instead of once per sequence through L2), so this kernel is the K/V stream and nothing else: bias / visibility row and chunk list -> LDS,
 // k / v appended, the walk over the visible 16-key chunks, merge, + ln1(x) residual.  grid (H, B / G), 1024 threads.
 // Dynamic LDS: bias row [Lpad] | residual [G][64] | qkv [G][192] | red [16][G+1][66] | chunk list [Lpad/16 + 2] (uint16)
-template <int DT, int G>
+template <int DT, int G, bool SP>
 __global__ __launch_bounds__(1024) void ar_attn_kernel(ArAttnFusedArgs a) {
     constexpr int NW = AF_WAVES;
     extern __shared__ float smem[];
@@ -548,13 +570,12 @@ __global__ __launch_bounds__(1024) void ar_attn_kernel(ArAttnFusedArgs a) {
             bias_s[tid + 1024 * j] = ((kraw[j] || !vis.has_allowed) && (lraw[j] || !vis.has_lay)) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
     for (int k = tid + 1024 * BR; k < n; k += 1024)
         bias_s[k] = ((keep_row[k] || !vis.has_allowed) && (lay_row[k / vis.blk] || !vis.has_lay)) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
-    if (vis.has_chunks && tid < chunk_total) list_s[tid] = (uint16_t)chunk_id;
+    if (SP && tid < chunk_total) list_s[tid] = (uint16_t)chunk_id;
     __syncthreads();
-    const uint16_t* walk = vis.has_chunks ? list_s : nullptr;
-    const int n_pos = vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < n) : (n + 15) >> 4;
-    const int p_pos = G == 1 ? 0 : (vis.has_chunks ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n)) : min((min(a.prefix, n) + 15) >> 4, n_pos));
+    const int n_pos = SP ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < n) : (n + 15) >> 4;
+    const int p_pos = G == 1 ? 0 : (SP ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n)) : min((min(a.prefix, n) + 15) >> 4, n_pos));
     AF_TRACE(2);
-    af_append_attend_store<DT, G>(a, bias_s, qkv_s, red, walk, n_pos, p_pos, n, head, b0, res_s, 64);
+    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, res_s, 64);
 }
 
 #undef AF_TRACE
@@ -589,10 +610,15 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     const double eb = a.kv_dtype == 0 ? 4 : 2;
     const double pfx = a.G > 1 ? (double)a.prefix : 0.0;
     ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pfx) + (double)(a.B / a.G) * pfx), s);
-#define AF_LAUNCH(DT, GG, WW) hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG, WW>), grid, dim3(1024), lds, s, a)
+    // SP instantiations only when a layout hides something (density < 1): chunk lists are then always present (context.cpp / the operator entry build both)
+    const bool sp = a.vis.has_chunks;
+    BG_REQUIRE(sp || !a.vis.has_lay, "fused decode attention: a block layout needs its chunk lists");
+#define AF_LAUNCH(DT, GG, WW) do { if (sp) hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG, WW, true>), grid, dim3(1024), lds, s, a); \
+                                   else hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG, WW, false>), grid, dim3(1024), lds, s, a); } while (0)
 #define AF_LAUNCH_G(DT, WW) do { if (a.G == 1) AF_LAUNCH(DT, 1, WW); else if (a.G == 2) AF_LAUNCH(DT, 2, WW); else AF_LAUNCH(DT, 4, WW); } while (0)
     if (pre) {
-#define AP_LAUNCH(DT, GG) hipLaunchKernelGGL((ar_attn_kernel<DT, GG>), grid, dim3(1024), lds, s, a)
+#define AP_LAUNCH(DT, GG) do { if (sp) hipLaunchKernelGGL((ar_attn_kernel<DT, GG, true>), grid, dim3(1024), lds, s, a); \
+                               else hipLaunchKernelGGL((ar_attn_kernel<DT, GG, false>), grid, dim3(1024), lds, s, a); } while (0)
 #define AP_LAUNCH_G(DT) do { if (a.G == 1) AP_LAUNCH(DT, 1); else if (a.G == 2) AP_LAUNCH(DT, 2); else AP_LAUNCH(DT, 4); } while (0)
         if (a.kv_dtype == 0) AP_LAUNCH_G(0); else AP_LAUNCH_G(1);
 #undef AP_LAUNCH_G
@@ -747,7 +773,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                                    fmaf(bt[j].z, fb, (v[j].z - mean) * rstd * gm[j].z), fmaf(bt[j].w, fb, (v[j].w - mean) * rstd * gm[j].w));
             }
             // every workgroup holds the same normalised rows: workgroup i writes the chunks c with c % gridDim.x == i (each element once)
-            if (g.xn_out) {
+            if (RS && g.xn_out) {   // (only the row-source form - the LayerNorm + QKV projection of the split decode path - keeps ln1(x))
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = q + 4 * wave + 32 * j, m = mc * 16 + r;
@@ -896,7 +922,7 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     BG_REQUIRE(g.ksplit <= ROWSRC_MAX_SPLITS, "skinny_fused: at most %d K splits", ROWSRC_MAX_SPLITS);
     BG_REQUIRE(g.lda % 4 == 0 && g.Wp, "skinny_fused: A stride must be a multiple of 4, weights packed");
     BG_REQUIRE(!g.a_src || (ln && g.a_src->ns <= ROWSRC_MAX_SPLITS), "skinny_fused: a row source needs the LayerNorm form and at most %d partial sums", ROWSRC_MAX_SPLITS);
-    BG_REQUIRE(!g.xn_out || ln, "skinny_fused: xn_out is the LayerNorm output");
+    BG_REQUIRE(!g.xn_out || (ln && g.a_src), "skinny_fused: xn_out is the LayerNorm output of the row-source form");
     if (g.a_src) { g.src = rowsrc_fix(*g.a_src); g.a_src = nullptr; }
     const bool rs = g.src.base != nullptr;
     BG_REQUIRE(rs || g.A, "skinny_fused: no A operand");

@@ -89,6 +89,7 @@ struct Ctx {
     uint8_t* lay = nullptr;        // [keep_layers, Hk, nb, nb]
     uint16_t* chunks = nullptr;    // [keep_layers, Hk, nb, chunks_ld] or null when no layer can skip anything (every block at or below the diagonal present)
     int chunks_ld = 0;
+    bool lay_hides = true;         // some layout hides an element the mask allows (false at density 1.0: the kernels are then given no layout at all)
     int keep_heads = 1, keep_layers = 1;   // layouts per layer (1 = shared by all heads) / layers with their own layouts (1 = shared)
     float* prefill_bias = nullptr; // [Hk, K, Kpad] when the layers share a layout; else built per layer in the prefill's workspace
     int Kpad = 0;
@@ -97,7 +98,7 @@ struct Ctx {
         const int nb = L / cfg.sparse_block_size;
         const size_t li = keep_layers > 1 ? (size_t)i : 0;
         v.allowed = allowed; v.ldallowed = L; v.allowed_head_stride = 0;
-        v.lay = lay + li * keep_heads * nb * nb; v.lay_head_stride = keep_heads > 1 ? (long)nb * nb : 0; v.nb = nb; v.blk = cfg.sparse_block_size;
+        if (lay_hides) { v.lay = lay + li * keep_heads * nb * nb; v.lay_head_stride = keep_heads > 1 ? (long)nb * nb : 0; v.nb = nb; v.blk = cfg.sparse_block_size; }
         if (chunks) { v.chunks = chunks + li * keep_heads * nb * chunks_ld; v.chunks_head_stride = keep_heads > 1 ? (long)nb * chunks_ld : 0; v.chunks_ld = chunks_ld; }
         return v;
     }
