@@ -291,7 +291,7 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     density < 1 = SURVEY 8(d) config 4 variant: every attention layer gets its own random per-head block layouts (drawn like the reference does at construction,
     gpt:176, maskgen:217-228) - absent blocks are never read.  path = 'split': LayerNorm + QKV projection kernel, then the attention-only kernel."""
     import torch
-    from bevgen_amd import presets, synthetic, tables
+    from bevgen_amd import presets, synthetic
     from bevgen_amd.runtime import Context
     from bevgen_amd.weights import gpt_state_dict
 
@@ -300,23 +300,8 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     sd = dict(cached(("gpt", "config4"), lambda: gpt_state_dict(presets.config4(), 1234)))
     visible_frac = 1.0
     if density < 1.0:
-        torch.manual_seed(4242)
-        pat = tables.attention_patterns(cfg)
-        lays = [tables.head_layouts(cfg, pat) for _ in range(cfg.num_layers)]
-        for i, lay in enumerate(lays):
-            sd[f"blocks.{i}.attention.sparse_self_attention.master_layout"] = lay.to(torch.int64)
-        # fraction of the causal (row, key) pairs of the decode rows that sit in a present block, averaged over layers and heads: the algorithmic K/V bytes scale with it
-        blk, K, N = cfg.sparse_block_size, cfg.num_cond_tokens, cfg.num_img_tokens
-        allowed = cfg.attention_mask != 0
-        tot = vis = 0.0
-        for lay in lays[:4]:
-            for h in range(0, cfg.num_heads, 4):
-                full = lay[h].bool().repeat_interleave(blk, 0).repeat_interleave(blk, 1) & allowed
-                rows = slice(K, K + (steps or N))
-                causal = torch.tril(torch.ones_like(allowed))
-                tot += float((causal[rows] & allowed[rows]).sum())
-                vis += float((causal[rows] & full[rows]).sum())
-        visible_frac = vis / tot
+        lay_sd, visible_frac = synthetic.random_layer_layouts(cfg)
+        sd.update(lay_sd)
     ctx.load_state_dict(sd)
     ctx.set_tables()
     ctx.finalize()

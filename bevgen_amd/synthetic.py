@@ -69,3 +69,30 @@ def make_batch(cfg, B: int, seed: int = 0) -> Dict[str, torch.Tensor]:
         "extrinsics_inv": E_inv,
         "cond_ids": bev_token_ids(B, cfg.num_cond_tokens, cfg.cond_vocab_size, seed),
     }
+
+
+def random_layer_layouts(cfg, seed: int = 4242):
+    """Per-layer block layouts for density < 1 models, drawn the way the reference draws them at construction (one `multi_outward_pattern` call per attention
+    layer, gpt:176 / maskgen:217-228, on torch's CPU generator): {state_dict key: int64 [H, L/blk, L/blk]} for every layer, and the fraction of the causal
+    (decode row, key) pairs that sit in a present block (averaged over a sample of layers / heads) - the factor by which the algorithmic K/V bytes shrink."""
+    import torch
+
+    from . import tables
+
+    state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    pat = tables.attention_patterns(cfg)
+    lays = [tables.head_layouts(cfg, pat) for _ in range(cfg.num_layers)]
+    torch.set_rng_state(state)
+    sd = {f"blocks.{i}.attention.sparse_self_attention.master_layout": lay.to(torch.int64) for i, lay in enumerate(lays)}
+    blk, K, N = cfg.sparse_block_size, cfg.num_cond_tokens, cfg.num_img_tokens
+    allowed = cfg.attention_mask != 0
+    causal = torch.tril(torch.ones_like(allowed))
+    rows = slice(K, K + N)
+    tot = vis = 0.0
+    for lay in lays[:4]:
+        for h in range(0, cfg.num_heads, 4):
+            full = lay[h].bool().repeat_interleave(blk, 0).repeat_interleave(blk, 1) & allowed
+            tot += float((causal[rows] & allowed[rows]).sum())
+            vis += float((causal[rows] & full[rows]).sum())
+    return sd, vis / tot
