@@ -96,7 +96,7 @@ void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const floa
     BG_REQUIRE(L % block == 0, "Sequence Length, %d, needs to be dividable by Block size %d!", L, block);  // ssa:54-57
     const int Lpad = (int)round_up(L, 32);
     const int nb = L / block;
-    const size_t keep_b = (size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * (cdiv(L, 16) + 1) * sizeof(uint16_t) + 3 * 256;
+    const size_t keep_b = (size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * (cdiv(L, 16) + 1) * sizeof(uint16_t) + attn_tiles_elems(H, L, Lpad) * sizeof(uint16_t) + 4 * 256;
     const size_t bias_b = (size_t)H * L * Lpad * sizeof(float);
     const size_t kv_b = Lpad != L ? (size_t)2 * B * H * Lpad * 64 * sizeof(float) : 0;
     c.arena.reserve(keep_b + bias_b + kv_b + 8 * 256);
@@ -113,6 +113,9 @@ void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const floa
     }
     float* bias = c.arena.get<float>((size_t)H * L * Lpad);
     launch_build_masked_bias(add, vis, bias, H, L, L, Lpad, L, 0.125f, s);
+    // only the key tiles in which some row of a query block sees a key are loaded and multiplied (the reference computes the nonzero layout blocks only, ssa:63-85)
+    uint16_t* tiles = c.arena.get<uint16_t>(attn_tiles_elems(H, L, Lpad));
+    launch_build_attn_tiles(bias, (long)L * Lpad, Lpad, H, L, Lpad, tiles, s);
     const float *kp = k, *vp = v;
     if (Lpad != L) {
         float* kpad = c.arena.get<float>((size_t)B * H * Lpad * 64);
@@ -130,6 +133,7 @@ void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const floa
     a.kv_bstride = (long)H * Lpad * 64; a.kv_hstride = (long)Lpad * 64;
     a.ldbias = Lpad; a.bias_head_stride = (long)L * Lpad; a.scale = 0.125f;
     a.o_bstride = (long)H * L * 64; a.o_qstride = 64; a.o_hstride = (long)L * 64;  // [B,H,L,64] like the reference op
+    a.tiles = tiles; a.tiles_head_stride = (long)cdiv(L, 128) * (Lpad / 32 + 1); a.tiles_ld = Lpad / 32 + 1;
     launch_attention(a, s);
 }
 
@@ -167,7 +171,8 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     const size_t rows = (size_t)G * K;
     const size_t tmp_kv = cache_dtype(c) ? (size_t)2 * G * H * c.Kpad * 64 : 0;   // fp16 cache: the prefill attention reads exact fp32 K/V from a scratch pair
     const size_t layer_bias = c.prefill_bias ? 0 : (size_t)c.keep_heads * K * c.Kpad;   // per-layer layouts: this layer's masked bias is built on the fly
-    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)G * H * K * 64 + tmp_kv + layer_bias) * sizeof(float) + (size_t)G * (K * 8 + (size_t)(g.num_cams + 1) * D * 4) + 32 * 256;
+    const size_t pre_b = (rows * D * 4 + rows * 3 * D + rows * 4 * D + (size_t)G * H * K * 64 + tmp_kv + layer_bias) * sizeof(float) + (size_t)G * (K * 8 + (size_t)(g.num_cams + 1) * D * 4) +
+                         attn_tiles_elems(c.keep_heads, K, c.Kpad) * sizeof(uint16_t) + 34 * 256;
     c.arena.reserve(step_ws_bytes(c, B) + pre_b);
     c.arena.reset();
     (void)step_ws(c, B);
@@ -179,6 +184,8 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     float* m1 = c.arena.get<float>(rows * 4 * D);
     float* Q = c.arena.get<float>((size_t)G * H * K * 64);
     float* lbias = c.prefill_bias ? nullptr : c.arena.get<float>(layer_bias);
+    uint16_t* ltiles = c.arena.get<uint16_t>(attn_tiles_elems(c.keep_heads, K, c.Kpad));   // key tiles of the condition rows that hold a present block (rebuilt per layer when layouts differ)
+    if (c.prefill_bias) launch_build_attn_tiles(c.prefill_bias, (long)K * c.Kpad, c.Kpad, c.keep_heads, K, c.Kpad, ltiles, s);
 
     if (g.image_embed)   // per-sequence state of the decode steps: for all B sequences
         launch_camera_embed(I_inv, E_inv, c.image_plane, c.pf("img_embed.weight"), c.pf("cam_embed.weight"), st.img_embed, st.c_embed, B, g.num_cams, c.T, D, s);
@@ -215,12 +222,16 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
         launch_ar_qkv_scatter(qkv, Q, kc, vc, 0, G, H, K, 0, Lk, s);   // cache slots [0, G) for now
         if (kvd) launch_ar_qkv_scatter(qkv, nullptr, kcb, vcb, kvd, G, H, K, 0, L, s);   // the fp16 image the decode steps read
         AttnArgs a{};
-        if (lbias) launch_build_masked_bias(c.attn_bias, c.vis_of_layer(i), lbias, c.keep_heads, K, K, c.Kpad, c.L, 0.125f, s);
+        if (lbias) {
+            launch_build_masked_bias(c.attn_bias, c.vis_of_layer(i), lbias, c.keep_heads, K, K, c.Kpad, c.L, 0.125f, s);
+            launch_build_attn_tiles(lbias, (long)K * c.Kpad, c.Kpad, c.keep_heads, K, c.Kpad, ltiles, s);
+        }
         a.Q = Q; a.K = kc; a.V = vc; a.bias = lbias ? lbias : c.prefill_bias; a.R = xn; a.O = x2;
         a.B = G; a.H = H; a.Nq = K; a.Nk_pad = c.Kpad;
         a.q_bstride = (long)H * K * 64; a.q_hstride = (long)K * 64;
         a.kv_bstride = (long)H * Lk * 64; a.kv_hstride = (long)Lk * 64;
         a.ldbias = c.Kpad; a.bias_head_stride = c.keep_heads > 1 ? (long)K * c.Kpad : 0; a.scale = 0.125f;
+        a.tiles = ltiles; a.tiles_head_stride = c.keep_heads > 1 ? (long)cdiv(K, 128) * (c.Kpad / 32 + 1) : 0; a.tiles_ld = c.Kpad / 32 + 1;
         a.o_bstride = (long)K * D; a.o_qstride = D; a.o_hstride = 64;
         BG_REQUIRE(c.Kpad <= L, "condition length padded to %d exceeds the cache length %d", c.Kpad, L);
         launch_attention(a, s);  // x2 = ln1(x) + attn

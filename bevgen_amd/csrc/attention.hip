@@ -75,14 +75,20 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs a) {
         *reinterpret_cast<float4*>(&Vs[buf][(lrow0 + 16) * VLD + lc4 * 4]) = rv1;
     };
 
-    const int ntiles = a.Nk_pad / KT;
-    gload(0);
-    lstore(0);
+    // key tiles to visit: all of them, or the list of this (head, query block) - tiles no row of the block can see are neither loaded nor multiplied
+    const uint16_t* tl = a.tiles ? a.tiles + (long)head * a.tiles_head_stride + (long)blockIdx.x * a.tiles_ld : nullptr;
+    const int ntiles = tl ? (int)tl[0] : a.Nk_pad / KT;
+    auto tile_at = [&](int i) { return tl ? (int)tl[1 + i] : i; };
+    if (ntiles > 0) {
+        gload(tile_at(0));
+        lstore(0);
+    }
     __syncthreads();
     int cur = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const bool more = tile + 1 < ntiles;
-        if (more) gload(tile + 1);
+    for (int ti = 0; ti < ntiles; ++ti) {
+        const int tile = tile_at(ti);
+        const bool more = ti + 1 < ntiles;
+        if (more) gload(tile_at(ti + 1));
 
         // ---- S^T = K Q^T  (A = K rows from LDS, B = Q registers)
         f32x16 s;
@@ -161,6 +167,34 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(AttnArgs a) {
                 *reinterpret_cast<float4*>(a.O + orow + d) = o;
             }
     }
+}
+
+// tiles[h][qb] = {count, ids...}: key tile t is listed when any row of query block qb (128 rows) has a bias value above the mask level in it
+__global__ __launch_bounds__(256) void build_attn_tiles_kernel(const float* __restrict__ bias, long bias_head_stride, int ldbias, int Nq, int Nk_pad, uint16_t* __restrict__ tiles,
+                                                               int tiles_ld) {
+    __shared__ int present[1024];
+    const int qb = blockIdx.x, h = blockIdx.y, nt = Nk_pad / KT;
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) present[t] = 0;
+    __syncthreads();
+    const float* B = bias + (long)h * bias_head_stride;
+    const int r1 = min(Nq, qb * 128 + 128);
+    for (int r = qb * 128; r < r1; ++r)
+        for (int c = threadIdx.x; c < Nk_pad; c += blockDim.x)
+            if (B[(long)r * ldbias + c] > 0.5f * kNegBig) present[c / KT] = 1;   // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint16_t* out = tiles + ((long)h * gridDim.x + qb) * tiles_ld;
+        int n = 0;
+        for (int t = 0; t < nt; ++t)
+            if (present[t]) out[1 + n++] = (uint16_t)t;
+        out[0] = (uint16_t)n;
+    }
+}
+size_t attn_tiles_elems(int heads, int Nq, int Nk_pad) { return (size_t)heads * cdiv(Nq, 128) * (Nk_pad / KT + 1); }
+void launch_build_attn_tiles(const float* masked_bias, long bias_head_stride, int ldbias, int heads, int Nq, int Nk_pad, uint16_t* tiles, hipStream_t s) {
+    BG_REQUIRE(Nk_pad / KT <= 1024, "attention tile lists: at most 1024 key tiles");
+    hipLaunchKernelGGL(build_attn_tiles_kernel, dim3(cdiv(Nq, 128), heads), dim3(256), 0, s, masked_bias, bias_head_stride, ldbias, Nq, Nk_pad, tiles, Nk_pad / KT + 1);
+    LAUNCH_CHECK();
 }
 
 void launch_attention(const AttnArgs& a, hipStream_t s) {

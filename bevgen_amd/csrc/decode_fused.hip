@@ -360,7 +360,11 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     // so that at any moment they pull on different lines / channels instead of queueing on one.
     // fp16 weight storage: 8 elements per 16-byte load, twice the rows per batch for the same registers
     constexpr int EL = WT ? 8 : 4, NCH = WT ? 2 : 4;                 // elements per lane and load; loads per row (D <= 1024)
-    constexpr int RB = (G == 1 ? 3 : 2) * (WT ? 2 : 1), NB = 12 / RB;
+    // Rows per batch: small enough that NOTHING spills.  A spilled register is not free here: 1024 threads x 256 workgroups park 1 MB per register in scratch and
+    // read it back, per launch - round 2's three-row batches (G = 1) spilled 1 / 4 registers in the fp32 / fp16-cache variants, i.e. up to 8 MB of extra traffic
+    // next to 22-44 MB of K/V; with two rows per batch the same-box A/B gives 1.617 -> 1.560 (fp32 cache), 1.306 -> 1.215 (fp16 cache) and 1.144 -> 1.122
+    // ms/step (fp16 cache + weights), and the FETCH_SIZE counter no longer shows MORE traffic at density 0.35 than at density 1.
+    constexpr int RB = (G >= 4 ? 1 : 2) * (WT ? 2 : 1), NB = 12 / RB;
     typedef typename std::conditional<WT == 1, half8_t, f32x4>::type WV;
     const int rot = grp % NB;
     auto wrow = [&](int bi, int r) { return wave * 12 + ((bi + rot) % NB) * RB + r; };

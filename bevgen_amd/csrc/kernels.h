@@ -108,8 +108,14 @@ struct AttnArgs {
     float scale;
     long o_bstride, o_qstride, o_hstride;  // O (and R) element index = b*o_bstride + q*o_qstride + head*o_hstride + d
     int kv_group = 1;             // consecutive groups of kv_group batches read the K / V of batch b / kv_group (samples of one BEV layout share the condition's cross-attention K / V)
+    // block-sparse layouts (Route A prefill, the SparseSelfAttention operator): per (head, 128-row query block) the ascending list of 32-key tiles in which ANY of the
+    // block's rows sees a key - count first, [heads or 1][cdiv(Nq, 128)][tiles_ld] (launch_build_attn_tiles from the masked bias); tiles outside the list are never
+    // loaded or multiplied (sparse_self_attention.py:63-85 computes only the nonzero layout blocks).  null = every tile
+    const uint16_t* tiles = nullptr; long tiles_head_stride = 0; int tiles_ld = 0;
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
+size_t attn_tiles_elems(int heads, int Nq, int Nk_pad);
+void launch_build_attn_tiles(const float* masked_bias, long bias_head_stride, int ldbias, int heads, int Nq, int Nk_pad, uint16_t* tiles, hipStream_t s);
 void launch_splitk_reduce(const GemmArgs& g, const float* partial, int ksplit, hipStream_t s);   // gemm_skinny.hip: C = act(alpha * sum_k partial[k] + bias) + R
 
 // Split-precision flash attention (attention_split.hip): operands pre-split into (hi, lo) f16 planes by the preparation kernels.

@@ -15,10 +15,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LIMITS = {
     "gemm_split_glds.hip": {"gemm_split_glds_kernelILi0ELi4ELi3ELb0ELb0E": 0, "gemm_split_glds_kernelILi1ELi4ELi3ELb0ELb0E": 16, "gemm_split_glds_kernelILi0ELi2ELi2ELb0ELb1E": 0,
                             "gemm_split_glds_kernelILi0ELi4ELi3ELb1ELb0E": 0},
-    # (the dense fused attention kernels are pinned at their round-2 budgets - the block-sparse instantiations <..., true> may park a few registers outside the key
-    # walk; the attention-only kernel and the projection kernels must not spill at all)
-    "decode_fused.hip": {"ar_attn_fused_kernelILi0ELi1ELi0ELb0E": 1, "ar_attn_fused_kernelILi1ELi1ELi0ELb0E": 4, "ar_attn_fused_kernelILi1ELi1ELi1ELb0E": 0,
-                         "ar_attn_fused_kernelILi0ELi1ELi0ELb1E": 8, "ar_attn_kernelILi1ELi1ELb0E": 0, "ar_attn_kernelILi0ELi1ELb0E": 0, "ar_attn_kernelILi1ELi1ELb1E": 0,
+    # (a spilled register of a 1024-thread x 256-workgroup launch is 1 MB of scratch written and read back per launch: the decode kernels must not spill at all)
+    "decode_fused.hip": {"ar_attn_fused_kernelILi0ELi1ELi0ELb0E": 0, "ar_attn_fused_kernelILi1ELi1ELi0ELb0E": 0, "ar_attn_fused_kernelILi1ELi1ELi1ELb0E": 0,
+                         "ar_attn_fused_kernelILi0ELi1ELi0ELb1E": 0, "ar_attn_fused_kernelILi1ELi1ELi0ELb1E": 0, "ar_attn_fused_kernelILi0ELi4ELi0ELb0E": 0,
+                         "ar_attn_kernelILi1ELi1ELb0E": 0, "ar_attn_kernelILi0ELi1ELb0E": 0, "ar_attn_kernelILi1ELi1ELb1E": 0,
                          "skinny_fused_kernelILb1ELi0ELb0E": 0,
                          "skinny_fused_kernelILb1ELi0ELb1E": 0, "skinny_fused_kernelILb0ELi0ELb0E": 0},
     "attention_split.hip": {"attention_split_kernelILb0E": 0},
