@@ -216,7 +216,7 @@ __device__ __forceinline__ void wave_merge(float& m, float& l, float (&acc)[DPL]
 // 16 waves, + residual (res_s[g * ldres + d], LDS) -> out.  Called by every thread of the workgroup after a barrier that made qkv_s / bias_s / the list visible.
 template <int DT, int G, bool SP>   // SP: the walk follows a chunk list (block-sparse layout); false = the dense interleaved walk with every stride a constant
 __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a, const float* bias_s, const float* qkv_s, float* red, const uint16_t* walk, int n_pos, int p_pos,
-                                                       int n, int head, int b0, const float* res_s, int ldres) {
+                                                       int n, int head, int b0, const float* res_s, int ldres, float* pf_sink) {
     using T = KvRow<DT>;
     constexpr int LPK = T::LPK, DPL = T::DPL, NW = AF_WAVES, TW = NW / G;
     constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // key loads per lane group and pipeline step (fp16 rows: 3 or 4 measured no faster)
@@ -289,6 +289,20 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
             }
         }
     }
+    // ---- this wave's walk is done: while the others finish, request this workgroup's slices of the next two launches' weight images (see ArAttnFusedArgs::pf_ptr)
+    if (a.pf_bytes[0] > 0) {
+        const long nwg = (long)gridDim.x * gridDim.y, wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        float* sink = pf_sink;   // ONE 1 KiB sink for all waves and pieces: the bytes are never read, only their passage through L2 matters
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long share = ((a.pf_bytes[k] + nwg * 16384 - 1) / (nwg * 16384)) * 16384;   // bytes per workgroup, a multiple of 16 waves x 1 KiB
+            const char* base = reinterpret_cast<const char*>(a.pf_ptr[k]);
+            for (long off = wg * share + wave * 1024; off < min((wg + 1) * share, a.pf_bytes[k]); off += 16 * 1024) {
+                const long o = min(off + lane * 16, a.pf_bytes[k] - 16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o), (__attribute__((address_space(3))) void*)sink, 16, 0, 0);
+            }
+        }
+    }
     __syncthreads();
     AF_TRACE(4);
 
@@ -321,6 +335,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
         }
         a.out[(long)(b0 + g) * a.ldo + head * 64 + d] = o / l + res_s[g * ldres + d];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prefetch DMA writes LDS: it must have landed before the workgroup's LDS is released)
     AF_TRACE(5);
 }
 
@@ -338,6 +353,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     float* red = qkv_s + G * 192;
     float* stat = red + NW * (G + 1) * 66;
     uint16_t* list_s = reinterpret_cast<uint16_t*>(stat + NW * G);
+    float* pf_sink = reinterpret_cast<float*>(list_s + ((a.Lpad / 16 + 2 + 7) & ~7));   // 1 KiB, 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, grp = blockIdx.y;
@@ -517,7 +533,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         n_pos = (n + 15) >> 4;
         p_pos = G == 1 ? 0 : min((min(a.prefix, n) + 15) >> 4, n_pos);
     }
-    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, xn_s + head * 64, D);
+    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, xn_s + head * 64, D, pf_sink);
 }
 
 // ----------------------------------------------------------------------------------------------------------------- decode attention proper
@@ -535,6 +551,7 @@ __global__ __launch_bounds__(1024) void ar_attn_kernel(ArAttnFusedArgs a) {
     float* qkv_s = res_s + G * 64;
     float* red = qkv_s + G * 192;
     uint16_t* list_s = reinterpret_cast<uint16_t*>(red + NW * (G + 1) * 66);
+    float* pf_sink = reinterpret_cast<float*>(list_s + ((a.Lpad / 16 + 2 + 7) & ~7));
 
     const int tid = threadIdx.x;
     const int head = blockIdx.x, grp = blockIdx.y;
@@ -579,15 +596,18 @@ __global__ __launch_bounds__(1024) void ar_attn_kernel(ArAttnFusedArgs a) {
     const int n_pos = SP ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < n) : (n + 15) >> 4;
     const int p_pos = G == 1 ? 0 : (SP ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n)) : min((min(a.prefix, n) + 15) >> 4, n_pos));
     AF_TRACE(2);
-    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, res_s, 64);
+    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, res_s, 64, pf_sink);
 }
 
 #undef AF_TRACE
 
-size_t ar_attn_lds_bytes(int G, int Lpad) { return ((size_t)Lpad + (size_t)G * 64 + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66) * sizeof(float) + ((size_t)Lpad / 16 + 2) * sizeof(uint16_t); }
+size_t ar_attn_lds_bytes(int G, int Lpad) {
+    return ((size_t)Lpad + (size_t)G * 64 + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66) * sizeof(float) + ((size_t)Lpad / 16 + 2 + 8) * sizeof(uint16_t) + 1024;
+}
 
 size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) {
-    return ((size_t)Lpad + (size_t)G * D + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66 + (size_t)AF_WAVES * G) * sizeof(float) + ((size_t)Lpad / 16 + 2) * sizeof(uint16_t);
+    return ((size_t)Lpad + (size_t)G * D + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66 + (size_t)AF_WAVES * G) * sizeof(float) + ((size_t)Lpad / 16 + 2 + 8) * sizeof(uint16_t) +
+           1024;   // + the prefetch sink
 }
 
 bool ar_attn_fused_supported(int B, int G, int D, int H) { return D == H * 64 && D % 4 == 0 && D <= 1024 && (G == 1 || G == 2 || G == 4) && B % G == 0; }

@@ -225,6 +225,11 @@ struct ArAttnFusedArgs {
     int prefix = 0;                    // G > 1: leading keys shared by the G sequences of a group (read from the group's first cache slot)
     float scale = 0.125f;
     long long* trace = nullptr;        // diagnostics: [workgroup][8] device timestamps (100 MHz) at the phase boundaries, or null
+    // cross-kernel prefetch: the weight images the NEXT two launches of the layer stream (ln2 + MLP-up, MLP-down).  Every workgroup pulls "its" 1/nwg slice of each
+    // through the L2 of its XCD while its K/V walk drains (LDS-DMA into a scratch sink: no registers) - workgroup j of the next launch runs on the same XCD (j % 8)
+    // and finds its 64 KB slice in L2 instead of starting with one cold HBM burst.  pf_bytes = 0: off
+    const void* pf_ptr[2] = {nullptr, nullptr};
+    long pf_bytes[2] = {0, 0};
     int has_bias = 0;                  // filled in by the launcher
 };
 bool ar_attn_fused_supported(int B, int G, int D, int H);

@@ -161,6 +161,9 @@ struct Ctx {
     std::vector<hipEvent_t> step_events;
     int step_events_used = 0;
     bool disable_graphs = false;
+    // experiment switch ($BEVGEN_PREFETCH = 1 both MLP images, 2 the up-projection only): the decode attention kernels pull the layer's MLP weight images through L2
+    // under the tail of their K/V walk.  Measured slower on the same box (1.55 -> 1.65 / 1.61 ms/step, profiles/r03_ab_prefetch.txt): default off
+    int prefetch_weights = getenv("BEVGEN_PREFETCH") ? atoi(getenv("BEVGEN_PREFETCH")) : 0;
     long long* trace = nullptr;   // diagnostics (bevgen_set_trace_buffer): phase timestamps of the fused decode kernels, [3 kinds][4096 workgroups][8]
     void retire_graph(hipGraphExec_t e, hipGraph_t g);  // destroyed once the stream has drained (next call or destroy)
 
