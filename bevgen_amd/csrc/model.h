@@ -40,6 +40,9 @@ struct MuseLayer {
     float* ff_w4_padded;  // [D, Fpad], owned
     void* null_self = nullptr;      // split-precision mode: prepared null key / value of the self-attention ([k_hi|k_lo|v_hi|v_lo][H][64] halves, owned)
     float* ff_w1_geglu = nullptr;   // split-precision mode: [2 Fpad, D] rows ordered for the fused GEGLU epilogue (owned)
+    // LayerNorm folded into the GEMMs (split-precision mode, GemmArgs::ln_*): colsum[n] = sum_k gamma_k W[n,k] of every consumer projection, gamma of the
+    // feed-forward's inner LayerNorm padded with zeros to Fpad (owned)
+    float *cs_q[2] = {nullptr, nullptr}, *cs_kv0 = nullptr, *cs_ff1 = nullptr, *cs_ff2 = nullptr, *ff_g3_pad = nullptr;
 };
 
 struct ArLayer {
