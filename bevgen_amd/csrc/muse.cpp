@@ -262,8 +262,10 @@ void muse_blocks_folded(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
 // one transformer pass over the current ids: leaves LayerNorm(x) (= `embed`, muse_net:202) in w.xn
 void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
     const auto& g = c.cfg;
-    static const bool no_fold = getenv("BEVGEN_NO_LN_FOLD") != nullptr;   // A/B switch
-    if (g.precision == BEVGEN_PRECISION_F16X3 && c.muse[0].ff_w1_geglu && !w.kpart && !no_fold) return muse_blocks_folded(c, w, ids, s);
+    // $BEVGEN_LN_FOLD: unset = folded LayerNorms at throughput batch sizes (no split-K workspace), 0 = never (A/B), 1 = always (tests: the small full-size goldens)
+    const char* fold_env = getenv("BEVGEN_LN_FOLD");
+    const bool can_fold = g.precision == BEVGEN_PRECISION_F16X3 && c.muse[0].ff_w1_geglu;
+    if (can_fold && (fold_env ? fold_env[0] == '1' : !w.kpart)) return muse_blocks_folded(c, w, ids, s);
     const std::string p = "transformer.";
     const int D = c.D, H = c.H, B = w.B, N = c.N;
     const int rows = (int)w.rows;
