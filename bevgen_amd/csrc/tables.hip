@@ -44,24 +44,31 @@ void launch_build_allowed(const float* mask, uint8_t* out, long n, hipStream_t s
     LAUNCH_CHECK();
 }
 // layout int64 [heads, nb, nb] -> lay uint8 [heads, nb, nb] and, per (head, block row), chunks[0] = count, chunks[1..] = ascending ids of the 16-key chunks that
-// overlap a present block (chunks_ld >= ceil(L / 16) + 1).  One thread per (head, block row): setup-time work.
-__global__ void build_layout_kernel(const int64_t* __restrict__ layout, uint8_t* __restrict__ lay, uint16_t* __restrict__ chunks, int heads, int nb, int blk, int L, int chunks_ld) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= heads * nb) return;
+// overlap a present block (chunks_ld >= ceil(L / 16) + 1).  One workgroup per (head, block row): threads test chunks, one thread compacts (<= 1024 chunks).
+__global__ __launch_bounds__(256) void build_layout_kernel(const int64_t* __restrict__ layout, uint8_t* __restrict__ lay, uint16_t* __restrict__ chunks, int heads, int nb, int blk, int L, int chunks_ld) {
+    __shared__ uint8_t present[1024];
+    const int i = blockIdx.x;   // (head, block row)
     const int64_t* src = layout + (long)i * nb;
     uint8_t* dst = lay + (long)i * nb;
-    for (int j = 0; j < nb; ++j) dst[j] = src[j] != 0 ? 1 : 0;
-    uint16_t* out = chunks + (long)i * chunks_ld;
-    int cnt = 0;
-    for (int c = 0; c * 16 < L; ++c) {
+    for (int j = threadIdx.x; j < nb; j += blockDim.x) dst[j] = src[j] != 0 ? 1 : 0;
+    const int nc = (L + 15) / 16;
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
         bool any = false;
         for (int k = c * 16; k < min(L, c * 16 + 16) && !any; k += (blk < 16 ? blk : 16)) any = src[k / blk] != 0;
-        if (any) out[1 + cnt++] = (uint16_t)c;
+        present[c] = any ? 1 : 0;
     }
-    out[0] = (uint16_t)cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint16_t* out = chunks + (long)i * chunks_ld;
+        int cnt = 0;
+        for (int c = 0; c < nc; ++c)
+            if (present[c]) out[1 + cnt++] = (uint16_t)c;
+        out[0] = (uint16_t)cnt;
+    }
 }
 void launch_build_layout(const int64_t* layout, uint8_t* lay, uint16_t* chunks, int heads, int nb, int blk, int L, int chunks_ld, hipStream_t s) {
-    hipLaunchKernelGGL(build_layout_kernel, dim3(cdiv(heads * nb, 64)), dim3(64), 0, s, layout, lay, chunks, heads, nb, blk, L, chunks_ld);
+    BG_REQUIRE((L + 15) / 16 <= 1024, "build_layout: at most 1024 key chunks per row (L = %d)", L);
+    hipLaunchKernelGGL(build_layout_kernel, dim3(heads * nb), dim3(256), 0, s, layout, lay, chunks, heads, nb, blk, L, chunks_ld);
     LAUNCH_CHECK();
 }
 
