@@ -17,7 +17,7 @@ ABI_VERSION = 3
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
-DECODE_FUSED, DECODE_PER_OP, DECODE_SPLIT = 0, 1, 2
+DECODE_FUSED, DECODE_PER_OP, DECODE_SPLIT, DECODE_AUTO = 0, 1, 2, 3
 VQ_OUT_RAW, VQ_OUT_DENORM, VQ_OUT_U8 = 0, 1, 2
 W_F32, W_F16 = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_F64 = 0, 1, 2, 3

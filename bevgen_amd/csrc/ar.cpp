@@ -33,11 +33,23 @@ struct StepWs {
     int splits;
 };
 
-bool fused_path(const Ctx& c, int B, int G) {
-    if (c.cfg.decode_path != BEVGEN_DECODE_FUSED && c.cfg.decode_path != BEVGEN_DECODE_SPLIT) return false;
+bool split_supported(const Ctx& c, int B) {
     const int D = c.D;
-    if (c.cfg.decode_path == BEVGEN_DECODE_SPLIT && !(skinny_fused_supported(B, 3 * D, D, true) && (c.cfg.decode_weight_dtype != BEVGEN_W_F16 || skinny_fused_f16_ok(3 * D, D, true))))
-        return false;
+    return skinny_fused_supported(B, 3 * D, D, true) && (c.cfg.decode_weight_dtype != BEVGEN_W_F16 || skinny_fused_f16_ok(3 * D, D, true));
+}
+// BEVGEN_DECODE_AUTO: the split layer for one or two sequences (layout groups) per call, else the fused one.  Same box, config 4, fp32, full decodes: B = 1 split 1.09 /
+// fused 1.27 ms per step, B = 2 1.15 / 1.23, B = 4 1.22 / 1.20, B = 8 1.34 / 1.24, B = 16 1.47 / 1.42 - with sixteen workgroups per layer the fused kernel's per-head
+// GEMV cannot pull the 12.6 MB of q/k/v weights fast enough; the projection kernel spreads them over 192 workgroups.
+int effective_decode_path(const Ctx& c, int B, int G) {
+    if (c.cfg.decode_path != BEVGEN_DECODE_AUTO) return c.cfg.decode_path;
+    return (B / std::max(G, 1) <= 2 && split_supported(c, B)) ? BEVGEN_DECODE_SPLIT : BEVGEN_DECODE_FUSED;
+}
+
+bool fused_path(const Ctx& c, int B, int G) {
+    const int path = effective_decode_path(c, B, G);
+    if (path != BEVGEN_DECODE_FUSED && path != BEVGEN_DECODE_SPLIT) return false;
+    const int D = c.D;
+    if (path == BEVGEN_DECODE_SPLIT && !split_supported(c, B)) return false;
     if (G > 1 && c.K % 16 != 0) return false;   // the shared condition prefix must end on a 16-key chunk boundary (the per-operator path replicates it instead)
     return ar_attn_fused_supported(B, G, D, c.H) && skinny_fused_supported(B, 4 * D, D, true) && skinny_fused_supported(B, D, 4 * D, false) &&
            skinny_fused_supported(B, c.V, D, true) && ar_attn_fused_lds_bytes(G, D, (int)round_up(c.L, 4)) <= 64 * 1024 &&
@@ -318,7 +330,7 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
     const int wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
     float* part = w.part + (size_t)ks * r0 * D;               // [ks][Bc][D] per chain, chains back to back
     float* m1 = w.m1 + (size_t)r0 * 4 * D;
-    const bool split = g.decode_path == BEVGEN_DECODE_SPLIT;
+    const bool split = effective_decode_path(c, B, st.G) == BEVGEN_DECODE_SPLIT;
     float* qkv = w.qkv + (size_t)r0 * 3 * D;
     float* xn = w.xn + (size_t)r0 * D;
     RowSrc src;

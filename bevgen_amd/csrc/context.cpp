@@ -250,7 +250,7 @@ static void finalize_ar(Ctx& c) {
     expect_shape(c, "cond_pos_emb", {1, c.K, D});
     expect_shape(c, "head.weight", {g.vocab_size, D});
     const bool wf16 = g.decode_weight_dtype == BEVGEN_W_F16;
-    const bool fused_like = g.decode_path == BEVGEN_DECODE_FUSED || g.decode_path == BEVGEN_DECODE_SPLIT;
+    const bool fused_like = g.decode_path == BEVGEN_DECODE_FUSED || g.decode_path == BEVGEN_DECODE_SPLIT || g.decode_path == BEVGEN_DECODE_AUTO;
     BG_REQUIRE(!wf16 || (fused_like && D % 256 == 0), "decode_weights = f16 needs the fused decode path and dim %% 256 == 0 (dim = %d)", D);
     BG_REQUIRE(g.weight_dtype != BEVGEN_W_F16 || wf16, "Route A: weight_dtype = f16 needs decode_weight_dtype = f16 as well (prefill and decode must run ONE rounded model)");
     c.ar.resize(g.num_layers);
@@ -276,7 +276,7 @@ static void finalize_ar(Ctx& c) {
         }
         if (fused_like) {
             const size_t eb = wf16 ? sizeof(_Float16) : sizeof(float);
-            if (g.decode_path == BEVGEN_DECODE_SPLIT) {
+            if (g.decode_path == BEVGEN_DECODE_SPLIT || g.decode_path == BEVGEN_DECODE_AUTO) {
                 l.wqkv_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(3 * D, D) * eb));
                 if (wf16) launch_pack_skinny_weight_f16(l.wqkv, l.wqkv_wp, 3 * D, D, 0);
                 else launch_pack_skinny_weight(l.wqkv, l.wqkv_wp, 3 * D, D, 0);

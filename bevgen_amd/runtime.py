@@ -52,7 +52,7 @@ class Context:
     """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
-                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "fused", decode_weights: str = "f32",
+                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "auto", decode_weights: str = "f32",
                  weights: Optional[str] = None, decode_chains: Optional[int] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -73,9 +73,9 @@ class Context:
         # Route A KV-cache storage: 'f32' (bit-exact tokens) or 'f16' (fp16 storage / fp32 accumulate, BASELINE config 4: half the decode traffic)
         c.kv_cache_dtype = {"f32": _lib.KV_F32, "f16": _lib.KV_F16}[kv_cache]
         self.kv_cache = kv_cache
-        # Route A decode step: 'fused' (three launches per layer), 'split' (LayerNorm + QKV projection kernel, then the attention-only kernel: four launches)
+        # Route A decode step: 'auto' (default: 'split' for one or two sequences per call, else 'fused'), 'fused' (three launches per layer), 'split' (LayerNorm + QKV projection kernel, then the attention-only kernel: four launches)
         # or 'per_op' (one kernel per operator, the A/B reference)
-        c.decode_path = {"fused": _lib.DECODE_FUSED, "per_op": _lib.DECODE_PER_OP, "split": _lib.DECODE_SPLIT}[decode_path]
+        c.decode_path = {"fused": _lib.DECODE_FUSED, "per_op": _lib.DECODE_PER_OP, "split": _lib.DECODE_SPLIT, "auto": _lib.DECODE_AUTO}[decode_path]
         self.decode_path = decode_path
         # Route A projection weights: 'f32', or 'f16' = the model with fp16-representable q/k/v, MLP and head weights (rounded at finalize), whose decode
         # step streams 2-byte weights

@@ -35,7 +35,7 @@ enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
  *         fp32 accumulation, up to 5x the fp32 MFMA rate.  Everything else (attention, norms, samplers, decode-step GEMMs) stays fp32. */
 enum { BEVGEN_PRECISION_FP32 = 0, BEVGEN_PRECISION_BF16 = 1 /* reserved */, BEVGEN_PRECISION_F16X3 = 2 };
 enum { BEVGEN_KV_F32 = 0, BEVGEN_KV_F16 = 1 };
-enum { BEVGEN_DECODE_FUSED = 0, BEVGEN_DECODE_PER_OP = 1, BEVGEN_DECODE_SPLIT = 2 };
+enum { BEVGEN_DECODE_FUSED = 0, BEVGEN_DECODE_PER_OP = 1, BEVGEN_DECODE_SPLIT = 2, BEVGEN_DECODE_AUTO = 3 };
 enum { BEVGEN_W_F32 = 0, BEVGEN_W_F16 = 1 };
 enum { BEVGEN_DTYPE_F32 = 0, BEVGEN_DTYPE_I64 = 1, BEVGEN_DTYPE_U8 = 2, BEVGEN_DTYPE_F64 = 3 };
 
@@ -72,7 +72,10 @@ typedef struct bevgen_cfg {
     int32_t decode_path;                               /* Route A decode step: BEVGEN_DECODE_FUSED (default: three launches per layer, decode_fused.hip) or
                                                           BEVGEN_DECODE_PER_OP (one kernel per operator: the round-1 path, kept as the A/B reference) or
                                                           BEVGEN_DECODE_SPLIT (four launches per layer: LayerNorm + QKV projection of the whole batch as one MFMA kernel that
-                                                          reads the weight once, then the decode-attention kernel proper = the K/V stream and nothing else) */
+                                                          reads the weight once, then the decode-attention kernel proper = the K/V stream and nothing else) or
+                                                          BEVGEN_DECODE_AUTO (what the Python host asks for: SPLIT for one or two sequences / layout groups per call - the
+                                                          interactive single-scene caller, where 16 workgroups per layer cannot pull the q/k/v weights fast enough:
+                                                          1.09 vs 1.27 ms/step at B = 1 - else FUSED) */
     int32_t decode_weight_dtype;                       /* Route A projection weights (q/k/v, MLP, head): BEVGEN_W_F32 (default) or BEVGEN_W_F16: bevgen_finalize rounds them to
                                                           fp16-representable values (prefill and decode then use the same model: the reference's Route A runs fp16,
                                                           sparse_self_attention.py:127) and the decode step streams the 2-byte copies: half the weight traffic */
