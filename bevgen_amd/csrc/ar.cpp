@@ -349,6 +349,12 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
             pq.M = Bc; pq.N = 3 * D; pq.K = D; pq.ksplit = 1;
             launch_skinny_fused(pq, s);
             a.qkv = qkv; a.xn = xn;
+            // one or two sequences: 16-32 workgroups cannot pull a 1.2 MB K/V range each at the chip's rate - split the key walk over more of them (the partial
+            // states live in the per-operator path's workspace, sized for at least this many splits)
+            if (st.G == 1 && Bc * H < 64) {
+                const int ks = std::min(std::min(4, 64 / (Bc * H)), w.splits);
+                if (ks > 1) { a.ksplit = ks; a.kws = w.dec_ws + (size_t)r0 * H * w.splits * 66; }   // (per chain: its sequences' slots)
+            }
         } else {
             a.x = src;
             a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;

@@ -391,6 +391,11 @@ __global__ __launch_bounds__(64) void decode_attention_combine_kernel(DecodeAttn
     a.O[(long)b * a.ldo + head * 64 + d] = v;
 }
 
+void launch_decode_attention_combine(const DecodeAttnArgs& a, const float* ws, int S, hipStream_t s) {
+    hipLaunchKernelGGL(decode_attention_combine_kernel, dim3(a.H, a.B), dim3(64), 0, s, a, ws, S);
+    LAUNCH_CHECK();
+}
+
 int decode_attention_splits(int B, int H, int n_max) {
     // B*H >= 192 workgroups already cover the chip: one 16-wave workgroup per (sequence, head), direct epilogue.
     // Fewer than that: split the context over workgroups (at least 256 keys per split) and merge in a second kernel.

@@ -226,7 +226,8 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
     const int row = n - 1;
     const float sl2 = a.scale * kLog2eF;
     // ---- append this step's k / v rows to the cache (row n-1 of every sequence of the group); read back through the normal path below
-    if (tid < 128 * G) {
+    //      (key split: the workgroup that owns the LAST list positions - the new key sits in the last visible chunk - appends; nobody else reads that row)
+    if (tid < 128 * G && blockIdx.z + 1 == gridDim.z) {
         const int g = tid >> 7, is_v = (tid >> 6) & 1, d = tid & 63;
         const float val = qkv_s[g * 192 + 64 + is_v * 64 + d];
         void* cache = is_v ? a.vcache : a.kcache;
@@ -244,7 +245,10 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
 #pragma unroll
         for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[sub * DPL + i] * sl2; acc[0][i] = 0.f; }
         const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-        Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, 0, n_pos, wave, kslot, n, sub, bias_s, q, m, l, acc);
+        // (key split: this workgroup's share of the list positions; gridDim.z == 1 -> all of them)
+        const int ksl = (int)gridDim.z, kz = (int)blockIdx.z;
+        const int p_lo = (int)((long)kz * n_pos / ksl), p_hi = (int)((long)(kz + 1) * n_pos / ksl);
+        Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, p_lo, p_hi, wave, kslot, n, sub, bias_s, q, m, l, acc);
         wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
         if (kslot == 0) {
             if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
@@ -333,7 +337,13 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
                 o += e[2 + d] * f;
             }
         }
-        a.out[(long)(b0 + g) * a.ldo + head * 64 + d] = o / l + res_s[g * ldres + d];
+        if (gridDim.z > 1) {   // key split (G == 1): partial state for the combine kernel
+            float* pw = a.kws + ((((long)b0 * a.H + head) * gridDim.z) + blockIdx.z) * 66;
+            if (d == 0) { pw[0] = mm; pw[1] = l; }
+            pw[2 + d] = o;
+        } else {
+            a.out[(long)(b0 + g) * a.ldo + head * 64 + d] = o / l + res_s[g * ldres + d];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prefetch DMA writes LDS: it must have landed before the workgroup's LDS is released)
     AF_TRACE(5);
@@ -628,7 +638,8 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     BG_REQUIRE(!a.vis.has_chunks || a.vis.chunks_ld <= 1025, "fused decode attention: at most 1024 key chunks per row");
     const size_t lds = pre ? ar_attn_lds_bytes(a.G, a.Lpad) : ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
-    dim3 grid(a.H, a.B / a.G);
+    BG_REQUIRE(a.ksplit >= 1 && (a.ksplit == 1 || (pre && a.G == 1 && a.kws)), "decode attention: a key split needs the attention-only kernel, one sequence per workgroup and a workspace");
+    dim3 grid(a.H, a.B / a.G, a.ksplit);
     // algorithmic bytes of one launch: K and V rows of the context, once each; the shared prefix once per group
     const double n_host = a.d_n ? a.n + a.n_hint : a.n;
     const double eb = a.kv_dtype == 0 ? 4 : 2;
@@ -656,6 +667,11 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
 #undef AF_LAUNCH_G
 #undef AF_LAUNCH
     LAUNCH_CHECK();
+    if (a.ksplit > 1) {   // merge the key ranges: o / l + ln1(x)
+        DecodeAttnArgs c;
+        c.R = a.xn; c.ldr = a.D; c.O = a.out; c.ldo = a.ldo; c.B = a.B; c.H = a.H;
+        launch_decode_attention_combine(c, a.kws, a.ksplit, s);
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------- (ln +) skinny GEMM

@@ -205,6 +205,7 @@ struct DecodeAttnArgs {
 int decode_attention_splits(int B, int H, int n_max);
 size_t decode_attention_ws_bytes(int B, int H, int S);
 void launch_decode_attention_ws(const DecodeAttnArgs& a, float* ws, int S, hipStream_t s);
+void launch_decode_attention_combine(const DecodeAttnArgs& a, const float* ws, int S, hipStream_t s);   // o / l (+ R) from [B][H][S][66] partials
 
 // ---------------------------------------------------------------- decode_fused.hip (Route A decode step, three launches per layer)
 // A [M, D] fp32 matrix that may still be "in flight" as split-K partial sums: element (m, c) = base[m*ld + c] + bias[c] + sum_k partial[k*pstride + m*pld + c]
@@ -239,6 +240,10 @@ struct ArAttnFusedArgs {
     // cross-kernel prefetch: the weight images the NEXT two launches of the layer stream (ln2 + MLP-up, MLP-down).  Every workgroup pulls "its" 1/nwg slice of each
     // through the L2 of its XCD while its K/V walk drains (LDS-DMA into a scratch sink: no registers) - workgroup j of the next launch runs on the same XCD (j % 8)
     // and finds its 64 KB slice in L2 instead of starting with one cold HBM burst.  pf_bytes = 0: off
+    // key split (attention-only kernel, G = 1, few sequences): gridDim.z = ksplit workgroups share one (sequence, head), each walks a contiguous range of the
+    // list positions and leaves (max, sum, unnormalised output[64]) in kws [B][H][ksplit][66]; launch_ar_attn_fused then runs the combine kernel (+ residual)
+    int ksplit = 1;
+    float* kws = nullptr;
     const void* pf_ptr[2] = {nullptr, nullptr};
     long pf_bytes[2] = {0, 0};
     int has_bias = 0;                  // filled in by the launcher
