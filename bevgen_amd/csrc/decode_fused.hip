@@ -248,7 +248,9 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
         // (key split: this workgroup's share of the list positions; gridDim.z == 1 -> all of them)
         const int ksl = (int)gridDim.z, kz = (int)blockIdx.z;
         const int p_lo = (int)((long)kz * n_pos / ksl), p_hi = (int)((long)(kz + 1) * n_pos / ksl);
-        Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, p_lo, p_hi, wave, kslot, n, sub, bias_s, q, m, l, acc);
+        // (the dense walk strides over whole 256-key spans: its end must be clipped to this share's last key, or the next share's keys are counted twice)
+        const int k_hi = SP ? n : min(n, 16 * p_hi);
+        Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, p_lo, p_hi, wave, kslot, k_hi, sub, bias_s, q, m, l, acc);
         wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
         if (kslot == 0) {
             if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
