@@ -351,7 +351,7 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
         BG_REQUIRE(ar_attn_fused_supported(B, G, D, H), "op_ar_attn_fused: unsupported shape B=%d G=%d D=%d H=%d", B, G, D, H);
         BG_REQUIRE(!layout || (block >= 1 && L % block == 0), "op_ar_attn_fused: Lmax %d is not a multiple of the block size %d", L, block);
         const int nb = layout ? L / block : 0, cld = (int)cdiv(L, 16) + 1;
-        ctx->arena.reserve((size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * cld * 2 + (size_t)3 * D * D * 2 + (split ? skinny_packed_floats(3 * D, D) * 4 + (size_t)B * 4 * D * 4 : 0) + 12 * 256);
+        ctx->arena.reserve((size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * cld * 2 + (size_t)3 * D * D * 2 + (split ? skinny_packed_floats(3 * D, D) * 4 + (size_t)B * 4 * D * 4 + (size_t)B * H * (split > 1 ? split : 0) * 66 * 4 : 0) + 14 * 256);
         ctx->arena.reset();
         ArAttnFusedArgs a;
         a.x.base = x; a.x.ld = D;
@@ -400,6 +400,11 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
             pq.M = B; pq.N = 3 * D; pq.K = D; pq.ksplit = 1;
             launch_skinny_fused(pq, s);
             a.qkv = qkv; a.xn = xn;
+            if (split > 1) {   // split = k > 1: the attention-only kernel with its key walk cut into k ranges (one sequence per workgroup)
+                BG_REQUIRE(G == 1, "op_ar_attn_fused: a key split needs G = 1");
+                a.ksplit = split;
+                a.kws = ctx->arena.get<float>((size_t)B * H * split * 66);
+            }
         }
         launch_ar_attn_fused(a, s);
     });

@@ -358,6 +358,37 @@ def test_ar_attn_fused_operator_f16_weights(gpu_ctx, split):
     assert rel(out.cpu().double(), ref) < 2e-5
 
 
+@pytest.mark.parametrize("kv", ["f32", "f16"])
+@pytest.mark.parametrize("B,H,n,Lmax,sparse,ks", [(1, 16, 2368, 2368, False, 4), (1, 16, 1301, 2368, True, 4), (2, 16, 700, 1024, False, 2), (1, 4, 40, 512, False, 4),
+                                                   (1, 4, 1, 128, False, 3), (3, 8, 511, 512, True, 2)])
+def test_ar_attn_key_split_operator(gpu_ctx, B, H, n, Lmax, sparse, ks, kv):
+    """The attention-only kernel with its key walk cut into ks ranges (one- and two-sequence calls: more workgroups than (sequence, head) pairs) + the combine
+    kernel, against fp64: long and short contexts (fewer chunks than ranges, n = 1), dense interleaved walk (range ends inside a 256-key span) and chunk lists."""
+    D = H * 64
+    g = torch.Generator().manual_seed(B * 77 + n)
+    x = torch.randn(B, D, generator=g)
+    ln_w, ln_b = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.1
+    wqkv = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bqkv = torch.randn(3 * D, generator=g) * 0.1
+    kc, vc = torch.randn(B, H, Lmax, 64, generator=g), torch.randn(B, H, Lmax, 64, generator=g)
+    bias = torch.randn(Lmax, Lmax, generator=g)
+    mask = layout = None
+    if sparse:
+        mask = (torch.rand(Lmax, Lmax, generator=g) > 0.2).float()
+        layout = (torch.rand(H, Lmax // 16, Lmax // 16, generator=g) < 0.4).long()
+        mask[:, 0] = 1
+        layout[:, :, 0] = 1
+    if kv == "f16":
+        kc, vc = kc.half().float(), vc.half().float()
+    ref, k_new, _ = _ar_attn_reference(x, None, None, ln_w, ln_b, wqkv, bqkv, kc, vc, n, bias, mask, layout, 16, 1, 0)
+    cdt = torch.float16 if kv == "f16" else torch.float32
+    dkc, dvc = dev(kc.to(cdt)), dev(vc.to(cdt))
+    out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dkc, dvc, n, bias=dev(bias), attn_mask=None if mask is None else dev(mask),
+                                   layout=None if layout is None else dev(layout), block=16, kv_dtype=1 if kv == "f16" else 0, split=ks)
+    assert rel(out.cpu().double(), ref) < (2e-3 if kv == "f16" else 2e-5)
+    assert rel(dkc[:, :, n - 1].float().cpu().double(), k_new) < (1e-3 if kv == "f16" else 1e-5)
+
+
 @pytest.mark.parametrize("M,N,K,ln,gelu", [(16, 4096, 1024, True, True), (16, 1024, 4096, False, False), (64, 1024, 1024, True, False), (5, 1000, 1024, True, False),
                                            (16, 256, 256, True, True), (33, 512, 2048, False, False)])
 def test_ln_gemm_operator(gpu_ctx, M, N, K, ln, gelu):
