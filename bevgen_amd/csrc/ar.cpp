@@ -37,12 +37,13 @@ bool split_supported(const Ctx& c, int B) {
     const int D = c.D;
     return skinny_fused_supported(B, 3 * D, D, true) && (c.cfg.decode_weight_dtype != BEVGEN_W_F16 || skinny_fused_f16_ok(3 * D, D, true));
 }
-// BEVGEN_DECODE_AUTO: the split layer for one or two sequences (layout groups) per call, else the fused one.  Same box, config 4, fp32, full decodes: B = 1 split 1.09 /
-// fused 1.27 ms per step, B = 2 1.15 / 1.23, B = 4 1.22 / 1.20, B = 8 1.34 / 1.24, B = 16 1.47 / 1.42 - with sixteen workgroups per layer the fused kernel's per-head
-// GEMV cannot pull the 12.6 MB of q/k/v weights fast enough; the projection kernel spreads them over 192 workgroups.
+// BEVGEN_DECODE_AUTO: the split layer for up to four sequences (layout groups) per call, else the fused one.  Same box, config 4, fp32, full decodes, ms per step
+// split / fused: B = 1 0.99 / 1.28, B = 2 1.04 / 1.24, B = 3 1.14 / 1.22, B = 4 1.17 / 1.21, B = 6 1.27 / 1.21, B = 8 1.34 / 1.24, B = 16 1.47 / 1.42.  With 16-64
+// workgroups per layer the fused kernel's per-head GEMV cannot pull the 12.6 MB of q/k/v weights fast enough and a workgroup's 1.2 MB K/V range streams at one CU's
+// rate; the projection kernel spreads the weights over 192 workgroups and the attention-only kernel cuts each key walk into up to four ranges.
 int effective_decode_path(const Ctx& c, int B, int G) {
     if (c.cfg.decode_path != BEVGEN_DECODE_AUTO) return c.cfg.decode_path;
-    return (B / std::max(G, 1) <= 2 && split_supported(c, B)) ? BEVGEN_DECODE_SPLIT : BEVGEN_DECODE_FUSED;
+    return (B / std::max(G, 1) <= 4 && split_supported(c, B)) ? BEVGEN_DECODE_SPLIT : BEVGEN_DECODE_FUSED;
 }
 
 bool fused_path(const Ctx& c, int B, int G) {
@@ -351,8 +352,8 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
             a.qkv = qkv; a.xn = xn;
             // one or two sequences: 16-32 workgroups cannot pull a 1.2 MB K/V range each at the chip's rate - split the key walk over more of them (the partial
             // states live in the per-operator path's workspace, sized for at least this many splits)
-            if (st.G == 1 && Bc * H < 64) {
-                const int ks = std::min(std::min(4, 64 / (Bc * H)), w.splits);
+            if (st.G == 1 && Bc * H < 128) {
+                const int ks = std::min(std::min(4, 128 / (Bc * H)), w.splits);
                 if (ks > 1) { a.ksplit = ks; a.kws = w.dec_ws + (size_t)r0 * H * w.splits * 66; }   // (per chain: its sequences' slots)
             }
         } else {

@@ -73,9 +73,9 @@ typedef struct bevgen_cfg {
                                                           BEVGEN_DECODE_PER_OP (one kernel per operator: the round-1 path, kept as the A/B reference) or
                                                           BEVGEN_DECODE_SPLIT (four launches per layer: LayerNorm + QKV projection of the whole batch as one MFMA kernel that
                                                           reads the weight once, then the decode-attention kernel proper = the K/V stream and nothing else) or
-                                                          BEVGEN_DECODE_AUTO (what the Python host asks for: SPLIT for one or two sequences / layout groups per call - the
-                                                          interactive single-scene caller, where 16 workgroups per layer cannot pull the q/k/v weights fast enough:
-                                                          1.09 vs 1.27 ms/step at B = 1 - else FUSED) */
+                                                          BEVGEN_DECODE_AUTO (what the Python host asks for: SPLIT, with the key walk of every (sequence, head) cut into up to
+                                                          four ranges, for up to four sequences / layout groups per call - the interactive single-scene caller, where 16-64
+                                                          workgroups per layer cannot pull weights and K/V fast enough: 0.99 vs 1.28 ms/step at B = 1 - else FUSED) */
     int32_t decode_weight_dtype;                       /* Route A projection weights (q/k/v, MLP, head): BEVGEN_W_F32 (default) or BEVGEN_W_F16: bevgen_finalize rounds them to
                                                           fp16-representable values (prefill and decode then use the same model: the reference's Route A runs fp16,
                                                           sparse_self_attention.py:127) and the decode step streams the 2-byte copies: half the weight traffic */
