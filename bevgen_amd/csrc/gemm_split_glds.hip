@@ -42,19 +42,34 @@ __device__ __forceinline__ void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// at most n (runtime, capped at MAXN) k-tiles of DMA wave-instructions each may stay in flight
+template <int DMA, int MAXN>
+__device__ __forceinline__ void wait_tiles(int n) {
+    if constexpr (MAXN <= 0) wait_vmcnt<0>();
+    else {
+        if (n >= MAXN) wait_vmcnt<MAXN * DMA>();
+        else wait_tiles<DMA, MAXN - 1>(n);
+    }
+}
 
 // W16: the B operand (a weight matrix) is f16-representable, its low plane is zero: the product is  b_hi a_hi + 2^-11 b_hi a_lo  - TWO MFMAs per
 // k-step pair instead of three, and no low-plane fragment reads (weight_dtype = f16 contexts)
 // KS: the k range is cut into gridDim.z slices (small-M problems; a template flag so that the throughput instantiations carry none of it - the 256-row convolution
 // variant sits at the register limit and spilled 300 VGPRs with the slice arithmetic compiled in)
-template <int MODE, int WM, int S, bool W16 = false, bool KS = false>
-__global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
+// TI: 32-row MFMA tiles per wave along M.  2 = the 64x64 wave patch.  1 = a 32x64 patch, twice the waves on the same block tile: the shape of a block that has its CU
+// to itself (one or two scenes: fewer blocks than CUs).  With four waves every SIMD holds ONE wave, and the ~70 issue cycles of each of its 8 DMA instructions per k-tile
+// are cycles in which that SIMD's matrix pipe has nothing queued: 0.55 us per k-tile measured against 0.32 us of MFMAs (tools/gemm_small_probe.py).  Eight waves halve
+// both the MFMAs and the DMA instructions of a wave and give every SIMD a second wave to run while one issues.
+template <int MODE, int WM, int S, bool W16 = false, bool KS = false, int TI = 2>
+__global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
     constexpr int TBM = WM * 64;                 // block rows
-    constexpr int NW = WM * 2;                   // waves
+    constexpr int NW = WM * 4 / TI;              // waves
+    constexpr int WROWS = TI * 32;               // rows of a wave's patch
+    constexpr int NAJ = TBM / 8 / NW;            // 8-row A pieces per wave
     constexpr int NBJ = 16 / NW;                 // 8-row B pieces per wave
     constexpr int AREGION = TBM * 2 * GBK;       // halves: TBM rows x (32 hi | 32 lo)
     constexpr int STAGE_H = AREGION + GBN * 2 * GBK;  // halves per stage
-    constexpr int DMA = 4 + NBJ;                      // DMA wave-instructions per k-tile
+    constexpr int DMA = NAJ + NBJ;                    // DMA wave-instructions per k-tile
     extern __shared__ __attribute__((aligned(1024))) _Float16 smem_g[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,13 +85,13 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     const _Float16* Bp = reinterpret_cast<const _Float16*>(g.B_hi);
 
     // ---- DMA descriptors of this lane.  One DMA piece = 8 rows x 128 B (hi|lo of one k-block): lane -> row lane>>3, 16-byte position lane&7.
-    // The wave owns 32 A rows (4 pieces) and 128/NW B rows (NBJ pieces).
+    // The wave owns TBM/NW A rows (NAJ pieces) and 128/NW B rows (NBJ pieces).
     // MODE_PLAIN: buffer_load ... lds with address = resource base + scalar k offset + a per-lane 32-bit byte offset that never changes:
     // no per-iteration address VALU and 6 VGPRs of DMA state.  Rows outside the problem are CLAMPED to the last row: they only feed
     // accumulator rows / columns that the epilogue never stores.
     // MODE_CONV3: the A address depends on the tap (and taps inside the zero padding read a zero page), so it is rebuilt per piece.
-    unsigned a_off[4], b_off[NBJ];
-    int a_img[4], a_yx[4];   // MODE_CONV3: image index and (y << 16 | x) of the output pixel; rows past M have a_img >= number of images
+    unsigned a_off[NAJ], b_off[NBJ];
+    int a_img[NAJ], a_yx[NAJ];   // MODE_CONV3: image index and (y << 16 | x) of the output pixel; rows past M have a_img >= number of images
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
         const int R = wave * (8 * NBJ) + j * 8 + (lane >> 3);   // B row inside the tile
@@ -85,8 +100,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         b_off[j] = (unsigned)(((long)n * 2 * g.ldb + c * 8) * 2);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int R = wave * 32 + j * 8 + (lane >> 3);   // A row inside the tile
+    for (int j = 0; j < NAJ; ++j) {
+        const int R = wave * (8 * NAJ) + j * 8 + (lane >> 3);   // A row inside the tile
         const int c = (lane & 7) ^ ((R >> 1) & 7);
         const int m = m0l + R;
         if (MODE == MODE_PLAIN) {
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ap), 0, MODE == MODE_CONV3 ? g.a_bytes : -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bp), 0, -1, 0x00020000);
     auto issue_a = [&](int stage, int j) {
-        _Float16* sa = smem_g + stage * STAGE_H + (wave * 32 + j * 8) * 2 * GBK;
+        _Float16* sa = smem_g + stage * STAGE_H + (wave * (8 * NAJ) + j * 8) * 2 * GBK;
         if (MODE == MODE_CONV3) {
             // scalar part (tap of this k-tile) + a dozen 32-bit VALU per piece; taps inside the zero padding (and rows past M) use an offset
             // beyond the resource's num_records: the buffer load returns zeros and the DMA writes them (checked on gfx950)
@@ -132,10 +147,14 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         for (int j = 0; j < NBJ; ++j) glds16_buf(b_rsrc, b_off[j], k_issue * 4, sb + j * 8 * 2 * GBK);
         k_issue += GBK;
     };
-
-    f32x16 accM[2][2], accC[2][2];
+    auto issue_a_half = [&](int stage, int half) {   // the A pieces in two groups (interleaved with the MFMA groups of a phase)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int j = half * (NAJ / 2); j < (half + 1) * (NAJ / 2); ++j) issue_a(stage, j);
+    };
+
+    f32x16 accM[TI][2], accC[TI][2];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int ra = wm * 64 + i * 32 + r, rb = wn * 64 + i * 32 + r;
+            const int ra = wm * WROWS + (i < TI ? i : 0) * 32 + r, rb = wn * 64 + i * 32 + r;
             a_rd[i][ks] = ra * 2 * GBK + (((ks * 2 + h) ^ ((ra >> 1) & 7)) << 3);
             b_rd[i][ks] = AREGION + rb * 2 * GBK + (((ks * 2 + h) ^ ((rb >> 1) & 7)) << 3);
         }
@@ -156,40 +175,40 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         const _Float16* st = smem_g + stage * STAGE_H;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            f.ah[i] = *reinterpret_cast<const half8*>(st + a_rd[i][ks]);
-            f.al[i] = *reinterpret_cast<const half8*>(st + (a_rd[i][ks] ^ 32));
+            if (i < TI) {
+                f.ah[i] = *reinterpret_cast<const half8*>(st + a_rd[i][ks]);
+                f.al[i] = *reinterpret_cast<const half8*>(st + (a_rd[i][ks] ^ 32));
+            }
             f.bh[i] = *reinterpret_cast<const half8*>(st + b_rd[i][ks]);
             if (!W16) f.bl[i] = *reinterpret_cast<const half8*>(st + (b_rd[i][ks] ^ 32));
         }
     };
     auto mma_main = [&](const Frag& f) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], accM[i][j], 0, 0, 0);
     };
     auto mma_c1 = [&](const Frag& f) {
         if (W16) return;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], accC[i][j], 0, 0, 0);
     };
     auto mma_c2 = [&](const Frag& f) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], accC[i][j], 0, 0, 0);
     };
 
     const int nk = nk_all / ksl + (kz < nk_all % ksl ? 1 : 0);
-    // ---- prologue: tiles 0..2 in flight, tile 0 landed, F0 of tile 0 on its way
+    // ---- prologue: tiles 0..S-1 in flight, tile 0 landed, F0 of tile 0 on its way
 #pragma unroll
     for (int s = 0; s < S; ++s)
-        if (s < nk) { issue_a(s, 0); issue_a(s, 1); issue_a(s, 2); issue_a(s, 3); issue_b(s); }
-    if (S >= 3 && nk >= 3) wait_vmcnt<2 * DMA>();
-    else if (nk >= 2) wait_vmcnt<DMA>();
-    else wait_vmcnt<0>();
+        if (s < nk) { issue_a_half(s, 0); issue_a_half(s, 1); issue_b(s); }
+    wait_tiles<DMA, S - 1>(nk - 1);   // tile 0 landed; the other tiles of the prologue stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     Frag f0, f1;
@@ -212,18 +231,18 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         BG_FENCE();
         mma_main(f0);
         BG_FENCE();
-        if (WHERE == 2) { issue_a(stage_prev, 0); issue_a(stage_prev, 1); BG_FENCE(); }
+        if (WHERE == 2) { issue_a_half(stage_prev, 0); BG_FENCE(); }
         mma_c1(f0);
         BG_FENCE();
-        if (WHERE == 2) { issue_a(stage_prev, 2); issue_a(stage_prev, 3); BG_FENCE(); }
+        if (WHERE == 2) { issue_a_half(stage_prev, 1); BG_FENCE(); }
         mma_c2(f0);
         if (WHERE == 2) { BG_FENCE(); issue_b(stage_prev); }
-        // this wave is done reading tile kt; tile kt+1 must be complete (own pieces; tile kt+2 may stay in flight).  The scheduling fences keep
+        // this wave is done reading tile kt; tile kt+1 must be complete (own pieces; tiles kt+2 .. kt+S-1 may stay in flight).  The scheduling fences keep
         // the MFMAs of F0 above the waits (they are not memory operations, nothing else would stop them sinking below) and F1's below.
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (S >= 3 && (STEADY || kt + 2 < nk)) wait_vmcnt<DMA>();
-        else wait_vmcnt<0>();
+        if (STEADY) wait_vmcnt<(S - 2) * DMA>();
+        else wait_tiles<DMA, S - 2>(nk - kt - 2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -231,10 +250,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         __builtin_amdgcn_sched_barrier(0);
         fetch(f0, stage_next, 0);        // unconditional (after the last tile it reads a stale stage and is never used): keeps the wait counters exact
         BG_FENCE();
-        if (WHERE == 1) { issue_a(stage, 0); issue_a(stage, 1); BG_FENCE(); }
+        if (WHERE == 1) { issue_a_half(stage, 0); BG_FENCE(); }
         mma_c1(f1);
         BG_FENCE();
-        if (WHERE == 1) { issue_a(stage, 2); issue_a(stage, 3); BG_FENCE(); }
+        if (WHERE == 1) { issue_a_half(stage, 1); BG_FENCE(); }
         mma_c2(f1);
         BG_FENCE();
         if (WHERE == 1) { issue_b(stage); BG_FENCE(); }
@@ -260,8 +279,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         // LayerNorm of the A rows, applied to the finished sums (GemmArgs::ln_*): the planes hold x * gamma, so  LN(x) W^T = rstd acc - (mean rstd) colsum.  In place:
         // every epilogue below then reads (accM + 0) as if the GEMM had run on normalised rows.
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = min(m0 + wm * 64 + i * 32 + r, g.M - 1);
+        for (int i = 0; i < TI; ++i) {
+            const int m = min(m0 + wm * WROWS + i * 32 + r, g.M - 1);
             const float2 st = *reinterpret_cast<const float2*>(g.ln_stats + 2 * (long)m);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -286,8 +305,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         _Float16* Ql = reinterpret_cast<_Float16*>(g.epi_lo);
         const int head = (n0 + wn * 64) >> 6;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * 64 + i * 32 + r;
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * WROWS + i * 32 + r;
             float v[2][16];
             float ss = 0.f;
 #pragma unroll
@@ -331,8 +350,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         const int head = (is_v ? ncol - HD : ncol) >> 6;
         const _Float16* aux = reinterpret_cast<const _Float16*>(g.epi_aux);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * 64 + i * 32 + r;
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * WROWS + i * 32 + r;
             const int mc = min(m, g.M - 1);
             const int bb = mc / g.epi_rows, nk = mc - bb * g.epi_rows;
             float v[2][16];
@@ -398,8 +417,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         // (half the bytes of the raw projection, and the separate GEGLU pass over [M, N] disappears: its LayerNorm half runs on the result).
         float* C = g.C;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * 64 + i * 32 + r;
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * WROWS + i * 32 + r;
             if (m >= g.M) continue;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
@@ -418,8 +437,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         if (g.ln_gamma) {
             // LayerNorm producer (GemmArgs::ln_*): the wave's 32 output columns of a row are one statistics group; planes of (h * gamma) for the down-projection
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = m0 + wm * 64 + i * 32 + r;
+            for (int i = 0; i < TI; ++i) {
+                const int m = m0 + wm * WROWS + i * 32 + r;
                 const int o0 = (n0 >> 1) + wn * 32;
                 float v[16];
                 float sum = 0.f;
@@ -459,8 +478,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     if (KS && ksl > 1) {   // raw tile sums of this k slice; launch_splitk_reduce adds the slices in order and applies the epilogue
         float* P = g.kpart + (long)kz * g.M * g.N;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * 64 + i * 32 + r;
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * WROWS + i * 32 + r;
             if (m >= g.M) continue;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -481,8 +500,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
         const float* Rp = g.R;
         const int ncol = n0 + wn * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * 64 + i * 32 + r;
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * WROWS + i * 32 + r;
             const int mr = min(m, g.M - 1);
             float v[2][16];
             float sum = 0.f;
@@ -533,8 +552,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2 && S == 2) ? 2 : 1) void gemm_sp
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!Rp || (reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + r;
+    for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * WROWS + i * 32 + r;
         if (m >= g.M) continue;
         const float bm = g.bias_m ? g.bias_m[m] : 0.f;
 #pragma unroll
@@ -607,7 +626,16 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU
     const int wm = force_wm ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
     const int tbm = wm * 64;
-    const int stages = wm == 4 ? 3 : 2;
+    // ... unless even those leave CUs without a second block (a batch of one or two scenes): then nothing shares the CU, and the block becomes eight waves with
+    // 32x64 patches on a four-stage ring (three k-tiles in flight instead of one; the kernel's TI note).  Measured on the Route M step (tools/ab_env_m.sh): one scene
+    // 236 -> 199 ms, two scenes 303 -> 270 ms; at three and four scenes (288 / 384 blocks: two four-wave blocks per CU) the eight-wave block is 2-3 % slower.
+    // $BEVGEN_GEMM_STAGES = 2 | 8 pins the small-problem shape for A/B runs and tests (2: four waves, two stages; 8: eight waves, four stages)
+    static const int stages_env = getenv("BEVGEN_GEMM_STAGES") ? atoi(getenv("BEVGEN_GEMM_STAGES")) : 0;
+    const bool lone = g.mode == MODE_PLAIN && (long)cdiv(g.N, GBN) * cdiv(g.M, 128) * g.ksplit <= 256;
+    int shape = lone ? 8 : 2;
+    if (g.mode == MODE_PLAIN && (stages_env == 2 || stages_env == 8)) shape = stages_env;
+    const int stages = wm == 4 ? 3 : (shape == 2 ? 2 : 4);
+    const bool thin = wm == 2 && shape == 8;
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
     dim3 grid(cdiv(g.N, GBN), cdiv(g.M, tbm), g.ksplit);
@@ -625,6 +653,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2);
 #undef BG_SET
         attr_set = true;
     }
@@ -635,7 +667,15 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, true>), grid, dim3(THREADS), lds, stream, g);    \
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, false>), grid, dim3(THREADS), lds, stream, g);               \
     } while (0)
-    if (g.ksplit > 1) {
+    if (thin) {
+        if (g.ksplit > 1) {
+            if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), grid, dim3(512), lds, stream, g);
+            else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), grid, dim3(512), lds, stream, g);
+        } else {
+            if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), grid, dim3(512), lds, stream, g);
+            else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, false, 1>), grid, dim3(512), lds, stream, g);
+        }
+    } else if (g.ksplit > 1) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), grid, dim3(256), lds, stream, g);
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), grid, dim3(256), lds, stream, g);
     } else if (wm == 2) {

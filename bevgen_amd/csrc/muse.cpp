@@ -30,17 +30,18 @@ struct MuseWs {
 // Low-latency path (one or two scenes per call, scripts/interactive_editing.py:273-277): a [rows, D] x [D, D] projection is only cdiv(rows, 128) * D / 128 tiles -
 // 96 workgroups at one six-view scene, on 256 CUs.  Its k range is cut into slices until the grid covers the chip; the slices' partial tiles are added in a fixed
 // order (tokens stay identical run to run, and identical to the unsplit path up to fp32 summation order - checked against the B = 16 path in the tests).
-// How many slices: measured at one six-view scene (rows = 1536, profiles/r03_b1_*): a [1536, 1024] x [1024, 1024] projection costs 12 us of fixed time (dispatch,
-// pipeline fill from cold operands, store tail) + 0.62 us per k-tile; every extra slice shortens the loop but adds its share of a 7 us reduce launch, so two
-// slices are the optimum (step 257 -> 241 ms; 3..5 slices 253-256, 6 slices 287) - the small-batch step is bound by the fixed cost of its ~280 dependent
-// kernels per forward, not by occupancy.
+// How many slices (measured at one six-view scene, rows = 1536, tools/gemm_small_probe.py + profiles/r03_gemm_small_*.txt): with the eight-wave small-problem block of
+// gemm_split_glds.hip a [1536, 1024] x [1024, K] projection costs 7.6 us of fixed time (dispatch, pipeline fill from cold operands, store tail) + 0.43 us per k-tile
+// on 96 CUs.  A second slice halves the loop but adds a 6.4 us reduce launch and gives up the fused epilogues (q preparation): a wash at K = 1024 (21.4 vs 20.9 us),
+// a clear gain for the feed-forward down-projection (K = 5504: 82 -> 51 us).  So: two slices from K = 2048 up, none below.  (Round-3 history: with the four-wave
+// block - 12 us + 0.62 us per k-tile - two slices everywhere were the optimum, step 257 -> 241 ms.)
 constexpr int KSPLIT_MAX = 6;
 int ksplit_env() { static const int v = getenv("BEVGEN_KSPLIT") ? atoi(getenv("BEVGEN_KSPLIT")) : 0; return v; }
 int pick_ksplit(long rows, int N, int K) {
     if ((long)cdiv(rows, 256) * cdiv(N, 128) >= 256) return 1;          // the 256-row tiling already fills the chip
     const long tiles = (long)cdiv(rows, 128) * cdiv(N, 128);
     if (tiles >= 160) return 1;
-    int s = 2;
+    int s = K >= 2048 ? 2 : 1;
     if (ksplit_env() > 0) s = std::min(KSPLIT_MAX, ksplit_env());
     while (s > 1 && K / 32 < 2 * s) --s;
     return s;
@@ -60,7 +61,7 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
     f += rows * 2 * c.F + rows * c.Fpad;
     f += rows * (c.V + 1);               // logits, scores (generate)
     f += rows * (2 * (size_t)(c.Fpad / 32) + 2) + 64;   // LayerNorm group statistics + merged row statistics
-    if (pick_ksplit((long)rows, c.D, c.D) > 1) f += (size_t)KSPLIT_MAX * rows * c.D;   // split-K partial tiles (small batches only)
+    if (std::max(pick_ksplit((long)rows, c.D, c.D), pick_ksplit((long)rows, c.D, c.Fpad)) > 1) f += (size_t)KSPLIT_MAX * rows * c.D;   // split-K partial tiles (small batches only)
     return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256;
 }
 
@@ -132,7 +133,7 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.g = a.get<float>((size_t)w.rows * c.Fpad);
     w.ln_part = a.get<float>((size_t)w.rows * 2 * (c.Fpad / 32));
     w.ln_stats = a.get<float>((size_t)w.rows * 2);
-    w.kpart = pick_ksplit(w.rows, D, D) > 1 ? a.get<float>((size_t)KSPLIT_MAX * w.rows * D) : nullptr;
+    w.kpart = std::max(pick_ksplit(w.rows, D, D), pick_ksplit(w.rows, D, c.Fpad)) > 1 ? a.get<float>((size_t)KSPLIT_MAX * w.rows * D) : nullptr;
     HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
     HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
 

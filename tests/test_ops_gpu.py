@@ -447,3 +447,40 @@ def test_gemm_split_precision_split_k(gpu_ctx, M, N, K):
         outs.append(out.cpu())
     assert rel(outs[0].double(), ref) < 2e-6
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("shape", ["2", "8"])
+def test_gemm_small_problem_block_shapes(shape):
+    """The LDS-DMA GEMM picks its small-problem block by the grid size (eight waves with 32x64 patches on a four-stage ring when every block has a CU to itself,
+    four waves on two stages otherwise).  $BEVGEN_GEMM_STAGES pins one of them (read once per process, hence the subprocess): both must give the fp64 product on the
+    same shapes - ragged M and N, one k-tile, fewer k-tiles than ring stages, split-K, the f16-weights form."""
+    import subprocess, sys, os
+    code = r'''
+import math, torch, sys
+sys.path.insert(0, %r)
+from bevgen_amd.runtime import Context, _ptr, _stream
+ctx = Context(None)
+worst = 0.0
+for (M, N, K) in [(128, 128, 32), (200, 136, 64), (333, 264, 96), (777, 1024, 1024), (1536, 1024, 2752), (3072, 1024, 1024)]:
+    for mode in (3, 4, 5):
+        if mode == 5 and K // 32 < 6:
+            continue
+        g = torch.Generator().manual_seed(M + N + K)
+        a = torch.randn(M, K, generator=g) * 3.0
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        if mode == 4:
+            w = w.half().float()
+        b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g)
+        ref = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double()) + r.double()
+        da, dw, db, dr = a.cuda(), w.cuda(), b.cuda(), r.cuda()
+        out = torch.empty(M, N, device="cuda")
+        ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(da), _ptr(dw), _ptr(db), _ptr(dr), _ptr(out), M, N, K, 1, mode, _stream()))
+        err = float((out.cpu().double() - ref).norm() / ref.norm())
+        worst = max(worst, err)
+        assert err < 2e-6, (M, N, K, mode, err)
+print("worst", worst)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BEVGEN_GEMM_STAGES=shape)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "worst" in res.stdout
