@@ -75,6 +75,7 @@ SIGNATURES = {
     "bevgen_op_layernorm": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "bevgen_op_geglu_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "bevgen_op_attention": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "bevgen_op_attention_ex": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p, _p]),
     "bevgen_op_decode_attention": (_i, [_p, _p, _p, _p, _i, _p, _i, _p, _i, _l, _i, _i, _i, _i, _f, _p, _p]),
     "bevgen_op_ar_attn_fused": (_i, [_p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "bevgen_op_conv3x3": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

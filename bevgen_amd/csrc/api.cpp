@@ -286,6 +286,11 @@ int bevgen_op_geglu_layernorm(bevgen_ctx* ctx, const float* h, const float* gamm
 
 int bevgen_op_attention(bevgen_ctx* ctx, const float* q, const float* k, const float* v, const float* bias, int ldbias, int B, int H, int Nq, int Nk_pad, float scale,
                         float* out, void* stream) {
+    return bevgen_op_attention_ex(ctx, q, k, v, bias, ldbias, B, H, Nq, Nk_pad, scale, 1, out, stream);
+}
+
+int bevgen_op_attention_ex(bevgen_ctx* ctx, const float* q, const float* k, const float* v, const float* bias, int ldbias, int B, int H, int Nq, int Nk_pad, float scale,
+                           int key_splits, float* out, void* stream) {
     return guarded(ctx, [&] {
         if (ctx->cfg.precision == BEVGEN_PRECISION_F16X3) {
             // the split-precision flash-attention kernel of Route M on caller-supplied fp32 operands: operand images and the packed bias are built here
@@ -293,7 +298,9 @@ int bevgen_op_attention(bevgen_ctx* ctx, const float* q, const float* k, const f
             hipStream_t s = (hipStream_t)stream;
             const size_t nq = (size_t)B * H * Nq * 64, nk = (size_t)B * H * Nk_pad * 64;
             const size_t bpk = bias ? (size_t)attn_bias_packed_floats(Nq, Nk_pad) : 0, braw = bias ? (size_t)Nq * ldbias : 0;
-            ctx->arena.reserve((nq + 2 * nk) * 4 + (bpk + braw) * 4 + 8192);
+            BG_REQUIRE(key_splits >= 1 && key_splits <= 8 && Nk_pad / 32 >= key_splits, "op_attention: key_splits=%d out of range for Nk_pad=%d", key_splits, Nk_pad);
+            const size_t kws = key_splits > 1 ? (size_t)attn_split_ws_floats(B, H, Nq, key_splits) : 0;
+            ctx->arena.reserve((nq + 2 * nk) * 4 + (bpk + braw + kws) * 4 + 8192);
             ctx->arena.reset();
             _Float16* Qp = reinterpret_cast<_Float16*>(ctx->arena.alloc(nq * 4));
             _Float16* Kp = reinterpret_cast<_Float16*>(ctx->arena.alloc(nk * 4));
@@ -310,6 +317,7 @@ int bevgen_op_attention(bevgen_ctx* ctx, const float* q, const float* k, const f
                 sa.bias = b2; sa.bias_pk = pk; sa.ldbias = ldbias;
             }
             sa.bias_head_stride = 0;
+            if (key_splits > 1) { sa.ksplit = key_splits; sa.kws = reinterpret_cast<float*>(ctx->arena.alloc(kws * 4)); }
             sa.O = out; sa.Op = nullptr; sa.B = B; sa.H = H; sa.Nq = Nq; sa.Nk_pad = Nk_pad; sa.scale = scale * kLog2e;
             sa.o_bstride = (long)Nq * H * 64; sa.o_qstride = (long)H * 64; sa.o_hstride = 64;
             launch_attention_split(sa, s);

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     const int nqb = gridDim.x, total = nqb * gridDim.y * gridDim.z;
     const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
     const int vid = (total % 8 == 0) ? (lin % 8) * (total / 8) + lin / 8 : lin;
-    const int qblk = vid % nqb, head = (vid / nqb) % gridDim.y, b = vid / (nqb * gridDim.y);
+    const int qblk = vid % nqb, head = (vid / nqb) % gridDim.y, bz = vid / (nqb * gridDim.y);
+    const int b = a.ksplit > 1 ? bz / a.ksplit : bz, ks = a.ksplit > 1 ? bz - b * a.ksplit : 0;   // gridDim.z = B * ksplit
     const int qrow = qblk * 256 + wave * 32 + qi;
     const bool qvalid = qrow < a.Nq;
     const int qc = qvalid ? qrow : a.Nq - 1;
@@ -78,8 +79,12 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     const long qoff = ((long)b * a.H + head) * a.Nq * 64 + (long)qc * 64 + 8 * h;
     const long koff = ((long)(b / a.kv_group) * a.H + head) * (long)a.Nk_pad * 64;
     // (no bias: the launcher points bias_pk at a zero block with both steps 0 - unconditional loads, no select in the loop)
-    const float* Bp = a.bias_pk + (long)head * a.bias_head_stride + (long)(qblk * 8 + wave) * a.bias_pk_qb_stride + lane * 4;
     const int bstep = a.bias_pk_tile_step;
+    // this workgroup's key tiles [t_first, t_first + ntiles)
+    const int ntiles_all = a.Nk_pad / SKT;
+    const int t_first = (int)((long)ks * ntiles_all / a.ksplit);
+    const int ntiles = (int)((long)(ks + 1) * ntiles_all / a.ksplit) - t_first;
+    const float* Bp = a.bias_pk + (long)head * a.bias_head_stride + (long)(qblk * 8 + wave) * a.bias_pk_qb_stride + lane * 4 + (long)t_first * bstep;
 
     // q_hi, q_hi 2^-11, q_lo 2^-11
     half8 qh[4], qs[4], qls[4];
@@ -103,13 +108,13 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     int src_step, dst_off;
     if (grp == 0) {
         const int kr = st >> 3, kc = st & 7;
-        src_hi = a.Kh + koff + kr * 64 + kc * 8; src_lo = a.Kl + koff + kr * 64 + kc * 8;
         src_step = SKT * 64;
+        src_hi = a.Kh + koff + kr * 64 + kc * 8 + (long)t_first * src_step; src_lo = a.Kl + koff + kr * 64 + kc * 8 + (long)t_first * src_step;
         dst_off = kr * SKLD + kc * 8;
     } else {
         const int vr = st >> 2, vc = st & 3;
-        src_hi = a.VTh + koff + (long)vr * a.Nk_pad + vc * 8; src_lo = a.VTl + koff + (long)vr * a.Nk_pad + vc * 8;
         src_step = SKT;
+        src_hi = a.VTh + koff + (long)vr * a.Nk_pad + vc * 8 + (long)t_first * src_step; src_lo = a.VTl + koff + (long)vr * a.Nk_pad + vc * 8 + (long)t_first * src_step;
         dst_off = 2 * PP_PLANE + vr * SVLD + vc * 8;
     }
     uint4 rh, rl;
@@ -133,7 +138,6 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
         }
     };
 
-    const int ntiles = a.Nk_pad / SKT;
     gload_bias(0);
     gload(0);
     lstore(0);
@@ -251,6 +255,21 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
 #endif
 
     const float l_tot = l_run + xor32(l_run);
+    if (a.ksplit > 1) {   // partial result of this key range: unnormalised output row (relative to m_run), m_run, row sum
+        if (qvalid) {
+            float* wrow = a.kws + ((((long)ks * a.B + b) * a.H + head) * a.Nq + qrow) * 66;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * t + 8 * g + 4 * h;
+                    *reinterpret_cast<float2*>(wrow + d) = make_float2(oM[t][4 * g] + oC[t][4 * g] * kLoI, oM[t][4 * g + 1] + oC[t][4 * g + 1] * kLoI);
+                    *reinterpret_cast<float2*>(wrow + d + 2) = make_float2(oM[t][4 * g + 2] + oC[t][4 * g + 2] * kLoI, oM[t][4 * g + 3] + oC[t][4 * g + 3] * kLoI);
+                }
+            if (h == 0) *reinterpret_cast<float2*>(wrow + 64) = make_float2(m_run, l_tot);
+        }
+        return;
+    }
     const float inv = 1.f / l_tot;
     if (qvalid) {
         const long orow = (long)b * a.o_bstride + (long)qrow * a.o_qstride + (long)head * a.o_hstride;
@@ -303,8 +322,37 @@ int g_attn_variant = 1;   // 0 = the round-1 kernel, 1 = this file's kernel, 2 =
 void attn_lab_read_trace(unsigned long long* out) { HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_trace), sizeof(g_attn_trace))); }
 #endif
 
+// merge of the key ranges of a split launch: one thread per (batch, head, query row, 4 output columns); ranges in order (deterministic)
+__global__ __launch_bounds__(256) void attention_split_combine_kernel(AttnSplitArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.B * a.H * a.Nq * 16;
+    if (i >= total) return;
+    const int d = (int)(i & 15) * 4;
+    const long row = i >> 4;   // (b * H + head) * Nq + q
+    const int q = (int)(row % a.Nq), head = (int)((row / a.Nq) % a.H), b = (int)(row / ((long)a.Nq * a.H));
+    const long stride = (long)a.B * a.H * a.Nq * 66;
+    const float* w0 = a.kws + row * 66;
+    float m = kNegBig;
+    for (int k = 0; k < a.ksplit; ++k) m = fmaxf(m, w0[k * stride + 64]);
+    float l = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < a.ksplit; ++k) {
+        const float* w = w0 + k * stride;
+        const float sc = __builtin_amdgcn_exp2f(w[64] - m);
+        l = fmaf(w[65], sc, l);
+        const float2 v0 = *reinterpret_cast<const float2*>(w + d), v1 = *reinterpret_cast<const float2*>(w + d + 2);
+        o.x = fmaf(v0.x, sc, o.x); o.y = fmaf(v0.y, sc, o.y); o.z = fmaf(v1.x, sc, o.z); o.w = fmaf(v1.y, sc, o.w);
+    }
+    const float inv = 1.f / l;
+    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
+    if (a.Op) store_planes4(a.Op + ((long)b * a.Nq + q) * 2 * (a.H * 64), head * 64 + d, o);
+    else *reinterpret_cast<float4*>(a.O + (long)b * a.o_bstride + (long)q * a.o_qstride + (long)head * a.o_hstride + d) = o;
+}
+
 void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
     AttnSplitArgs a = a0;
+    if (a.ksplit < 1) a.ksplit = 1;
+    BG_REQUIRE(a.ksplit == 1 || (a.kws && a.Nk_pad / SKT >= a.ksplit), "attention_split: key split %d needs a workspace and at least one key tile per range", a.ksplit);
     BG_REQUIRE(a.Nk_pad % SKT == 0 && a.Nk_pad > 0, "attention_split: Nk_pad=%d must be a positive multiple of %d", a.Nk_pad, SKT);
     a.bias_pk_tile_step = 1024;
     a.bias_pk_qb_stride = (long)(a.Nk_pad / SKT) * 1024;
@@ -312,7 +360,7 @@ void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
         a.bias_pk = zero_block();
         a.bias_head_stride = 0; a.bias_pk_tile_step = 0; a.bias_pk_qb_stride = 0;
     }
-    const dim3 grid(cdiv(a.Nq, 256), a.H, a.B);
+    const dim3 grid(cdiv(a.Nq, 256), a.H, a.B * a.ksplit);
     ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk_pad * 64, s);
 #ifdef BEVGEN_ATTN_LAB
     if (g_attn_variant == 0) launch_attention_split_r1(a, s);
@@ -321,6 +369,11 @@ void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
 #endif
         hipLaunchKernelGGL(attention_split_kernel<false>, grid, dim3(512), 0, s, a);
     LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        const long total = (long)a.B * a.H * a.Nq * 16;
+        hipLaunchKernelGGL(attention_split_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        LAUNCH_CHECK();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ operator-level entry (bevgen_op_attention in a split-precision context)

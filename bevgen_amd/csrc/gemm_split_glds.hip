@@ -621,10 +621,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
                    "gemm_split_glds: bad LayerNorm-producer arguments (N=%d epi=%d)", g.N, g.epi);
     if (g.ln_stats) BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_colsum && g.N % 4 == 0 && g.ksplit <= 1, "gemm_split_glds: bad LayerNorm-consumer arguments");
     g.tile_band = 4;   // band height of the XCD-aware tile order (measured optimum for 256 x 128 tiles)
-    const int force_wm = 0;
+    static const int force_wm = getenv("BEVGEN_GEMM_WM") ? atoi(getenv("BEVGEN_GEMM_WM")) : 0;   // 2 | 4: pins the block rows (128 | 256) for A/B runs
     // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
     // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU
-    const int wm = force_wm ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
+    const int wm = (force_wm == 2 || force_wm == 4) ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
     const int tbm = wm * 64;
     // ... unless even those leave CUs without a second block (a batch of one or two scenes): then nothing shares the CU, and the block becomes eight waves with
     // 32x64 patches on a four-stage ring (three k-tiles in flight instead of one; the kernel's TI note).  Measured on the Route M step (tools/ab_env_m.sh): one scene

@@ -147,7 +147,12 @@ struct AttnSplitArgs {
     int bias_pk_tile_step = 0;        // set by the launcher
     long bias_pk_qb_stride = 0;
     int kv_group = 1;                 // as AttnArgs::kv_group
+    // key split (low-latency path: one scene gives cdiv(Nq, 256) * H = 96 workgroups for 256 CUs): the key tiles are cut into `ksplit` ranges, one workgroup per
+    // (query block, head, batch, range); each writes its unnormalised output row, running maximum and row sum to `kws` and a combine kernel merges the ranges
+    int ksplit = 1;
+    float* kws = nullptr;             // attn_split_ws_floats(B, H, Nq, ksplit) floats
 };
+inline long attn_split_ws_floats(int B, int H, int Nq, int ksplit) { return (long)ksplit * B * H * Nq * 66; }
 long attn_bias_packed_floats(int Nq, int Nk_pad);
 void launch_pack_attn_bias(const float* bias, int ld, int Nq, int Nk_pad, float* out, hipStream_t s);
 void launch_attn_split_operands(const float* q, const float* k, const float* v, void* Qh, void* Ql, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nq, int Nk_pad,

@@ -24,6 +24,7 @@ struct MuseWs {
     std::vector<float*> crossK, crossV;
     float *x = nullptr, *xn = nullptr, *qraw = nullptr, *kvraw = nullptr, *Q = nullptr, *Ks = nullptr, *Vs = nullptr, *att = nullptr, *h = nullptr, *g = nullptr;
     float *ln_part = nullptr, *ln_stats = nullptr;   // LayerNorm folded into the GEMMs: per-row group statistics written by the producer epilogues, merged (rstd, mean rstd)
+    float* attn_ws = nullptr; int attn_ks = 1;   // key-split self-attention of the low-latency path (pick_attn_ksplit): partial rows of the key ranges
     float* kpart = nullptr;   // split-K partial tiles of the narrow (N = D) projections when the batch is too small to fill the chip (low-latency path)
 };
 
@@ -47,6 +48,17 @@ int pick_ksplit(long rows, int N, int K) {
     return s;
 }
 
+// Key ranges of the self-attention (same low-latency path): one scene is cdiv(1536, 256) * 16 heads = 96 workgroups on 256 CUs, each walking all 49 key tiles;
+// with the keys cut in two, 192 workgroups walk half of them and a combine kernel merges the pairs.  Only when the ranges stay long (>= 8 tiles each) and the
+// grid leaves at least half of the CUs idle.  $BEVGEN_ATTN_KSPLIT pins it (A/B runs, tests).
+int pick_attn_ksplit(long blocks, int ntiles) {
+    static const int env = getenv("BEVGEN_ATTN_KSPLIT") ? atoi(getenv("BEVGEN_ATTN_KSPLIT")) : 0;
+    if (env > 0) return std::max(1, std::min(std::min(env, 8), ntiles));
+    if (blocks * 2 > 256) return 1;
+    const int ks = std::min(std::min(4, (int)(256 / blocks)), ntiles / 8);
+    return std::max(ks, 1);
+}
+
 size_t muse_ws_bytes(const Ctx& c, int B) {
     const size_t rows = (size_t)B * c.N;
     const size_t crows = (size_t)B * c.K;
@@ -61,7 +73,11 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
     f += rows * 2 * c.F + rows * c.Fpad;
     f += rows * (c.V + 1);               // logits, scores (generate)
     f += rows * (2 * (size_t)(c.Fpad / 32) + 2) + 64;   // LayerNorm group statistics + merged row statistics
-    if (std::max(pick_ksplit((long)rows, c.D, c.D), pick_ksplit((long)rows, c.D, c.Fpad)) > 1) f += (size_t)KSPLIT_MAX * rows * c.D;   // split-K partial tiles (small batches only)
+    if (std::max(pick_ksplit((long)rows, c.D, c.D), pick_ksplit((long)rows, c.D, c.Fpad)) > 1) f += (size_t)KSPLIT_MAX * rows * c.D;
+    {
+        const int ks = pick_attn_ksplit((long)cdiv(c.N, 256) * c.H * B, c.NkS_pad / 32);
+        if (ks > 1) f += (size_t)attn_split_ws_floats(B, c.H, c.N, ks);
+    }   // split-K partial tiles (small batches only)
     return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256;
 }
 
@@ -134,6 +150,8 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.ln_part = a.get<float>((size_t)w.rows * 2 * (c.Fpad / 32));
     w.ln_stats = a.get<float>((size_t)w.rows * 2);
     w.kpart = std::max(pick_ksplit(w.rows, D, D), pick_ksplit(w.rows, D, c.Fpad)) > 1 ? a.get<float>((size_t)KSPLIT_MAX * w.rows * D) : nullptr;
+    w.attn_ks = pick_attn_ksplit((long)cdiv(c.N, 256) * H * B, c.NkS_pad / 32);
+    w.attn_ws = w.attn_ks > 1 ? a.get<float>((size_t)attn_split_ws_floats(B, H, c.N, w.attn_ks)) : nullptr;
     HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
     HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
 
@@ -240,7 +258,9 @@ void muse_blocks_folded(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s, bo
         sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f * kLog2e;
         sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
         sa.Op = reinterpret_cast<_Float16*>(w.att);
+        sa.ksplit = w.attn_ks; sa.kws = w.attn_ws;
         launch_attention_split(sa, s);
+        sa.ksplit = 1; sa.kws = nullptr;   // (the cross-attention's 9 key tiles stay one range)
         project_residual(w.att, D, l.to_out[0], D, l.norm_g[1], nullptr, nullptr);
         // ---- cross attention
         project_q(l.to_q[1], l.q_scale[1], l.cs_q[1]);
@@ -314,7 +334,9 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f * kLog2e;
             sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
             sa.Op = reinterpret_cast<_Float16*>(w.att);
+            sa.ksplit = w.attn_ks; sa.kws = w.attn_ws;
             launch_attention_split(sa, s);
+            sa.ksplit = 1; sa.kws = nullptr;   // (the cross-attention's 9 key tiles stay one range)
         } else {
             launch_muse_q_prep(w.qraw, l.q_scale[0], w.Q, B, H, N, s);
             launch_muse_kv_prep(w.kvraw, l.null_kv[0], l.k_scale[0], w.Ks, w.Vs, B, H, N, c.NkS_pad, s);

@@ -387,12 +387,13 @@ class Context:
         self._check(self.lib.bevgen_op_geglu_layernorm(self._h, _ptr(h), _ptr(gamma), _ptr(y), rows, F, ldy, self._s()))
         return y
 
-    def op_attention(self, q, k, v, bias, scale):
+    def op_attention(self, q, k, v, bias, scale, key_splits=1):
         B, H, Nq, _ = q.shape
         Nk_pad = k.shape[2]
         out = torch.empty((B, Nq, H * 64), dtype=torch.float32, device=self.device)
         ld = 0 if bias is None else bias.shape[-1]
-        self._check(self.lib.bevgen_op_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(bias), ld, B, H, Nq, Nk_pad, float(scale), _ptr(out), self._s()))
+        self._check(self.lib.bevgen_op_attention_ex(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(bias), ld, B, H, Nq, Nk_pad, float(scale), int(key_splits), _ptr(out),
+                                                    self._s()))
         return out
 
     def op_decode_attention(self, q, kcache, vcache, n, bias=None, keep=None, scale=0.125, kv_dtype=0):

@@ -138,6 +138,36 @@ def test_attention_split_precision(gpu_ctx_split, B, H, Nq, Nk, use_bias):
     assert rel(out.cpu().double(), ref) < 5e-6
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,splits", [(1, 2, 300, 1537, 2), (2, 3, 77, 250, 3), (1, 1, 256, 64, 2), (1, 4, 513, 1568, 5)])
+def test_attention_split_precision_key_ranges(gpu_ctx_split, B, H, Nq, Nk, splits):
+    """Key-split form of the split-precision kernel (the low-latency self-attention of Route M at one scene per call): the key tiles cut into `splits` ranges - uneven
+    ones, one-tile ones, a range whose keys are all masked for some rows, the spike of the rescale branch in the last range - merged by the combine kernel; fp64 reference,
+    same bound as the unsplit kernel, and bit-identical run to run."""
+    g = torch.Generator().manual_seed(Nq + Nk + splits)
+    q = torch.randn(B, H, Nq, 64, generator=g)
+    k = torch.randn(B, H, Nk, 64, generator=g)
+    v = torch.randn(B, H, Nk, 64, generator=g)
+    k[0, 0, Nk - 3] = q[0, 0, 5] * 2.5                      # late spike: the last range holds the row maximum
+    Nk_pad = (Nk + 31) // 32 * 32
+    kp = torch.zeros(B, H, Nk_pad, 64); kp[:, :, :Nk] = k
+    vp = torch.zeros(B, H, Nk_pad, 64); vp[:, :, :Nk] = v
+    scale = 0.31
+    bias_real = torch.randn(Nq, Nk, generator=g) * 2
+    bias_real[::3, 1::2] = -1e30
+    bias_real[1::4, : Nk // 2] = -1e30                        # rows that see nothing of the first range(s)
+    bias_real[:, Nk - 1] = 0.5
+    sim = torch.einsum("bhid,bhjd->bhij", q.double(), k.double()) * scale + bias_real.double()
+    bias = torch.full((Nq, Nk_pad), -1e30)
+    bias[:, :Nk] = bias_real
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v.double()).permute(0, 2, 1, 3).reshape(B, Nq, H * 64)
+    dq, dk, dv, db = dev(q), dev(kp), dev(vp), dev(bias)
+    out = gpu_ctx_split.op_attention(dq, dk, dv, db, scale, key_splits=splits).cpu()
+    one = gpu_ctx_split.op_attention(dq, dk, dv, db, scale).cpu()
+    assert rel(out.double(), ref) < 5e-6
+    assert rel(out.double(), one.double()) < 2e-6
+    assert torch.equal(out, gpu_ctx_split.op_attention(dq, dk, dv, db, scale, key_splits=splits).cpu())
+
+
 def test_attention_split_precision_rescale_branch(gpu_ctx_split):
     """A key far above the running maximum in a LATE tile (every accumulator rescaled exactly once), split-precision kernel."""
     B, H, Nq, Nk = 1, 1, 64, 256

@@ -9,6 +9,8 @@ from bevgen_amd.runtime import Context
 REPS = 20
 M = int(os.environ.get("PROBE_M", "1536"))
 SHAPES = [(1024, 256), (1024, 512), (1024, 1024), (1024, 2048), (1024, 4096), (2048, 1024), (512, 1024), (4096, 1024)]
+if os.environ.get("PROBE_SHAPES"):   # "NxK,NxK,..."
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["PROBE_SHAPES"].split(",")]
 ctx = Context(None)
 for N, K in SHAPES:
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda")

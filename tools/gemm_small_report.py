@@ -4,6 +4,8 @@ import sqlite3, sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 REPS = 20
 SHAPES = [(1024, 256), (1024, 512), (1024, 1024), (1024, 2048), (1024, 4096), (2048, 1024), (512, 1024), (4096, 1024)]
+if os.environ.get("PROBE_SHAPES"):   # "NxK,NxK,..."
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["PROBE_SHAPES"].split(",")]
 M = int(os.environ.get("PROBE_M", "1536"))
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.cursor().execute("select name, grid_x, grid_y, grid_z, end-start from kernels where name like '%gemm_split_glds_kernel%' order by start"))
