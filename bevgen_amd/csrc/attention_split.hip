@@ -56,7 +56,8 @@ __device__ unsigned long long g_attn_trace[8 * 16 * 8];   // [wave][tile][stamp]
 #define PP_STAMP(k) do { } while (0)
 #endif
 
-template <bool TRACE>
+// KS: key-split form (AttnSplitArgs::ksplit > 1; a template flag so that the throughput instantiation carries none of its index arithmetic)
+template <bool TRACE, bool KS = false>
 __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2][4][PP_PLANE];   // [stage][Kh, Kl, Vh, Vl]
 #ifdef BEVGEN_ATTN_LAB
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
     const int vid = (total % 8 == 0) ? (lin % 8) * (total / 8) + lin / 8 : lin;
     const int qblk = vid % nqb, head = (vid / nqb) % gridDim.y, bz = vid / (nqb * gridDim.y);
-    const int b = a.ksplit > 1 ? bz / a.ksplit : bz, ks = a.ksplit > 1 ? bz - b * a.ksplit : 0;   // gridDim.z = B * ksplit
+    const int nks = KS ? a.ksplit : 1;
+    const int b = KS ? bz / nks : bz, ks = KS ? bz - b * nks : 0;   // gridDim.z = B * ksplit
     const int qrow = qblk * 256 + wave * 32 + qi;
     const bool qvalid = qrow < a.Nq;
     const int qc = qvalid ? qrow : a.Nq - 1;
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     const int bstep = a.bias_pk_tile_step;
     // this workgroup's key tiles [t_first, t_first + ntiles)
     const int ntiles_all = a.Nk_pad / SKT;
-    const int t_first = (int)((long)ks * ntiles_all / a.ksplit);
-    const int ntiles = (int)((long)(ks + 1) * ntiles_all / a.ksplit) - t_first;
+    const int t_first = KS ? ks * ntiles_all / nks : 0;
+    const int ntiles = KS ? (ks + 1) * ntiles_all / nks - t_first : ntiles_all;
     const float* Bp = a.bias_pk + (long)head * a.bias_head_stride + (long)(qblk * 8 + wave) * a.bias_pk_qb_stride + lane * 4 + (long)t_first * bstep;
 
     // q_hi, q_hi 2^-11, q_lo 2^-11
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
 #endif
 
     const float l_tot = l_run + xor32(l_run);
-    if (a.ksplit > 1) {   // partial result of this key range: unnormalised output row (relative to m_run), m_run, row sum
+    if (KS) {   // partial result of this key range: unnormalised output row (relative to m_run), m_run, row sum
         if (qvalid) {
             float* wrow = a.kws + ((((long)ks * a.B + b) * a.H + head) * a.Nq + qrow) * 66;
 #pragma unroll
@@ -367,7 +369,10 @@ void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
     else if (g_attn_variant == 2) hipLaunchKernelGGL(attention_split_kernel<true>, grid, dim3(512), 0, s, a);
     else
 #endif
-        hipLaunchKernelGGL(attention_split_kernel<false>, grid, dim3(512), 0, s, a);
+    {
+        if (a.ksplit > 1) hipLaunchKernelGGL((attention_split_kernel<false, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attention_split_kernel<false, false>), grid, dim3(512), 0, s, a);
+    }
     LAUNCH_CHECK();
     if (a.ksplit > 1) {
         const long total = (long)a.B * a.H * a.Nq * 16;
