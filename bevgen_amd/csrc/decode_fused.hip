@@ -355,7 +355,6 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
 // grid (H, B / G), 1024 threads.  Dynamic LDS: bias row [Lpad] | xn [G][D] | qkv [G][192] | red [16][G+1][66] | stat [16][G] | chunk list [Lpad/16 + 2] (uint16)
 template <int DT, int G, int WT, bool SP>   // KV-cache storage (0 fp32, 1 fp16), sequences per workgroup, decode-weight storage (0 fp32, 1 fp16), block-sparse layout
 __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) {
-    using T = KvRow<DT>;
     constexpr int NW = AF_WAVES;
     extern __shared__ float smem[];
     const int D = a.D;

@@ -625,18 +625,21 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
     // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU
     const int wm = (force_wm == 2 || force_wm == 4) ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
-    const int tbm = wm * 64;
     // ... unless even those leave CUs without a second block (a batch of one or two scenes): then nothing shares the CU, and the block becomes eight waves with
     // 32x64 patches on a four-stage ring (three k-tiles in flight instead of one; the kernel's TI note).  Measured on the Route M step (tools/ab_env_m.sh): one scene
     // 236 -> 199 ms, two scenes 303 -> 270 ms; at three and four scenes (288 / 384 blocks: two four-wave blocks per CU) the eight-wave block is 2-3 % slower.
-    // $BEVGEN_GEMM_STAGES = 2 | 8 pins the small-problem shape for A/B runs and tests (2: four waves, two stages; 8: eight waves, four stages)
+    // $BEVGEN_GEMM_STAGES = 2 | 8 | 16 pins the small-problem shape for A/B runs and tests (2: four waves, two stages; 8: eight waves, four stages; 16: 64-row blocks)
     static const int stages_env = getenv("BEVGEN_GEMM_STAGES") ? atoi(getenv("BEVGEN_GEMM_STAGES")) : 0;
     const bool lone = g.mode == MODE_PLAIN && (long)cdiv(g.N, GBN) * cdiv(g.M, 128) * g.ksplit <= 256;
-    int shape = lone ? 8 : 2;
-    if (g.mode == MODE_PLAIN && (stages_env == 2 || stages_env == 8)) shape = stages_env;
+    // ... and when even the 128-row blocks cover at most half of the CUs (a [1536, 1024] projection: 96), 64-row blocks of four waves (32x64 patches, four stages): twice
+    // the blocks, a shorter k-tile each (16 = that shape): 21.4 -> 18.4 us at K = 1024, one-scene step 195.7 -> 187.4 ms on the same box (profiles/r03_ab_b1_half_rows.txt)
+    const bool half_rows = lone && g.ksplit == 1 && (long)cdiv(g.N, GBN) * cdiv(g.M, 128) <= 128;
+    int shape = lone ? (half_rows ? 16 : 8) : 2;
+    if (g.mode == MODE_PLAIN && (stages_env == 2 || stages_env == 8 || (stages_env == 16 && g.ksplit == 1))) shape = stages_env;
     const int stages = wm == 4 ? 3 : (shape == 2 ? 2 : 4);
-    const bool thin = wm == 2 && shape == 8;
-    BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
+    const bool thin = wm == 2 && shape == 8, half = wm == 2 && shape == 16;
+    const int tbm = half ? 64 : wm * 64;
+    BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
     dim3 grid(cdiv(g.N, GBN), cdiv(g.M, tbm), g.ksplit);
     const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16);
@@ -657,6 +660,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2);
 #undef BG_SET
         attr_set = true;
     }
@@ -667,7 +672,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, true>), grid, dim3(THREADS), lds, stream, g);    \
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, false>), grid, dim3(THREADS), lds, stream, g);               \
     } while (0)
-    if (thin) {
+    if (half) {
+        if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), grid, dim3(256), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), grid, dim3(256), lds, stream, g);
+    } else if (thin) {
         if (g.ksplit > 1) {
             if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), grid, dim3(512), lds, stream, g);
             else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), grid, dim3(512), lds, stream, g);

@@ -111,7 +111,6 @@ void attnblock(const AttnBlockW& a, Act& x, float* y, DecWs& ws, hipStream_t s) 
     const int hw = x.h * x.w, C = a.c, n = x.n;
     const int hwp = (int)round_up(hw, 32);   // key dimension padded to the GEMM's k granularity (non-square latents: 14 x 25 = 350 -> 352); pad keys carry P = 0, v = 0
     const long rows = (long)n * hw;
-    Act t{ws.t, n, x.h, x.w, C};
     gn(x, a.nw, a.nb, ws.t, 0, ws, s);
     conv1(ws.t, rows, a.q, ws.q, nullptr, s);
     conv1(ws.t, rows, a.k, ws.k, nullptr, s);

@@ -479,10 +479,10 @@ def test_gemm_split_precision_split_k(gpu_ctx, M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("shape", ["2", "8"])
+@pytest.mark.parametrize("shape", ["2", "8", "16"])
 def test_gemm_small_problem_block_shapes(shape):
     """The LDS-DMA GEMM picks its small-problem block by the grid size (eight waves with 32x64 patches on a four-stage ring when every block has a CU to itself,
-    four waves on two stages otherwise).  $BEVGEN_GEMM_STAGES pins one of them (read once per process, hence the subprocess): both must give the fp64 product on the
+    64-row blocks of four waves when even those cover at most half of the CUs, four waves on two stages otherwise).  $BEVGEN_GEMM_STAGES pins one of them (read once per process, hence the subprocess): both must give the fp64 product on the
     same shapes - ragged M and N, one k-tile, fewer k-tiles than ring stages, split-K, the f16-weights form."""
     import subprocess, sys, os
     code = r'''
