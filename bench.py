@@ -97,7 +97,7 @@ class _StubContext:
         pass
 
     def profile_end(self):
-        return {k: {"launches": 0.0, "ms": 0.0, "work": 0.0} for k in ("gemm", "conv3x3", "attention", "decode_attention", "gemm_skinny")}
+        return {k: {"launches": 0.0, "ms": 0.0, "work": 0.0} for k in ("gemm", "conv3x3", "attention", "decode_attention", "gemm_skinny", "gemm_small")}
 
     def close(self):
         pass
@@ -489,7 +489,10 @@ def main():
             peak, kern, note = MFMA_F16_PEAK_TF / 3.0, "gemm_split_glds_kernel<MODE_PLAIN, 4, 3>", "3 v_mfma_f32_32x32x16_f16 per fp32 product (hi/lo split): ceiling = f16 dense peak / 3"
         tr = pmc_traffic(kern)
         return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr, "kernel": kern, "note": note,
-                "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1)}
+                "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1),
+                # launches of the same GEMM family that are not this kernel (small-problem blocks, the short last part of a row-split launch): timed apart, so that
+                # launches / avg_us above are one kernel's and can be held against the rocprof trace
+                "other_gemm_launches": {"launches": int(prof.get("gemm_small", {}).get("launches", 0)), "ms": prof.get("gemm_small", {}).get("ms", 0.0)}}
 
     import numpy as np
     scenes = n_gpus * args.batch * args.steps
@@ -506,7 +509,7 @@ def main():
         "gather_ms_per_step": float(np.mean(parts["gather"])),
         "roofline": roof(prof, args.precision),
         "kernel_time_share": {k: v["ms"] / prof["_pass"]["ms"] for k, v in prof.items() if v["launches"]},
-        "kernel_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12) for k, v in prof.items() if v["launches"] and k in ("gemm", "conv3x3", "attention")},
+        "kernel_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12) for k, v in prof.items() if v["launches"] and k in ("gemm", "gemm_small", "conv3x3", "attention")},
         "profiled_pass": {"steps": prof["_pass"]["steps"], "ms_per_step": prof["_pass"]["ms"] / prof["_pass"]["steps"],
                           "note": "roofline / kernel_time_share / kernel_tflops come from this separate pass of the same step with a HIP-event pair around every hot launch; `value` is timed without it"},
     }

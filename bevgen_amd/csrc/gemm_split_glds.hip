@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
     int tx, ty;
     if (g.tile_band > 0) xcd_tile_banded(gridDim.x, gridDim.y, g.tile_band, tx, ty);
     else xcd_tile(gridDim.x, gridDim.y, tx, ty);
-    const int n0 = tx * GBN, m0 = ty * TBM;
+    const int n0 = tx * GBN, m0 = ty * TBM + g.m_base;
     const int n0l = n0, m0l = m0;
 
     const _Float16* Ap = reinterpret_cast<const _Float16*>(g.A_hi);   // interleaved planes: (row, 32-k block) = 64 halves = one 128-byte line
@@ -606,7 +606,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.batch == 1, "gemm_split_glds: batched form not provided");
     if (g.epi == EPI_MUSE_KV)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N == 2 * g.epi_heads * 64 && g.epi_hi && g.epi_lo && g.epi_hi2 && g.epi_lo2 && g.epi_aux && g.epi_scale && g.epi_rows > 0 &&
-                       g.epi_ld >= g.epi_rows + 1 && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE && g.M % g.epi_rows == 0,
+                       g.epi_ld >= g.epi_rows + 1 && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE && (g.no_row_split || g.M % g.epi_rows == 0),
                    "gemm_split_glds: bad fused k/v-preparation arguments");
     if (g.epi == EPI_GEGLU)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % GBN == 0 && ((g.ldc % 4 == 0 && g.ldc >= g.N / 2) || (!g.C && g.ln_gamma)) && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE,
@@ -624,16 +624,37 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     static const int force_wm = getenv("BEVGEN_GEMM_WM") ? atoi(getenv("BEVGEN_GEMM_WM")) : 0;   // 2 | 4: pins the block rows (128 | 256) for A/B runs
     // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
     // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU
-    const int wm = (force_wm == 2 || force_wm == 4) ? force_wm : ((long)cdiv(g.M, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
+    const int rows = g.M - g.m_base;   // (g.M is the END row of this launch, g.m_base its first)
+    const int wm = (force_wm == 2 || force_wm == 4) ? force_wm : ((long)cdiv(rows, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
+    // Tile quantisation: T tiles of 256 x 128 on 256 CUs cost ceil(T / 256) rounds - the up-projection of sixteen scenes is 4128 tiles = 16.1 rounds and pays 17, of one
+    // scene 258 tiles and pays 2, a [12288, 1024] projection of the three-camera shape 384 tiles and pays 2.  When the last round would hold at most 128 tiles, the launch
+    // is cut at a row-tile boundary: the first part fills whole rounds, the rest (<= 128 tiles' worth of rows) runs as 128-row blocks, one short round of its own
+    // (about 0.45 of a full one).  Same kernels, same per-row arithmetic: results are bit-identical to the single launch.  $BEVGEN_GEMM_ROWSPLIT=0 turns it off (A/B runs)
+    static const int rowsplit_env = getenv("BEVGEN_GEMM_ROWSPLIT") ? atoi(getenv("BEVGEN_GEMM_ROWSPLIT")) : 1;
+    if (rowsplit_env && !g.no_row_split && wm == 4 && g.mode == MODE_PLAIN && g.ksplit <= 1 && !g.ln_gamma && !g.ln_stats) {
+        const long gx = cdiv(g.N, GBN), gy = cdiv(rows, 256), T = gx * gy;
+        const long full = T / 256;                       // whole rounds
+        const long gy_top = full * 256 / gx;             // row tiles that fit them
+        const long rest = (gy - gy_top) * gx;            // tiles left for the last round
+        if (T % 256 != 0 && full >= 1 && gy_top >= 1 && gy_top < gy && rest <= 128) {
+            GemmArgs top = g, bot = g;
+            top.no_row_split = bot.no_row_split = true;
+            top.M = g.m_base + (int)gy_top * 256;        // end row of the first part
+            bot.m_base = top.M;
+            launch_gemm_split_glds(top, stream);
+            launch_gemm_split_glds(bot, stream);
+            return;
+        }
+    }
     // ... unless even those leave CUs without a second block (a batch of one or two scenes): then nothing shares the CU, and the block becomes eight waves with
     // 32x64 patches on a four-stage ring (three k-tiles in flight instead of one; the kernel's TI note).  Measured on the Route M step (tools/ab_env_m.sh): one scene
     // 236 -> 199 ms, two scenes 303 -> 270 ms; at three and four scenes (288 / 384 blocks: two four-wave blocks per CU) the eight-wave block is 2-3 % slower.
     // $BEVGEN_GEMM_STAGES = 2 | 8 | 16 pins the small-problem shape for A/B runs and tests (2: four waves, two stages; 8: eight waves, four stages; 16: 64-row blocks)
     static const int stages_env = getenv("BEVGEN_GEMM_STAGES") ? atoi(getenv("BEVGEN_GEMM_STAGES")) : 0;
-    const bool lone = g.mode == MODE_PLAIN && (long)cdiv(g.N, GBN) * cdiv(g.M, 128) * g.ksplit <= 256;
+    const bool lone = g.mode == MODE_PLAIN && (long)cdiv(g.N, GBN) * cdiv(rows, 128) * g.ksplit <= 256;
     // ... and when even the 128-row blocks cover at most half of the CUs (a [1536, 1024] projection: 96), 64-row blocks of four waves (32x64 patches, four stages): twice
     // the blocks, a shorter k-tile each (16 = that shape): 21.4 -> 18.4 us at K = 1024, one-scene step 195.7 -> 187.4 ms on the same box (profiles/r03_ab_b1_half_rows.txt)
-    const bool half_rows = lone && g.ksplit == 1 && (long)cdiv(g.N, GBN) * cdiv(g.M, 128) <= 128;
+    const bool half_rows = lone && g.ksplit == 1 && (long)cdiv(g.N, GBN) * cdiv(rows, 128) <= 128;
     int shape = lone ? (half_rows ? 16 : 8) : 2;
     if (g.mode == MODE_PLAIN && (stages_env == 2 || stages_env == 8 || (stages_env == 16 && g.ksplit == 1))) shape = stages_env;
     const int stages = wm == 4 ? 3 : (shape == 2 ? 2 : 4);
@@ -641,7 +662,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     const int tbm = half ? 64 : wm * 64;
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
-    dim3 grid(cdiv(g.N, GBN), cdiv(g.M, tbm), g.ksplit);
+    dim3 grid(cdiv(g.N, GBN), cdiv(rows, tbm), g.ksplit);
     const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -665,7 +686,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
 #undef BG_SET
         attr_set = true;
     }
-    ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : PROF_GEMM, 2.0 * g.M * (double)g.N * g.K, stream);
+    ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : (wm == 4 ? PROF_GEMM : PROF_GEMM_SMALL), 2.0 * rows * (double)g.N * g.K, stream);
     const bool conv = g.mode == MODE_CONV3;
 #define BG_LAUNCH(MODE_, WM_, S_, THREADS)                                                                                           \
     do {                                                                                                                             \

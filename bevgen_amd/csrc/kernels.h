@@ -69,6 +69,8 @@ struct GemmArgs {
     float* kpart = nullptr;
     int a_bytes = 0;                  // MODE_CONV3: size of the activation plane image (buffer-resource bound), filled in by the launcher
     int tile_band = 0;                // tile-order band height (0 = row-major); filled in by the launcher
+    int m_base = 0;                   // first row of this launch (the launcher cuts a problem whose last round of tiles would be nearly empty into two row ranges; M stays the END row)
+    bool no_row_split = false;        // launcher-internal
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
 void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);

@@ -8,7 +8,9 @@
 
 namespace bevgen {
 
-enum ProfKind { PROF_GEMM = 0, PROF_CONV3 = 1, PROF_ATTN = 2, PROF_DECODE_ATTN = 3, PROF_GEMM_SKINNY = 4, PROF_KINDS = 5 };
+// PROF_GEMM_SMALL: launches of the LDS-DMA GEMM that are NOT its 256-row throughput instantiation (small-problem blocks, the short last part of a row-split
+// launch): kept apart so that PROF_GEMM's launches / milliseconds are those of ONE kernel and can be checked against a rocprof trace
+enum ProfKind { PROF_GEMM = 0, PROF_CONV3 = 1, PROF_ATTN = 2, PROF_DECODE_ATTN = 3, PROF_GEMM_SKINNY = 4, PROF_GEMM_SMALL = 5, PROF_KINDS = 6 };
 
 struct Profiler {
     struct Rec { int kind; double work; hipEvent_t a, b; };

@@ -324,7 +324,7 @@ class Context:
         return out
 
     # ------------------------------------------------------------------------------------------ per-kernel HIP-event timing
-    PROFILE_KINDS = ("gemm", "conv3x3", "attention", "decode_attention", "gemm_skinny")
+    PROFILE_KINDS = ("gemm", "conv3x3", "attention", "decode_attention", "gemm_skinny", "gemm_small")
 
     def profile_begin(self):
         self._check(self.lib.bevgen_profile_begin(self._h))

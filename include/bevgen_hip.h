@@ -267,9 +267,10 @@ int bevgen_decode_attention_splits(int B, int H, int n);
 
 /* HIP-event timing of the hot kernels on their launch stream.  Between begin and end every launch of
  *   0 gemm (fp32 MFMA)   1 conv3x3 (implicit GEMM)   2 flash attention   3 decode attention   4 skinny GEMM
+ *   5 small-problem launches of the split-precision GEMM (128- / 64-row blocks, the short last part of a row-split launch; kind 0 is then one kernel)
  * is bracketed by an event pair; end synchronises the device and writes out[kind*3 + {0,1,2}] =
- * {launches, total milliseconds, total algorithmic work (FLOP for 0-2, bytes for 3-4)} for the 5 kinds (15 doubles). */
-#define BEVGEN_PROFILE_KINDS 5
+ * {launches, total milliseconds, total algorithmic work (FLOP for 0-2 and 5, bytes for 3-4)} for the 6 kinds (18 doubles). */
+#define BEVGEN_PROFILE_KINDS 6
 int bevgen_profile_begin(bevgen_ctx* ctx);
 int bevgen_profile_end(bevgen_ctx* ctx, double* out);
 

@@ -514,3 +514,37 @@ print("worst", worst)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "worst" in res.stdout
+
+
+def test_gemm_row_split_launches_are_bit_identical():
+    """A problem whose last round of 256 x 128 tiles would be nearly empty is launched as two row ranges (whole rounds + a short round of 128-row blocks).  Same kernels,
+    same per-row arithmetic: the result must equal the single launch bit for bit ($BEVGEN_GEMM_ROWSPLIT=0, read once per process, hence two subprocesses) and the fp64
+    product within the split-precision bound - ragged M, bias + GELU + residual epilogue, the f16-weights form."""
+    import subprocess, sys, os, hashlib
+    code = r'''
+import math, torch, sys, hashlib
+sys.path.insert(0, %r)
+from bevgen_amd.runtime import Context, _ptr, _stream
+ctx = Context(None)
+for (M, N, K, mode) in [(8448 + 37, 1024, 256, 3), (66 * 256, 1024, 128, 4), (3072, 5504, 64, 3)]:
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 3.0
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    if mode == 4:
+        w = w.half().float()
+    b = torch.randn(N, generator=g); r = torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + b.double()) + r.double()
+    da, dw, db, dr = a.cuda(), w.cuda(), b.cuda(), r.cuda()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(da), _ptr(dw), _ptr(db), _ptr(dr), _ptr(out), M, N, K, 1, mode, _stream()))
+    o = out.cpu()
+    err = float((o.double() - ref).norm() / ref.norm())
+    assert err < 2e-6, (M, N, K, mode, err)
+    print("digest", M, N, K, mode, hashlib.sha256(o.numpy().tobytes()).hexdigest())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BEVGEN_GEMM_ROWSPLIT=flag), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        outs.append([l for l in res.stdout.splitlines() if l.startswith("digest")])
+    assert len(outs[0]) == 3 and outs[0] == outs[1], (outs[0], outs[1])
