@@ -625,7 +625,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
     // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU
     const int rows = g.M - g.m_base;   // (g.M is the END row of this launch, g.m_base its first)
-    const int wm = (force_wm == 2 || force_wm == 4) ? force_wm : ((long)cdiv(rows, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
+    static const int top_wm_env = getenv("BEVGEN_GEMM_TOPWM") ? atoi(getenv("BEVGEN_GEMM_TOPWM")) : 4;
+    const int wm = (force_wm == 2 || force_wm == 4) ? force_wm : (g.force_wm == 4 && top_wm_env == 4) ? 4 : ((long)cdiv(rows, 256) * cdiv(g.N, GBN) >= 256 ? 4 : 2);
     // Tile quantisation: T tiles of 256 x 128 on 256 CUs cost ceil(T / 256) rounds - the up-projection of sixteen scenes is 4128 tiles = 16.1 rounds and pays 17, of one
     // scene 258 tiles and pays 2, a [12288, 1024] projection of the three-camera shape 384 tiles and pays 2.  When the last round would hold at most 128 tiles, the launch
     // is cut at a row-tile boundary: the first part fills whole rounds, the rest (<= 128 tiles' worth of rows) runs as 128-row blocks, one short round of its own
@@ -639,6 +640,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         if (T % 256 != 0 && full >= 1 && gy_top >= 1 && gy_top < gy && rest <= 128) {
             GemmArgs top = g, bot = g;
             top.no_row_split = bot.no_row_split = true;
+            top.force_wm = 4;                            // the part that was sized to fill whole rounds of 256-row blocks keeps them
             top.M = g.m_base + (int)gy_top * 256;        // end row of the first part
             bot.m_base = top.M;
             launch_gemm_split_glds(top, stream);

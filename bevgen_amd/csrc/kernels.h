@@ -71,6 +71,7 @@ struct GemmArgs {
     int tile_band = 0;                // tile-order band height (0 = row-major); filled in by the launcher
     int m_base = 0;                   // first row of this launch (the launcher cuts a problem whose last round of tiles would be nearly empty into two row ranges; M stays the END row)
     bool no_row_split = false;        // launcher-internal
+    int force_wm = 0;                 // launcher-internal: 4 = keep 256-row blocks (the whole-rounds part of a row-split launch)
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
 void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);
