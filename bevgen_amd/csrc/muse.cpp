@@ -34,7 +34,8 @@ struct MuseWs {
 // How many slices (measured at one six-view scene, rows = 1536, tools/gemm_small_probe.py + profiles/r03_gemm_small_*.txt): with the eight-wave small-problem block of
 // gemm_split_glds.hip a [1536, 1024] x [1024, K] projection costs 7.6 us of fixed time (dispatch, pipeline fill from cold operands, store tail) + 0.43 us per k-tile
 // on 96 CUs.  A second slice halves the loop but adds a 6.4 us reduce launch and gives up the fused epilogues (q preparation): a wash at K = 1024 (21.4 vs 20.9 us),
-// a clear gain for the feed-forward down-projection (K = 5504: 82 -> 51 us).  So: two slices from K = 2048 up, none below.  (Round-3 history: with the four-wave
+// a clear gain for a long k loop (K = 5504: 82 -> 51 us).  So: two slices from K = 2048 up, none below - and none where the 128-row grid covers at most half of the CUs:
+// there the launcher's 64-row blocks double the grid without a reduce launch (one-scene down-projection, K = 2752: 37.9 + 7.1 -> 40 us; step 169.9 -> 167.9 ms).  (Round-3 history: with the four-wave
 // block - 12 us + 0.62 us per k-tile - two slices everywhere were the optimum, step 257 -> 241 ms.)
 constexpr int KSPLIT_MAX = 6;
 int ksplit_env() { static const int v = getenv("BEVGEN_KSPLIT") ? atoi(getenv("BEVGEN_KSPLIT")) : 0; return v; }
@@ -42,7 +43,7 @@ int pick_ksplit(long rows, int N, int K) {
     if ((long)cdiv(rows, 256) * cdiv(N, 128) >= 256) return 1;          // the 256-row tiling already fills the chip
     const long tiles = (long)cdiv(rows, 128) * cdiv(N, 128);
     if (tiles >= 160) return 1;
-    int s = K >= 2048 ? 2 : 1;
+    int s = (K >= 2048 && tiles > 128) ? 2 : 1;   // (<= 128 tiles: the launcher's 64-row blocks already double the grid, without a reduce: 45 -> 40 us at K = 2752)
     if (ksplit_env() > 0) s = std::min(KSPLIT_MAX, ksplit_env());
     while (s > 1 && K / 32 < 2 * s) --s;
     return s;
