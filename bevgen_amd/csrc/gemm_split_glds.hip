@@ -60,11 +60,15 @@ __device__ __forceinline__ void wait_tiles(int n) {
 // to itself (one or two scenes: fewer blocks than CUs).  With four waves every SIMD holds ONE wave, and the ~70 issue cycles of each of its 8 DMA instructions per k-tile
 // are cycles in which that SIMD's matrix pipe has nothing queued: 0.55 us per k-tile measured against 0.32 us of MFMAs (tools/gemm_small_probe.py).  Eight waves halve
 // both the MFMAs and the DMA instructions of a wave and give every SIMD a second wave to run while one issues.
-template <int MODE, int WM, int S, bool W16 = false, bool KS = false, int TI = 2>
-__global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
+// TJ: 32-column MFMA tiles per wave along N (2 = the wave's 64 columns are one head / one x|gate pair, which the fused epilogues rely on; 1 = 32x32 patches, plain
+// epilogue only: the 64-row block of a lone small problem on eight waves instead of four)
+template <int MODE, int WM, int S, bool W16 = false, bool KS = false, int TI = 2, int TJ = 2>
+__global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
     constexpr int TBM = WM * 64;                 // block rows
-    constexpr int NW = WM * 4 / TI;              // waves
+    constexpr int NW = WM * 8 / (TI * TJ);       // waves
     constexpr int WROWS = TI * 32;               // rows of a wave's patch
+    constexpr int WCOLS = TJ * 32;               // columns of a wave's patch
+    constexpr int WN = GBN / WCOLS;              // waves along N
     constexpr int NAJ = TBM / 8 / NW;            // 8-row A pieces per wave
     constexpr int NBJ = 16 / NW;                 // 8-row B pieces per wave
     constexpr int AREGION = TBM * 2 * GBK;       // halves: TBM rows x (32 hi | 32 lo)
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
     extern __shared__ __attribute__((aligned(1024))) _Float16 smem_g[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     int tx, ty;
     if (g.tile_band > 0) xcd_tile_banded(gridDim.x, gridDim.y, g.tile_band, tx, ty);
@@ -149,14 +153,14 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
     };
     auto issue_a_half = [&](int stage, int half) {   // the A pieces in two groups (interleaved with the MFMA groups of a phase)
 #pragma unroll
-        for (int j = half * (NAJ / 2); j < (half + 1) * (NAJ / 2); ++j) issue_a(stage, j);
+        for (int j = half * NAJ / 2; j < (half + 1) * NAJ / 2; ++j) issue_a(stage, j);   // (NAJ = 1: the piece goes with the second group)
     };
 
-    f32x16 accM[TI][2], accC[TI][2];
+    f32x16 accM[TI][TJ], accC[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) { accM[i][j][q] = 0.f; accC[i][j][q] = 0.f; }
 
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int ra = wm * WROWS + (i < TI ? i : 0) * 32 + r, rb = wn * 64 + i * 32 + r;
+            const int ra = wm * WROWS + (i < TI ? i : 0) * 32 + r, rb = wn * WCOLS + (i < TJ ? i : 0) * 32 + r;
             a_rd[i][ks] = ra * 2 * GBK + (((ks * 2 + h) ^ ((ra >> 1) & 7)) << 3);
             b_rd[i][ks] = AREGION + rb * 2 * GBK + (((ks * 2 + h) ^ ((rb >> 1) & 7)) << 3);
         }
@@ -179,28 +183,30 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
                 f.ah[i] = *reinterpret_cast<const half8*>(st + a_rd[i][ks]);
                 f.al[i] = *reinterpret_cast<const half8*>(st + (a_rd[i][ks] ^ 32));
             }
-            f.bh[i] = *reinterpret_cast<const half8*>(st + b_rd[i][ks]);
-            if (!W16) f.bl[i] = *reinterpret_cast<const half8*>(st + (b_rd[i][ks] ^ 32));
+            if (i < TJ) {
+                f.bh[i] = *reinterpret_cast<const half8*>(st + b_rd[i][ks]);
+                if (!W16) f.bl[i] = *reinterpret_cast<const half8*>(st + (b_rd[i][ks] ^ 32));
+            }
         }
     };
     auto mma_main = [&](const Frag& f) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], accM[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], accM[i][j], 0, 0, 0);
     };
     auto mma_c1 = [&](const Frag& f) {
         if (W16) return;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], accC[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], accC[i][j], 0, 0, 0);
     };
     auto mma_c2 = [&](const Frag& f) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], accC[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], accC[i][j], 0, 0, 0);
     };
 
     const int nk = nk_all / ksl + (kz < nk_all % ksl ? 1 : 0);
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
     // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
+    if constexpr (TJ == 2) {   // the fused epilogues and the split-K partial store assume 64-column wave patches
     if (MODE == MODE_PLAIN && g.ln_stats) {
         // LayerNorm of the A rows, applied to the finished sums (GemmArgs::ln_*): the planes hold x * gamma, so  LN(x) W^T = rstd acc - (mean rstd) colsum.  In place:
         // every epilogue below then reads (accM + 0) as if the GEMM had run on normalised rows.
@@ -547,6 +554,7 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
         }
         return;
     }
+    }
     float* C = g.C;
     const float* Rp = g.R;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
@@ -557,10 +565,10 @@ __global__ __launch_bounds__(WM * 256 / TI, (WM == 2 && S == 2) ? 2 : 1) void ge
         if (m >= g.M) continue;
         const float bm = g.bias_m ? g.bias_m[m] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TJ; ++j) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * qq + 4 * h;
+                const int n = n0 + wn * WCOLS + j * 32 + 8 * qq + 4 * h;
                 if (n >= g.N) continue;
                 float v[4];
 #pragma unroll
@@ -661,6 +669,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     if (g.mode == MODE_PLAIN && (stages_env == 2 || stages_env == 8 || (stages_env == 16 && g.ksplit == 1))) shape = stages_env;
     const int stages = wm == 4 ? 3 : (shape == 2 ? 2 : 4);
     const bool thin = wm == 2 && shape == 8, half = wm == 2 && shape == 16;
+    // ... and with the plain epilogue (bias / activation / residual: the fused ones need 64-column wave patches) the 64-row block runs on eight waves of 32x32 patches
+    static const int half8_env = getenv("BEVGEN_GEMM_HALF8") ? atoi(getenv("BEVGEN_GEMM_HALF8")) : 1;
+    const bool half8 = half && half8_env && g.epi == 0 && !g.ln_gamma && !g.ln_stats;
     const int tbm = half ? 64 : wm * 64;
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
@@ -685,6 +696,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
 #undef BG_SET
         attr_set = true;
     }
@@ -695,7 +708,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, true>), grid, dim3(THREADS), lds, stream, g);    \
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, false>), grid, dim3(THREADS), lds, stream, g);               \
     } while (0)
-    if (half) {
+    if (half8) {
+        if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1, 1>), grid, dim3(512), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), grid, dim3(512), lds, stream, g);
+    } else if (half) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), grid, dim3(256), lds, stream, g);
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), grid, dim3(256), lds, stream, g);
     } else if (thin) {
