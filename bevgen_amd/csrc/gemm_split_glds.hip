@@ -661,10 +661,11 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     // 236 -> 199 ms, two scenes 303 -> 270 ms; at three and four scenes (288 / 384 blocks: two four-wave blocks per CU) the eight-wave block is 2-3 % slower.
     // $BEVGEN_GEMM_STAGES = 2 | 8 | 16 pins the small-problem shape for A/B runs and tests (2: four waves, two stages; 8: eight waves, four stages; 16: 64-row blocks)
     static const int stages_env = getenv("BEVGEN_GEMM_STAGES") ? atoi(getenv("BEVGEN_GEMM_STAGES")) : 0;
-    const bool lone = g.mode == MODE_PLAIN && (long)cdiv(g.N, GBN) * cdiv(rows, 128) * g.ksplit <= 256;
+    static const int conv_thin_env = getenv("BEVGEN_CONV_THIN") ? atoi(getenv("BEVGEN_CONV_THIN")) : 1;
+    const bool lone = (g.mode == MODE_PLAIN || conv_thin_env) && (long)cdiv(g.N, GBN) * cdiv(rows, 128) * g.ksplit <= 256;
     // ... and when even the 128-row blocks cover at most half of the CUs (a [1536, 1024] projection: 96), 64-row blocks of four waves (32x64 patches, four stages): twice
     // the blocks, a shorter k-tile each (16 = that shape): 21.4 -> 18.4 us at K = 1024, one-scene step 195.7 -> 187.4 ms on the same box (profiles/r03_ab_b1_half_rows.txt)
-    const bool half_rows = lone && g.ksplit == 1 && (long)cdiv(g.N, GBN) * cdiv(rows, 128) <= 128;
+    const bool half_rows = lone && g.mode == MODE_PLAIN && g.ksplit == 1 && (long)cdiv(g.N, GBN) * cdiv(rows, 128) <= 128;
     int shape = lone ? (half_rows ? 16 : 8) : 2;
     if (g.mode == MODE_PLAIN && (stages_env == 2 || stages_env == 8 || (stages_env == 16 && g.ksplit == 1))) shape = stages_env;
     const int stages = wm == 4 ? 3 : (shape == 2 ? 2 : 4);
@@ -694,6 +695,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
@@ -714,6 +717,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     } else if (half) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), grid, dim3(256), lds, stream, g);
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), grid, dim3(256), lds, stream, g);
+    } else if (thin && conv) {
+        if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2, 4, true, false, 1>), grid, dim3(512), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2, 4, false, false, 1>), grid, dim3(512), lds, stream, g);
     } else if (thin) {
         if (g.ksplit > 1) {
             if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), grid, dim3(512), lds, stream, g);
