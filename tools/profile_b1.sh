@@ -15,6 +15,12 @@ db = sqlite3.connect("$DB")
 c = db.cursor()
 n, tot, t0, t1 = list(c.execute("select count(*), sum(end-start), min(start), max(end) from kernels"))[0]
 print(f"kernels {n}, busy {tot/1e6:.1f} ms, span {(t1-t0)/1e6:.1f} ms")
+# idle time BETWEEN consecutive kernels (gaps below 100 us: back-to-back launches of one forward, not host work between steps)
+rows = list(c.execute("select start, end from kernels order by start"))
+gaps = [b[0] - a[1] for a, b in zip(rows, rows[1:])]
+small = [g for g in gaps if 0 <= g < 100000]
+import statistics
+print(f"gaps < 100 us between consecutive kernels: {len(small)} of {len(gaps)}, total {sum(small)/1e6:.1f} ms, median {statistics.median(small)/1e3:.2f} us, mean {sum(small)/len(small)/1e3:.2f} us; overlapping starts {sum(1 for g in gaps if g < 0)}")
 PY
 rm -rf $R/gpurun_out/prof_b1
 cat $R/gpurun_out/${TAG}_b${B}_by_grid.txt | head -40
