@@ -14,8 +14,14 @@ for case in range(n_cases):
     M = rng.choice([1, 7, 31, 64, 127, 128, 129, 255, 300, 513, 1000, 1537, 3000]) + rng.randint(0, 5)
     N = rng.choice([1, 4, 60, 64, 128, 130, 200, 256, 700, 1024]) + rng.randint(0, 3)
     K = 32 * rng.choice([1, 2, 3, 4, 5, 7, 8, 13, 32])
+    if os.environ.get("FUZZ_BIG"):   # problems large enough for 256-row tiles and the row-split launches (tile counts just above a multiple of 256)
+        N = rng.choice([1024, 1000, 2048, 5504, 640])
+        gx = (N + 127) // 128
+        gy = (256 * rng.choice([1, 2, 3]) + gx - 1) // gx + rng.choice([0, 1, 2, 5])
+        M = 256 * gy - rng.randint(0, 255)
+        K = 32 * rng.choice([1, 2, 4, 9])
     mode = rng.choice([3, 3, 4, 5])
-    if mode == 5 and K // 32 < 6:
+    if mode == 5 and (K // 32 < 6 or os.environ.get("FUZZ_BIG")):   # (split-K is the small-M path: the library refuses it for 256-row problems)
         mode = 3
     g = torch.Generator().manual_seed(case)
     a = torch.randn(M, K, generator=g) * 3.0
