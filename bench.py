@@ -538,6 +538,12 @@ def main():
         e3, _, p3 = run_route_m(args.precision, 2, 1, 3, args.batch)   # the shape of the released Argoverse checkpoint (3 cameras, N=768)
         line["released_3_camera_shape"] = {"value": args.batch * 2 / e3, "unit": "scenes/s", "ms_per_step": e3 * 1e3 / 2, "ms_per_maskgit_iteration": float(np.mean(p3["generate"])) / args.timesteps,
                                            "config": f"Route M, 3x256x256 (configs/modes/argoverse.yaml), batch {args.batch}, 2 steps"}
+    if world == 1 and not args.no_extra_legs and args.batch > 1:
+        # the interactive caller's shape (scripts/interactive_editing.py:273-277): ONE scene per call - latency, not throughput.  Same step (MaskGit generate + VQGAN decode
+        # to uint8), the library picks its small-grid kernels by itself (64- / 128-row GEMM blocks, key-split self-attention, row-split launches)
+        e1, _, p1 = run_route_m(args.precision, 3, 1, args.cams, 1)
+        line["single_scene_latency"] = {"value": e1 * 1e3 / 3, "unit": "ms per scene", "higher_is_better": False, "ms_per_maskgit_iteration": float(np.mean(p1["generate"])) / args.timesteps,
+                                        "config": f"Route M, {args.cams}x256x256, batch 1, 3 steps"}
     if world == 1 and not args.no_decode_leg:
         line.update(decode_leg(local_rank, args.decode_batch, args.decode_steps))
         # BASELINE config 4 names fp16 storage: the same decode with the KV cache stored as fp16 (fp32 accumulate; logits within 2e-3 of the range, tests)

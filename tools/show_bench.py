@@ -11,3 +11,6 @@ for k in ("decode_f16_kv_cache","decode_f16_kv_cache_f16_weights","decode_densit
 print({k: round(d[k]["value"],2) for k in ("exact_fp32_mode","f16_weights_mode","released_3_camera_shape") if k in d})
 if "config5_topk32_4_samples_per_layout" in d: print("config5 ms/step", d["config5_topk32_4_samples_per_layout"]["ms_per_decode_step"])
 if "cpu_baseline" in d: print("cpu", d["cpu_baseline"]["value"])
+
+if "single_scene_latency" in d:
+    print("single scene", round(d["single_scene_latency"]["value"], 1), "ms")
