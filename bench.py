@@ -16,11 +16,12 @@ per GPU), no data-path collective; the only RCCL traffic is the final gather of 
 Default arithmetic mode: f16x3 (every GEMM / conv / attention product as three f16 MFMAs on hi/lo splits, fp32 accumulation: fp32-class accuracy,
 bit-identical greedy tokens on every parity fixture); the line also carries a one-step `exact_fp32_mode` leg (exact fp32 MFMA).
 
-One JSON line on rank 0: the headline metric with median / p99 step times, ms per MaskGit iteration and VQGAN ms per scene, `roofline` for the
-dominant kernel of the workload (the LDS-DMA split-precision GEMM), and at N = 1: the Route A decode legs (BASELINE config 4: ms per decode step
-mean / median / p99, `roofline_decode_attention` = the HBM-bound kernel the north star names, `decode_step_roofline` = (KV + weight bytes) per step
-against HBM peak; f32 and f16 KV cache), the config 5 leg (top-k 32, 4 samples per layout, 64 sequences, shared condition prefix), the released
-3-camera shape, and `cpu_baseline` (the CPU oracle timed on this host: one full scene, plus Route A KV-cache vs full recompute).
+One SHORT JSON line on rank 0: the contract keys, `roofline` for the dominant kernel of the workload (the LDS-DMA split-precision GEMM; `traffic` measured by
+this run through two `rocprofv3 --pmc` child passes, tools/pmc_inrun.py), `cpu_baseline` (the CPU oracle timed on this host), and LAST a flat `legs` object with the
+scalar result of every other leg - at N = 1: Route A decode (BASELINE config 4: ms per decode step mean / median / p99, decode-attention roofline fraction by
+SURVEY 8(d)'s bytes and by storage bytes, whole-step fraction; f32 / f16 KV cache, f16 weights, density 0.35, split path), config 5 on one GPU, the released 3-camera
+shape, single-scene latency, exact-fp32 and f16-weights modes; at N > 1: the strong-scaling leg and BASELINE configs[4] across the ranks (64 sequences per GPU,
+token ids gathered to rank 0), per-rank step times.  The unabridged per-leg objects go to gpurun_out/bench_detail_n<N>.json (`detail_file`).
 """
 from __future__ import annotations
 
@@ -93,6 +94,11 @@ class _StubContext:
         import torch
         return (ids.reshape(ids.shape[0], -1)[:, :1, None, None] % 256).to(torch.uint8).expand(ids.shape[0], 3, 16 * latent_hw[0], 16 * latent_hw[1]).contiguous()
 
+    def ar_sample(self, cond_ids, I_inv, E_inv, steps=None, **kw):
+        import torch
+        g = torch.Generator().manual_seed(int(cond_ids.sum()) % (2 ** 31))
+        return torch.randint(0, self.cfg.vocab_size, (cond_ids.shape[0], self.cfg.num_cams, self.cfg.num_cam_tokens), generator=g)
+
     def profile_begin(self):
         pass
 
@@ -119,9 +125,35 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
+def gemm_algorithmic_bytes(cfg, batch):
+    """Mean algorithmic bytes per launch of the seven projections of a Route M layer (A + W + C, 4 bytes per element: operands are hi/lo f16 plane pairs)."""
+    M, D = batch * cfg.num_img_tokens, cfg.num_embed
+    F = int(D * 4 * 2 / 3)
+    Fp = (F + 31) // 32 * 32
+    shapes = [(D, D)] * 4 + [(2 * D, D), (2 * Fp, D), (D, Fp)]   # to_q / to_out (self, cross), to_kv, GEGLU up (C leaves half as wide), down
+    tot = 0.0
+    for n, k in shapes:
+        c = Fp if n == 2 * Fp else n
+        tot += 4.0 * (M * k + n * k + M * c)
+    return tot / len(shapes)
+
+
+def inrun_traffic(kernel_substr):
+    """`roofline.traffic`, measured by this run: tools/pmc_inrun.py spawns two `rocprofv3 --kernel-trace --pmc` child passes (FETCH_SIZE, WRITE_SIZE) over one
+    transformer forward of the headline workload - outside the timed region, rank 0, N = 1.  $BEVGEN_BENCH_NO_PMC=1 skips it (traffic = null)."""
+    if DRY_RUN or os.environ.get("BEVGEN_BENCH_NO_PMC") == "1":
+        return {"error": "skipped"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_inrun
+        return pmc_inrun.measure(kernel_substr)
+    except Exception as e:   # a failed counter pass must not take the bench line with it
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950
-    correction applied) at the probe shape recorded there - a PMC pass cannot run inside this process; None if no summary covers the kernel."""
+    correction applied) at the probe shape recorded there (detail file only: the headline `roofline.traffic` is measured in-run, see inrun_traffic)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")), reverse=True):
         try:
@@ -373,6 +405,65 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------- config 5 across ranks
+def config5_multi_rank(local_rank, rank, world, dist, steps):
+    """BASELINE configs[4] across the ranks: every GPU decodes 64 sequences (16 BEV layouts x 4 samples; the samples of a layout stay on one rank - they share the
+    condition prefix's K/V rows), top-k 32, explicit Philox-2025 uniforms, Route A config-4 model.  No data-path collective; one gather of the token ids to rank 0
+    inside the timed region (bevgen_amd.parallel.gather_token_ids).  Timing as the contract says: barrier + synchronize on both sides, max over ranks."""
+    import torch
+    from bevgen_amd import presets, synthetic
+    from bevgen_amd.parallel import gather_token_ids
+
+    S, batch, top_k = 4, 64, 32
+    cfg = presets.config4()
+    if DRY_RUN:
+        ctx = _StubContext(cfg)
+        steps = steps or 8
+    else:
+        from bevgen_amd.runtime import Context
+        from bevgen_amd.weights import gpt_state_dict
+        ctx = Context(cfg, route="ar", device=local_rank, max_batch=batch, kv_cache="f32")
+        ctx.load_state_dict(cached(("gpt", "config4"), lambda: gpt_state_dict(presets.config4(), 1234)))
+        ctx.set_tables()
+        ctx.finalize()
+        steps = steps or cfg.num_img_tokens
+    bt = synthetic.make_batch(cfg, batch // S, seed=5000 + rank)            # each rank: its own 16 layouts
+    bt = {k: v.repeat_interleave(S, dim=0).to(ctx.device) for k, v in bt.items()}
+    noise = synthetic.uniform_noise((steps, batch), 2025, 1 + rank).to(ctx.device)
+    sync = (lambda: None) if DRY_RUN else torch.cuda.synchronize
+
+    def run(n):
+        ids = ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=n, greedy=False, top_k=top_k, temperature=1.0,
+                            noise_u=noise[:n].contiguous() if n != steps else noise, samples_per_layout=S)
+        return gather_token_ids(ids, dist)
+
+    run(min(8, steps))   # warm-up (graph capture, workspace)
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = run(steps)
+    sync()
+    mine = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, mine], dtype=torch.float64, device=ctx.device)
+    per_rank = [t.clone() for _ in range(world)] if dist else [t]
+    if dist:
+        dist.all_gather(per_rank, t)
+    elapsed = max(float(x[0]) for x in per_rank)
+    ctx.close()
+    if rank != 0:
+        return None
+    assert out is not None and out.shape[0] == world * batch
+    return {"scaling": "weak", "sequences_per_gpu": batch, "layouts_per_gpu": batch // S, "samples_per_layout": S, "top_k": top_k, "decode_steps": steps,
+            "sequences_per_s": world * batch / elapsed, "ms_per_decode_step": elapsed * 1e3 / steps, "per_rank_ms_per_decode_step": [float(x[1]) * 1e3 / steps for x in per_rank],
+            "gathered_token_ids": list(out.shape),
+            "config": "BASELINE configs[4]: Route A config-4 model, top-k 32, explicit uniforms (Philox seed 2025), 16 BEV layouts x 4 samples per GPU (a layout's samples share "
+                      "one rank and its condition-prefix K/V), token ids gathered to rank 0 over RCCL"}
+
+
 # ----------------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -433,6 +524,7 @@ def main():
         for i in range(steps):
             one_step(ev[i])
         sync()
+        mine = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier)
         if dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -447,32 +539,38 @@ def main():
         prof_elapsed = time.perf_counter() - tp0
         prof = ctx.profile_end()
         prof["_pass"] = {"steps": prof_steps, "ms": prof_elapsed * 1e3, "launches": 0}
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        t = torch.tensor([elapsed, mine], dtype=torch.float64, device=ctx.device)
+        per_rank = [t.clone() for _ in range(world)] if dist else [t]
         if dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_gather(per_rank, t)
         parts = {"step": [e[0].elapsed_time(e[3]) for e in ev], "generate": [e[0].elapsed_time(e[1]) for e in ev],
-                 "vq_decode": [e[1].elapsed_time(e[2]) for e in ev], "gather": [e[2].elapsed_time(e[3]) for e in ev]}
+                 "vq_decode": [e[1].elapsed_time(e[2]) for e in ev], "gather": [e[2].elapsed_time(e[3]) for e in ev],
+                 "per_rank_ms_per_step": [float(x[1]) * 1e3 / steps for x in per_rank]}
         ctx.close()
-        return float(t.item()), prof, parts
+        return max(float(x[0]) for x in per_rank), prof, parts, cfg
 
-    elapsed, prof, parts = run_route_m(args.precision, args.steps, args.warmup, args.cams, args.batch)
+    elapsed, prof, parts, cfg_m = run_route_m(args.precision, args.steps, args.warmup, args.cams, args.batch)
     strong = None
     if world > 1 and 16 % world == 0:
         s_steps = max(2, min(args.steps, 5))
-        e_s, _, _ = run_route_m(args.precision, s_steps, 1, args.cams, 16 // world)   # 16 scenes in total, sharded
-        strong = {"scaling": "strong", "global_batch": 16, "scenes_per_gpu": 16 // world, "steps": s_steps, "value": 16 * s_steps / e_s, "unit": "scenes/s", "ms_per_step": e_s * 1e3 / s_steps}
+        e_s, _, p_s, _ = run_route_m(args.precision, s_steps, 1, args.cams, 16 // world)   # 16 scenes in total, sharded
+        strong = {"scaling": "strong", "global_batch": 16, "scenes_per_gpu": 16 // world, "steps": s_steps, "value": 16 * s_steps / e_s, "unit": "scenes/s", "ms_per_step": e_s * 1e3 / s_steps,
+                  "per_rank_ms_per_step": p_s["per_rank_ms_per_step"]}
+    c5_multi = None
+    if world > 1 and not args.no_decode_leg:
+        c5_multi = config5_multi_rank(local_rank, rank, world, dist, args.decode_steps)
     exact = None
     if DRY_RUN:
         args.no_extra_legs = args.no_decode_leg = args.no_cpu_baseline = args.no_exact_leg = True
     if world == 1 and args.precision != "fp32" and not args.no_exact_leg:
-        e2, p2, _ = run_route_m("fp32", 1, 1, args.cams, args.batch)   # the exact-fp32 parity mode on the same workload (one step)
+        e2, p2, _, _ = run_route_m("fp32", 1, 1, args.cams, args.batch)   # the exact-fp32 parity mode on the same workload (one step)
         exact = (e2, p2)
 
     w16 = None
     if world == 1 and args.precision != "fp32" and not args.no_extra_legs:
         # the f16-weights model (GEMM / convolution matrices rounded to f16 at load, two MFMAs per product; tokens bit-exact vs the oracle on the rounded
         # weights, tests): NOT the headline - a different (rounded) model, reported beside it
-        e4, p4, parts4 = run_route_m(args.precision, 2, 1, args.cams, args.batch, weights="f16")
+        e4, p4, parts4, _ = run_route_m(args.precision, 2, 1, args.cams, args.batch, weights="f16")
         w16 = (e4, p4, parts4)
 
     if rank != 0:
@@ -480,43 +578,55 @@ def main():
             dist.destroy_process_group()
         return
 
-    def roof(prof, precision):
+    def roof(prof, precision, measure=False):
         g = prof["gemm"]
         ach = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         if precision == "fp32":
             peak, kern, note = MFMA_FP32_PEAK_TF, "gemm_f32_kernel<MODE_PLAIN>", "v_mfma_f32_32x32x2_f32, exact fp32"
         else:
             peak, kern, note = MFMA_F16_PEAK_TF / 3.0, "gemm_split_glds_kernel<MODE_PLAIN, 4, 3>", "3 v_mfma_f32_32x32x16_f16 per fp32 product (hi/lo split): ceiling = f16 dense peak / 3"
-        tr = pmc_traffic(kern)
-        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr, "kernel": kern, "note": note,
-                "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1),
-                # launches of the same GEMM family that are not this kernel (small-problem blocks, the short last part of a row-split launch): timed apart, so that
-                # launches / avg_us above are one kernel's and can be held against the rocprof trace
-                "other_gemm_launches": {"launches": int(prof.get("gemm_small", {}).get("launches", 0)), "ms": prof.get("gemm_small", {}).get("ms", 0.0)}}
+        r = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "kernel": kern, "note": note,
+             "launches": int(g["launches"]), "avg_us": g["ms"] * 1e3 / max(g["launches"], 1),
+             # launches of the same GEMM family that are not this kernel (small-problem blocks, the short last part of a row-split launch): timed apart, so that
+             # launches / avg_us above are one kernel's and can be held against the rocprof trace
+             "other_gemm_launches": {"launches": int(prof.get("gemm_small", {}).get("launches", 0)), "ms": prof.get("gemm_small", {}).get("ms", 0.0)}}
+        if measure and world == 1 and precision != "fp32":
+            tr = inrun_traffic("gemm_split_glds_kernel<0, 4, 3")
+            if "error" in tr:
+                r["traffic_note"] = "not measured: " + tr["error"]
+            else:
+                alg = gemm_algorithmic_bytes(cfg_m, args.batch)
+                r["traffic"] = tr["bytes_per_launch"]
+                r["traffic_detail"] = dict(tr, algorithmic_bytes_per_launch=alg, traffic_over_algorithmic=tr["bytes_per_launch"] / alg)
+        return r
 
     import numpy as np
     scenes = n_gpus * args.batch * args.steps
-    line = {
+    detail = {
         "metric": "multi-view scenes/sec (6x256x256)", "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps, "ms_per_step_median": pct(parts["step"], 50), "ms_per_step_p99": pct(parts["step"], 99),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM/conv/attention products as 3 f16 MFMAs on hi/lo splits, fp32 accumulate; everything else fp32)",
+        "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM/conv/attention products as 3 f16 MFMAs on hi/lo splits, fp32 accumulate)",
         "data": "synthetic" if not DRY_RUN else "DRY RUN: stub context on CPU, control flow only - no performance meaning",
-        "config": {"workload": f"BASELINE configs[1]: Route M MaskGit (14 layers, D=1024, 18 iterations, top-k 0.9 + gumbel / critic noise, self-critic) {args.cams}x256x256, batch {args.batch} scenes/GPU, + VQGAN f16 decode to uint8",
+        "config": {"workload": f"BASELINE configs[1]: Route M MaskGit, {args.cams}x256x256, batch {args.batch} scenes/GPU, 18 iterations, + VQGAN decode to uint8",
                    "global_batch": n_gpus * args.batch, "parallelism": f"scene-parallel x{n_gpus} (RCCL gather of uint8 pixels)", "precision_mode": args.precision},
+        "rccl_world_size": n_gpus, "per_rank_ms_per_step": parts["per_rank_ms_per_step"],
         "ms_per_maskgit_iteration": float(np.mean(parts["generate"])) / args.timesteps,
         "vqgan_decode_ms_per_scene": float(np.mean(parts["vq_decode"])) / args.batch,
         "gather_ms_per_step": float(np.mean(parts["gather"])),
-        "roofline": roof(prof, args.precision),
+        "roofline": roof(prof, args.precision, measure=True),
         "kernel_time_share": {k: v["ms"] / prof["_pass"]["ms"] for k, v in prof.items() if v["launches"]},
         "kernel_tflops": {k: (v["work"] / (v["ms"] * 1e-3) / 1e12) for k, v in prof.items() if v["launches"] and k in ("gemm", "gemm_small", "conv3x3", "attention")},
         "profiled_pass": {"steps": prof["_pass"]["steps"], "ms_per_step": prof["_pass"]["ms"] / prof["_pass"]["steps"],
                           "note": "roofline / kernel_time_share / kernel_tflops come from this separate pass of the same step with a HIP-event pair around every hot launch; `value` is timed without it"},
     }
+    line = detail
     if DRY_RUN:
         line["dry_run"] = True
     if strong is not None:
         line["strong_scaling"] = strong
+    if c5_multi is not None:
+        line["config5"] = c5_multi
     if exact is not None:
         e2, p2 = exact
         line["exact_fp32_mode"] = {"value": args.batch / e2, "unit": "scenes/s", "ms_per_step": e2 * 1e3, "roofline": roof(p2, "fp32"),
@@ -535,33 +645,31 @@ def main():
                                             "every call), activations and attention operands keep their hi + lo planes; same workload, 2 steps.  A different (rounded) model: the "
                                             "headline above is the fp32-weights model"}
     if world == 1 and not args.no_extra_legs:
-        e3, _, p3 = run_route_m(args.precision, 2, 1, 3, args.batch)   # the shape of the released Argoverse checkpoint (3 cameras, N=768)
+        e3, _, p3, _ = run_route_m(args.precision, 2, 1, 3, args.batch)   # the shape of the released Argoverse checkpoint (3 cameras, N=768)
         line["released_3_camera_shape"] = {"value": args.batch * 2 / e3, "unit": "scenes/s", "ms_per_step": e3 * 1e3 / 2, "ms_per_maskgit_iteration": float(np.mean(p3["generate"])) / args.timesteps,
                                            "config": f"Route M, 3x256x256 (configs/modes/argoverse.yaml), batch {args.batch}, 2 steps"}
     if world == 1 and not args.no_extra_legs and args.batch > 1:
         # the interactive caller's shape (scripts/interactive_editing.py:273-277): ONE scene per call - latency, not throughput.  Same step (MaskGit generate + VQGAN decode
         # to uint8), the library picks its small-grid kernels by itself (64- / 128-row GEMM blocks, key-split self-attention, row-split launches)
-        e1, _, p1 = run_route_m(args.precision, 3, 1, args.cams, 1)
+        e1, _, p1, _ = run_route_m(args.precision, 3, 1, args.cams, 1)
         line["single_scene_latency"] = {"value": e1 * 1e3 / 3, "unit": "ms per scene", "higher_is_better": False, "ms_per_maskgit_iteration": float(np.mean(p1["generate"])) / args.timesteps,
                                         "config": f"Route M, {args.cams}x256x256, batch 1, 3 steps"}
+    dkeys = ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline", "visible_fraction_of_causal_keys")
     if world == 1 and not args.no_decode_leg:
         line.update(decode_leg(local_rank, args.decode_batch, args.decode_steps))
         # BASELINE config 4 names fp16 storage: the same decode with the KV cache stored as fp16 (fp32 accumulate; logits within 2e-3 of the range, tests)
         f16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16")
-        line["decode_f16_kv_cache"] = {k: f16[k] for k in ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline")}
+        line["decode_f16_kv_cache"] = {k: f16[k] for k in dkeys}
         # ... and the all-fp16-storage model (projection weights rounded to fp16 at load, tokens bit-exact vs the oracle on the rounded weights; fp32 arithmetic)
         h16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16")
-        line["decode_f16_kv_cache_f16_weights"] = {k: h16[k] for k in ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline")}
-        keys = ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline", "visible_fraction_of_causal_keys")
+        line["decode_f16_kv_cache_f16_weights"] = {k: h16[k] for k in dkeys}
         if not args.no_extra_legs:
             # SURVEY 8(d) config 4 variant: density 0.35, every layer with its own random per-head block layouts - the key walk follows the chunk lists of present blocks
             d35 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", density=0.35)
-            line["decode_density_035_f16_kv_cache"] = {k: d35[k] for k in keys}
-            # the four-launch form: the decode-attention kernel proper (K/V stream only) with the projection as its own MFMA kernel - slower per step than the fused
-            # form (a 14.6 us projection kernel + an 8.9 us attention kernel vs 19.0 us fused at context ~556), reported for its attention-kernel roofline
+            line["decode_density_035_f16_kv_cache"] = {k: d35[k] for k in dkeys}
+            # the four-launch form: the decode-attention kernel proper (K/V stream only) with the projection as its own MFMA kernel, reported for its attention-kernel roofline
             sp = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16", path="split")
-            line["decode_split_path_f16_kv_cache_f16_weights"] = {k: sp[k] for k in keys}
-        if not args.no_extra_legs:
+            line["decode_split_path_f16_kv_cache_f16_weights"] = {k: sp[k] for k in dkeys}
             c5 = decode_leg(local_rank, 64, args.decode_steps, kv_cache="f32", S=4, top_k=32, stochastic=True)
             line["config5_topk32_4_samples_per_layout"] = {"sequences": 64, "layouts": 16, "ms_per_decode_step": c5["ms_per_decode_step"], "ms_per_decode_step_median": c5["ms_per_decode_step_median"],
                                                            "ms_per_decode_step_p99": c5["ms_per_decode_step_p99"], "sequences_per_s": c5["decode_sequences_per_s"], "prefill_ms": c5["decode_prefill_ms"],
@@ -569,7 +677,69 @@ def main():
                                                            "config": "BASELINE configs[4] on one GPU: Route A config-4 model, top-k 32, explicit uniforms (Philox seed 2025), 16 BEV layouts x 4 samples, condition prefix prefilled and read once per layout"}
     if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "none":
         line["cpu_baseline"] = cpu_baseline(args.cams, args.timesteps, args.cpu_baseline)
-    print(json.dumps(line), flush=True)
+
+    # ---- what is printed: ONE short JSON line (contract keys + compact `roofline` / `cpu_baseline` + flat scalars per leg, `legs` LAST so that it survives a tail
+    #      cut); everything above goes, unabridged, to the detail file next to it
+    detail_path = os.path.join(ROOT, "gpurun_out", f"bench_detail_n{n_gpus}.json")
+    try:
+        os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+        json.dump(detail, open(detail_path, "w"), indent=1)
+    except OSError as e:
+        detail_path = f"not written: {e}"
+    short = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                                    "rccl_world_size", "per_rank_ms_per_step")}
+    if DRY_RUN:
+        short["dry_run"] = True
+    r = detail["roofline"]
+    short["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches", "avg_us")}
+    if r.get("traffic_detail"):
+        short["roofline"]["traffic_over_algorithmic"] = r["traffic_detail"]["traffic_over_algorithmic"]
+        short["roofline"]["traffic_source"] = "in-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes"
+    elif r.get("traffic_note"):
+        short["roofline"]["traffic_note"] = r["traffic_note"][:100]
+    if "cpu_baseline" in detail:
+        c = detail["cpu_baseline"]
+        short["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                                 "sample": f"1 scene end to end, {c['sample'].split('MaskGit generate with ')[1].split(' =')[0]} of {args.timesteps} scaled linearly, {c['host']['threads_used']} torch threads on {c['host']['cpu_model']}"[:118]}
+    short["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
+
+    def rnd(x, n=4):
+        return None if x is None else round(float(x), n)
+
+    def dshort(d):
+        ra, rs = d["roofline_decode_attention"], d["decode_step_roofline"]
+        return {"ms_step": rnd(d["ms_per_decode_step"]), "median": rnd(d["ms_per_decode_step_median"]), "p99": rnd(d["ms_per_decode_step_p99"]),
+                "attn_frac_8d_fp16_bytes": rnd(ra.get("frac_by_survey_8d_fp16_bytes")), "attn_frac_storage_bytes": rnd(ra["frac"]), "attn_avg_us": rnd(ra["avg_us"], 2),
+                "attn_phase_frac": rnd(ra["attention_phase"]["frac"]), "step_frac": rnd(rs["frac"])}
+
+    legs = {"ms_per_step_median": rnd(detail["ms_per_step_median"], 2), "ms_per_step_p99": rnd(detail["ms_per_step_p99"], 2), "ms_per_maskgit_iteration": rnd(detail["ms_per_maskgit_iteration"], 3),
+            "vqgan_decode_ms_per_scene": rnd(detail["vqgan_decode_ms_per_scene"], 3), "gather_ms_per_step": rnd(detail["gather_ms_per_step"], 3),
+            "kernel_tflops": {k: rnd(v, 1) for k, v in detail["kernel_tflops"].items()}, "kernel_time_share": {k: rnd(v, 3) for k, v in detail["kernel_time_share"].items() if k != "_pass"}}
+    if strong is not None:
+        legs["strong_scaling"] = {"global_batch": 16, "scenes_per_s": rnd(strong["value"]), "ms_per_step": rnd(strong["ms_per_step"], 2), "per_rank_ms_per_step": [rnd(x, 2) for x in strong["per_rank_ms_per_step"]]}
+    if c5_multi is not None:
+        legs["config5"] = {"sequences_per_s": rnd(c5_multi["sequences_per_s"], 2), "ms_per_decode_step": rnd(c5_multi["ms_per_decode_step"]), "sequences_per_gpu": 64, "decode_steps": c5_multi["decode_steps"],
+                           "per_rank_ms_per_decode_step": [rnd(x) for x in c5_multi["per_rank_ms_per_decode_step"]]}
+    if "single_scene_latency" in detail:
+        legs["single_scene_latency_ms"] = rnd(detail["single_scene_latency"]["value"], 2)
+    if "released_3_camera_shape" in detail:
+        legs["released_3_camera_scenes_per_s"] = rnd(detail["released_3_camera_shape"]["value"], 3)
+    if "exact_fp32_mode" in detail:
+        legs["exact_fp32"] = {"scenes_per_s": rnd(detail["exact_fp32_mode"]["value"], 3), "gemm_frac": rnd(detail["exact_fp32_mode"]["roofline"]["frac"], 3)}
+    if "f16_weights_mode" in detail:
+        legs["f16_weights"] = {"scenes_per_s": rnd(detail["f16_weights_mode"]["value"], 3), "gemm_frac": rnd(detail["f16_weights_mode"]["roofline"]["frac"], 3)}
+    if "ms_per_decode_step" in detail:
+        legs["decode_config4_B16"] = {"f32_kv": dshort(detail), "prefill_ms": rnd(detail["decode_prefill_ms"], 2)}
+        for name, key in (("f16_kv", "decode_f16_kv_cache"), ("f16_kv_f16_w", "decode_f16_kv_cache_f16_weights"), ("density035_f16_kv", "decode_density_035_f16_kv_cache"),
+                          ("split_path_f16_kv_f16_w", "decode_split_path_f16_kv_cache_f16_weights")):
+            if key in detail:
+                legs["decode_config4_B16"][name] = dshort(detail[key])
+        if "config5_topk32_4_samples_per_layout" in detail:
+            c = detail["config5_topk32_4_samples_per_layout"]
+            legs["config5_64seq_1gpu"] = {"ms_step": rnd(c["ms_per_decode_step"]), "median": rnd(c["ms_per_decode_step_median"]), "p99": rnd(c["ms_per_decode_step_p99"]),
+                                          "sequences_per_s": rnd(c["sequences_per_s"], 2), "attn_frac_storage_bytes": rnd(c["roofline_decode_attention"]["frac"]), "step_frac": rnd(c["decode_step_roofline"]["frac"])}
+    short["legs"] = legs
+    print(json.dumps(short), flush=True)
     if dist:
         dist.destroy_process_group()
 

@@ -162,6 +162,8 @@ void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_
     const int G = B / S;   // layouts = sequences actually prefilled
     const int D = c.D, H = c.H, K = c.K, L = c.L;
     auto& st = c.ars;
+    // decode_path = auto: the split layer's QKV operand image is packed by the first batch that will run it (S sequences per workgroup only on the fused paths)
+    if (effective_decode_path(c, B, fused_path(c, B, S) ? S : 1) == BEVGEN_DECODE_SPLIT) ctx_pack_split_qkv(c, s);
     // persistent per-batch state
     const size_t cache_b = (size_t)g.num_layers * B * H * L * 64 * cache_elem_bytes(c);
     const size_t img_b = g.image_embed ? (size_t)B * g.num_cams * c.T * D * sizeof(float) : 0;

@@ -159,6 +159,8 @@ static void finalize_muse(Ctx& c) {
         expect_shape(c, "token_critic.to_pred.bias", {1});
     }
     const int inner = H * 64;
+    // the Route M workspace (qraw, att, split-K partial tiles) and every projection call size their rows by D: the released model has heads * 64 == dim
+    BG_REQUIRE(inner == D, "Route M: num_heads * 64 = %d must equal dim = %d", inner, D);
     c.Fpad = (int)round_up(F, 32);
     c.muse.resize(g.num_layers);
     for (int i = 0; i < g.num_layers; ++i) {
@@ -241,6 +243,15 @@ static void finalize_muse(Ctx& c) {
     }
 }
 
+// operand image of the fused QKV weight for the split decode layer's LayerNorm + projection kernel (packed like the MLP images)
+static void pack_split_qkv_layer(Ctx& c, ArLayer& l, hipStream_t s) {
+    const int D = c.D;
+    const bool wf16 = c.cfg.decode_weight_dtype == BEVGEN_W_F16;
+    l.wqkv_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(3 * D, D) * (wf16 ? sizeof(_Float16) : sizeof(float))));
+    if (wf16) launch_pack_skinny_weight_f16(l.wqkv, l.wqkv_wp, 3 * D, D, s);
+    else launch_pack_skinny_weight(l.wqkv, l.wqkv_wp, 3 * D, D, s);
+}
+
 static void finalize_ar(Ctx& c) {
     const auto& g = c.cfg;
     const int D = c.D;
@@ -276,11 +287,9 @@ static void finalize_ar(Ctx& c) {
         }
         if (fused_like) {
             const size_t eb = wf16 ? sizeof(_Float16) : sizeof(float);
-            if (g.decode_path == BEVGEN_DECODE_SPLIT || g.decode_path == BEVGEN_DECODE_AUTO) {
-                l.wqkv_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(3 * D, D) * eb));
-                if (wf16) launch_pack_skinny_weight_f16(l.wqkv, l.wqkv_wp, 3 * D, D, 0);
-                else launch_pack_skinny_weight(l.wqkv, l.wqkv_wp, 3 * D, D, 0);
-            }
+            // decode_path = split packs the QKV operand image now; auto packs it on the first call that resolves to the split layer (ctx_pack_split_qkv:
+            // 3 D D elements per layer, ~300 MB at config 4 in fp32, that a context whose calls all carry more than four sequences never needs)
+            if (g.decode_path == BEVGEN_DECODE_SPLIT) pack_split_qkv_layer(c, l, 0);
             l.mlp0_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(4 * D, D) * eb));
             l.mlp2_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(D, 4 * D) * eb));
             if (wf16) {
@@ -354,7 +363,9 @@ static void finalize_ar(Ctx& c) {
     uint16_t* chunks = reinterpret_cast<uint16_t*>(c.own(chunk_plane * c.keep_layers * sizeof(uint16_t)));
     for (int i = 0; i < c.keep_layers; ++i)
         launch_build_layout(reinterpret_cast<const int64_t*>(lays[i]->ptr), c.lay + i * lay_plane, chunks + i * chunk_plane, c.keep_heads, nb, blk, c.L, c.chunks_ld, 0);
-    c.chunks = skippable ? chunks : nullptr;
+    // (a layout that hides an allowed element anywhere - also above the diagonal - makes vis_of_layer() hand out the layout: its chunk lists must go with it,
+    // the fused decode kernel walks them: launch_ar_attn_fused requires lists whenever a layout is set)
+    c.chunks = (skippable || lay_hides) ? chunks : nullptr;
     // prefill bias over the condition rows: scale*(bias) where visible, -1e30 elsewhere.  One image when the layers share their layout;
     // per-layer layouts (density < 1) build theirs in the prefill's workspace, layer by layer (ar.cpp)
     c.Kpad = (int)round_up(c.K, 32);
@@ -363,6 +374,12 @@ static void finalize_ar(Ctx& c) {
         c.prefill_bias = reinterpret_cast<float*>(c.own((size_t)c.keep_heads * c.K * c.Kpad * sizeof(float)));
         launch_build_masked_bias(c.attn_bias, c.vis_of_layer(0), c.prefill_bias, c.keep_heads, c.K, c.K, c.Kpad, c.L, 0.125f, 0);
     }
+}
+
+void ctx_pack_split_qkv(Ctx& c, hipStream_t s) {
+    if (c.ar.empty() || c.ar[0].wqkv_wp) return;
+    for (ArLayer& l : c.ar) pack_split_qkv_layer(c, l, s);
+    HIP_CHECK(hipStreamSynchronize(s));   // once per context, before the first split-path step is captured
 }
 
 void ctx_finalize(Ctx& c) {

@@ -180,6 +180,7 @@ struct Ctx {
 // context.cpp
 void ctx_load_tensor(Ctx& c, const char* name, const void* h, int dtype, int ndim, const int64_t* shape);
 void ctx_finalize(Ctx& c);
+void ctx_pack_split_qkv(Ctx& c, hipStream_t s);   // decode_path = auto: QKV operand image of the split decode layer, packed on first need
 // muse.cpp
 void muse_forward(Ctx& c, const int64_t* ids, const int64_t* cond, const float* I_inv, const float* E_inv, int B, float* logits, float* embed, hipStream_t s);
 void maskgit_generate(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, int timesteps, const int32_t* sched, float temperature,

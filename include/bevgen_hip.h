@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BEVGEN_ABI_VERSION 3
+#define BEVGEN_ABI_VERSION 4   /* 4: BEVGEN_PROFILE_KINDS 5 -> 6 (bevgen_profile_end writes 18 doubles), bevgen_cfg.decode_chains, decode_path values 2 / 3 */
 
 enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
 /* FP32  : every product and accumulation in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32) - bit-exact greedy tokens vs the CPU reference.

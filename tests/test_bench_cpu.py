@@ -32,10 +32,18 @@ def test_bench_world_2_control_flow_under_gloo():
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["global_batch"] == 8 and "x2" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6     # whole-job scenes / max-over-ranks time
-    s = d["strong_scaling"]
-    assert s["scaling"] == "strong" and s["global_batch"] == 16 and s["scenes_per_gpu"] == 8 and s["value"] > 0
-    for k in ("roofline", "cpu_baseline", "ms_per_decode_step"):     # single-GPU legs stay off in a multi-rank run (cpu_baseline: rank 0 at N = 1 only)
-        assert k == "roofline" or k not in d
+    assert d["rccl_world_size"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.0001   # per-rank K-step times <= the job's
+    legs = d["legs"]
+    assert list(d)[-1] == "legs", "the flat per-leg scalars come LAST in the line (they must survive a tail cut)"
+    s = legs["strong_scaling"]
+    assert s["global_batch"] == 16 and s["scenes_per_s"] > 0 and len(s["per_rank_ms_per_step"]) == 2
+    c5 = legs["config5"]       # BASELINE configs[4] across the ranks: 64 sequences per GPU, token ids gathered to rank 0
+    assert c5["sequences_per_gpu"] == 64 and c5["sequences_per_s"] > 0 and len(c5["per_rank_ms_per_decode_step"]) == 2
+    assert abs(c5["sequences_per_s"] - 2 * 64 / (c5["ms_per_decode_step"] * c5["decode_steps"] * 1e-3)) / c5["sequences_per_s"] < 1e-2
+    assert "cpu_baseline" not in d and "decode_config4_B16" not in legs      # single-GPU legs stay off in a multi-rank run (cpu_baseline: rank 0 at N = 1 only)
+    assert "roofline" in d and len(lines[0]) < 4000, "the printed line stays short; the per-leg objects live in the detail file"
+    detail = json.load(open(os.path.join(ROOT, d["detail_file"])))
+    assert detail["config5"]["gathered_token_ids"][0] == 128 and detail["strong_scaling"]["scaling"] == "strong"
 
 
 def test_bench_self_launch_and_world_size_mismatch():
@@ -55,4 +63,5 @@ def test_bench_single_rank_dry_run_line_shape():
     r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--batch", "2"])
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 1 and d["metric"].startswith("multi-view scenes/sec") and d["unit"] == "scenes/s" and d["vs_baseline"] is None and "strong_scaling" not in d
+    assert d["n_gpus"] == 1 and d["metric"].startswith("multi-view scenes/sec") and d["unit"] == "scenes/s" and d["vs_baseline"] is None
+    assert "strong_scaling" not in d["legs"] and "config5" not in d["legs"] and d["rccl_world_size"] == 1 and d["roofline"]["traffic"] is None
