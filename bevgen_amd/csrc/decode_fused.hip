@@ -96,6 +96,23 @@ __device__ __forceinline__ float wave_sum_dpp(float d) {
     return d + xor32(d);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every global load / LDS-DMA a wave has in flight must land before it passes - in
+// the fused decode kernel that makes the LayerNorm barriers wait for the K/V pieces and weight rows streaming behind them (statistics done at 6.5 instead of 3.9 us).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS-DMA request the compiler does not see (inline asm): 16 bytes per lane from `src` (per-lane address) to LDS byte address `lds_base` + lane * 16 (wave-uniform base).
+// With the builtin, LLVM's wait-count pass counts the request like a load and - not knowing which LDS bytes it writes - puts `s_waitcnt vmcnt(0)` in front of later LDS
+// writes (the xn / bias row stores of ln1 then waited for every K/V piece: statistics done at 10.0 instead of 5.8 us).  Hidden requests only ever make the compiler's counted
+// waits stricter (loads return in issue order; an uncounted later request means it waits for a few more of the older ones), never weaker; the one reader of the staged bytes
+// (Attend::run_staged) orders itself by an explicit vmcnt wait.
+__device__ __forceinline__ void glds16_hidden(const void* src, unsigned lds_base) {
+    unsigned keep;   // (m0 is the compiler's: saved and restored around the request)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 constexpr float kLog2eF = 1.44269504088896340736f;
 constexpr int AF_WAVES = 16;
 
@@ -189,6 +206,46 @@ struct Attend {
             if (j + 1 < steps) compute<USTRIDE>(b1, key_of(j + 1), k_end, bias_s, q, m, l, acc);
         }
     }
+    // Dense walk over the keys [0, k_end) by a team of NSLOTS waves whose leading `js` pipeline steps were STAGED in LDS while the kernel's prologue ran:
+    // step j of wave `slot` = U K pieces + U V pieces of 1 KiB (piece p = j U + u = keys p NSLOTS KPI + slot KPI .. + KPI - 1), staged step-major at
+    // st + (2 U j + u) KiB (K) / st + (2 U j + U + u) KiB (V), st = the wave's region + lane * 16.  The pieces were requested by LDS-DMA earlier; the walk opens by requesting
+    // its first TWO global steps - they queue behind the pieces in the CU's in-order memory pipeline and keep HBM busy - then waits until only those are outstanding (every
+    // piece has landed: loads return in issue order), scores the staged steps out of LDS, and continues with the global steps already in flight: no cold start.
+    template <int NSLOTS>
+    __device__ static __forceinline__ void run_staged(const void* kc, const void* vc, long row0, int slot, int kslot, int k_end, int sub, const float* bias_s, const char* st, int js,
+                                                      const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL]) {
+        constexpr int USTRIDE = NSLOTS * KPI, SPAN = U * NSLOTS * KPI;
+        const int steps = k_end > 0 ? (k_end + SPAN - 1) / SPAN : 0;   // js <= steps: staged steps are whole steps below k_end
+        auto key_of = [&](int j) { return j * SPAN + slot * KPI + kslot; };
+        Buf b0, b1;
+        if (js + 1 < steps) {
+            load<USTRIDE>(b0, kc, vc, row0, key_of(js), k_end, sub);
+            load<USTRIDE>(b1, kc, vc, row0, key_of(js + 1), k_end, sub);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * U) : "memory");
+        } else if (js < steps) {
+            load<USTRIDE>(b0, kc, vc, row0, key_of(js), k_end, sub);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * U) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int j = 0; j < js; ++j) {   // (one K/V piece pair at a time: a third U-deep register buffer next to b0 / b1 spills in the fp32-cache variants)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                typename Attend<DT, NQ, 1>::Buf t;
+                t.k[0] = *reinterpret_cast<const typename T::Raw*>(st + (2 * U * j + u) * 1024);
+                t.v[0] = *reinterpret_cast<const typename T::Raw*>(st + (2 * U * j + U + u) * 1024);
+                Attend<DT, NQ, 1>::template compute<USTRIDE>(t, key_of(j) + u * USTRIDE, k_end, bias_s, q, m, l, acc);
+            }
+        }
+        for (int j = js; j < steps; j += 2) {
+            compute<USTRIDE>(b0, key_of(j), k_end, bias_s, q, m, l, acc);
+            if (j + 2 < steps) load<USTRIDE>(b0, kc, vc, row0, key_of(j + 2), k_end, sub);
+            if (j + 1 < steps) {
+                compute<USTRIDE>(b1, key_of(j + 1), k_end, bias_s, q, m, l, acc);
+                if (j + 3 < steps) load<USTRIDE>(b1, kc, vc, row0, key_of(j + 3), k_end, sub);
+            }
+        }
+    }
 };
 
 // merge the key slots of a wave (lanes with equal `sub`); afterwards every lane holds the wave's state for its dims
@@ -210,23 +267,31 @@ __device__ __forceinline__ void wave_merge(float& m, float& l, float (&acc)[DPL]
     m = m_all;
 }
 
+// key loads per lane group and pipeline step of the private walk (fp16 rows: 3 or 4 measured no faster)
+template <int DT, int G> struct WalkU { static constexpr int value = (G == 1 && DT == 0) ? 4 : 2; };
+
 #define AF_TRACE(i) do { if (a.trace && tid == 0) a.trace[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 
 // Second half of both attention kernels: this step's k / v rows (qkv_s, LDS) go into the cache, the walk over the visible 16-key chunks, the merge of the
 // 16 waves, + residual (res_s[g * ldres + d], LDS) -> out.  Called by every thread of the workgroup after a barrier that made qkv_s / bias_s / the list visible.
-template <int DT, int G, bool SP>   // SP: the walk follows a chunk list (block-sparse layout); false = the dense interleaved walk with every stride a constant
+// SP: the walk follows a chunk list (block-sparse layout); false = the dense interleaved walk with every stride a constant.
+// STG (G = 1, dense): the walk opens with `js` steps staged in LDS at `st` (Attend::run_staged)
+template <int DT, int G, bool SP, bool STG = false>
 __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a, const float* bias_s, const float* qkv_s, float* red, const uint16_t* walk, int n_pos, int p_pos,
-                                                       int n, int head, int b0, const float* res_s, int ldres, float* pf_sink) {
+                                                       int n, int head, int b0, const float* res_s, int ldres, float* pf_sink, const char* st = nullptr, int js = 0) {
+    static_assert(!STG || (G == 1 && !SP), "staged steps are defined on the dense walk of one sequence");
     using T = KvRow<DT>;
     constexpr int LPK = T::LPK, DPL = T::DPL, NW = AF_WAVES, TW = NW / G;
-    constexpr int U = (G == 1 && DT == 0) ? 4 : 2;   // key loads per lane group and pipeline step (fp16 rows: 3 or 4 measured no faster)
+    constexpr int U = WalkU<DT, G>::value;
     constexpr int UP = G >= 4 ? 1 : U;   // same for the shared-prefix phase (G queries' state lives in registers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane % LPK, kslot = lane / LPK;
     const int row = n - 1;
     const float sl2 = a.scale * kLog2eF;
-    // ---- append this step's k / v rows to the cache (row n-1 of every sequence of the group); read back through the normal path below
-    //      (key split: the workgroup that owns the LAST list positions - the new key sits in the last visible chunk - appends; nobody else reads that row)
+    // ---- append this step's k / v rows to the cache (row n-1 of every sequence of the group).  The row is NOT read back by this launch: the walk below covers the keys
+    //      [0, n-1) that were in the cache when the kernel started, and the new key joins in the merge straight from LDS (rounded to the cache's storage type, so that
+    //      it counts exactly as the next step will read it).  No barrier, no wait for the store: nothing in this launch depends on it.
+    //      (key split: the workgroup that owns the LAST list positions appends and counts the new key)
     if (tid < 128 * G && blockIdx.z + 1 == gridDim.z) {
         const int g = tid >> 7, is_v = (tid >> 6) & 1, d = tid & 63;
         const float val = qkv_s[g * 192 + 64 + is_v * 64 + d];
@@ -235,7 +300,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
         if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
         else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)val;
     }
-    __syncthreads();
+    const int n_old = n - 1;   // keys the walk covers
 
     AF_TRACE(3);
     // ---- attention
@@ -249,8 +314,9 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
         const int ksl = (int)gridDim.z, kz = (int)blockIdx.z;
         const int p_lo = (int)((long)kz * n_pos / ksl), p_hi = (int)((long)(kz + 1) * n_pos / ksl);
         // (the dense walk strides over whole 256-key spans: its end must be clipped to this share's last key, or the next share's keys are counted twice)
-        const int k_hi = SP ? n : min(n, 16 * p_hi);
-        Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, p_lo, p_hi, wave, kslot, k_hi, sub, bias_s, q, m, l, acc);
+        const int k_hi = SP ? n_old : min(n_old, 16 * p_hi);
+        if (STG) Attend<DT, 1, U>::template run_staged<NW>(a.kcache, a.vcache, row0, wave, kslot, k_hi, sub, bias_s, st, js, q, m, l, acc);
+        else Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, p_lo, p_hi, wave, kslot, k_hi, sub, bias_s, q, m, l, acc);
         wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
         if (kslot == 0) {
             if (sub == 0) { my_red[0] = m[0]; my_red[1] = l[0]; }
@@ -268,7 +334,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
                 for (int i = 0; i < DPL; ++i) { q[g][i] = qkv_s[g * 192 + sub * DPL + i] * sl2; acc[g][i] = 0.f; }
             }
             const long row0 = ((long)b0 * a.H + head) * a.Lmax;
-            Attend<DT, G, UP>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, 0, p_pos, wave, kslot, min(a.prefix, n), sub, bias_s, q, m, l, acc);
+            Attend<DT, G, UP>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, 0, p_pos, wave, kslot, min(a.prefix, n_old), sub, bias_s, q, m, l, acc);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 wave_merge<LPK, DPL>(m[g], l[g], acc[g]);
@@ -286,7 +352,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
 #pragma unroll
             for (int i = 0; i < DPL; ++i) { q[0][i] = qkv_s[g_own * 192 + sub * DPL + i] * sl2; acc[0][i] = 0.f; }
             const long row0 = ((long)(b0 + g_own) * a.H + head) * a.Lmax;
-            Attend<DT, 1, U>::template run_as<SP, TW>(a.kcache, a.vcache, row0, walk, p_pos, n_pos, wt, kslot, n, sub, bias_s, q, m, l, acc);
+            Attend<DT, 1, U>::template run_as<SP, TW>(a.kcache, a.vcache, row0, walk, p_pos, n_pos, wt, kslot, n_old, sub, bias_s, q, m, l, acc);
             wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
             if (kslot == 0) {
                 if (sub == 0) { my_red[G * 66] = m[0]; my_red[G * 66 + 1] = l[0]; }
@@ -339,6 +405,18 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
                 o += e[2 + d] * f;
             }
         }
+        if (blockIdx.z + 1 == gridDim.z) {   // the new key (row n-1), from LDS: wave g = sequence g, lane d = dim d
+            float kn = qkv_s[g * 192 + 64 + d], vn = qkv_s[g * 192 + 128 + d];
+            if (DT == 1) { kn = (float)(_Float16)kn; vn = (float)(_Float16)vn; }
+            const float bv = bias_s[row];
+            const float sn = wave_sum_dpp(qkv_s[g * 192 + d] * sl2 * kn) + bv;
+            if (bv > kNegBig) {
+                const float m2 = fmaxf(mm, sn), f = __builtin_amdgcn_exp2f(mm - m2), pn = __builtin_amdgcn_exp2f(sn - m2);
+                l = l * f + pn;
+                o = o * f + pn * vn;
+                mm = m2;
+            }
+        }
         if (gridDim.z > 1) {   // key split (G == 1): partial state for the combine kernel
             float* pw = a.kws + ((((long)b0 * a.H + head) * gridDim.z) + blockIdx.z) * 66;
             if (d == 0) { pw[0] = mm; pw[1] = l; }
@@ -372,6 +450,27 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     const int n = a.d_n ? *a.d_n + a.n : a.n;   // context length incl. the new key
     const int row = n - 1;
     const float sl2 = a.scale * kLog2eF;        // scores live in the base-2 domain
+
+    // K/V rows staged in LDS while ln1 and the projection run (ArAttnFusedArgs::stage_cap; one sequence per workgroup, dense walk): every wave requests the leading whole
+    // pipeline steps of ITS OWN share of the key walk - U K pieces + U V pieces of 1 KiB per step - by LDS-DMA into its region behind the sink, and the walk reads them
+    // from there (Attend::run_staged).  HBM has nothing else to do for the 13 us of the prologue; the 128 KB the CU's 160 KB of LDS leave free are 40 % of a
+    // (sequence, head)'s fp16 K/V rows at the mean context of a decode.
+    constexpr bool STG = G == 1 && !SP;
+    using TS = KvRow<DT>;
+    constexpr int KPI = 64 / TS::LPK, PIECE = NW * KPI, SU = WalkU<DT, G>::value, ROWB = 64 * (DT ? 2 : 4);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* st_w = reinterpret_cast<const char*>(pf_sink + 256) + (wave_u * a.stage_cap) * 1024;   // this wave's region
+    const int js = STG && a.stage_cap > 0 ? min(((n - 1) / PIECE) / SU, a.stage_cap / (2 * SU)) : 0;   // staged steps: whole steps of rows in the cache at kernel start
+    int q_iss = 0;
+    auto stage_issue = [&](int count) {   // request the next `count` pieces in LDS order (step-major: K pieces of the step, then its V pieces)
+        const long wrow = (((long)b0 * a.H + head) * a.Lmax + wave_u * KPI) * ROWB + lane * 16;
+        const int hi = min(q_iss + count, js * 2 * SU);
+        for (; q_iss < hi; ++q_iss) {
+            const int j = q_iss / (2 * SU), r = q_iss % (2 * SU);
+            const char* src = reinterpret_cast<const char*>(r >= SU ? a.vcache : a.kcache) + wrow + (long)(j * SU + r % SU) * (PIECE * ROWB);
+            glds16_hidden(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(st_w + q_iss * 1024)));
+        }
+    };
 
     AF_TRACE(0);
     // ---- every load that does not depend on another load is requested up front, in the order the results are needed (vmcnt waits are in order):
@@ -437,11 +536,16 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
             for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
         }
-        __syncthreads();
+        lds_barrier();   // (from here to the walk every barrier orders LDS only: K/V pieces and weight rows stay in flight across them)
         AF_TRACE(6);
         // the x rows have arrived: only now request the first weight batch (issued earlier, the 50 MB the 256 workgroups ask their L2s for at
         // once would queue in front of the later workgroups' x rows)
         load_batch(0, wb[0]);
+        // ... and behind it the first K/V pieces: they stream from HBM while the statistics run on LDS and registers.  Placement matters - the CU returns loads in issue
+        // order across its waves, an L2 hit queued behind an HBM miss waits for it: requested BEFORE the x rows, the pieces delay them from 1.6 to 6.3 us (measured);
+        // mixed into the projection's weight stream they make every row batch wait an HBM latency.  Hence two bursts: `stage_top` pieces here - they have landed
+        // when the projection asks for its second batch - and the rest behind the LAST row batch, where nothing waits on them but the walk.
+        if (STG) stage_issue(a.stage_top);
         float mean[G], var[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -450,7 +554,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
             for (int w = 0; w < NW; ++w) t += stat[w * G + g];
             mean[g] = t / (float)D;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float d = tid < D ? xv[g] - mean[g] : 0.f;
@@ -460,7 +564,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
             for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float t = 0.f;
@@ -479,7 +583,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
                 bias_s[tid + 1024 * j] = (kraw[j] || !vis.has_allowed) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
         for (int k = tid + 1024 * BR; k < n; k += 1024)   // sequences longer than 3072: the remainder the plain way
             bias_s[k] = (keep_row[k] || !vis.has_allowed) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
-        __syncthreads();
+        lds_barrier();
     }
 
     AF_TRACE(1);
@@ -520,12 +624,14 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
         for (int bi = 0; bi < NB; bi += 2) {
             if (bi + 1 < NB) load_batch(bi + 1, wb[1]);
+            if (STG && bi + 1 == NB - 1) stage_issue(1 << 20);   // behind the last row batch: the pieces not requested before ln1
             dot_batch(bi, wb[0]);
             if (bi + 2 < NB) load_batch(bi + 2, wb[0]);
+            if (STG && bi + 2 == NB - 1) stage_issue(1 << 20);
             if (bi + 1 < NB) dot_batch(bi + 1, wb[1]);
         }
     }
-    __syncthreads();
+    lds_barrier();
     AF_TRACE(2);
     // block layout (kernel-uniform branches): keys of absent blocks are hidden, and the walk follows the list of chunks that hold a present block.  List positions
     // [0, n_pos) are the chunks that start below n (ascending list); without a list position = chunk
@@ -544,7 +650,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         n_pos = (n + 15) >> 4;
         p_pos = G == 1 ? 0 : min((min(a.prefix, n) + 15) >> 4, n_pos);
     }
-    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, xn_s + head * 64, D, pf_sink);
+    af_append_attend_store<DT, G, SP, STG>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, xn_s + head * 64, D, pf_sink, st_w + lane * 16, js);
 }
 
 // ----------------------------------------------------------------------------------------------------------------- decode attention proper
@@ -621,6 +727,18 @@ size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) {
            1024;   // + the prefetch sink
 }
 
+// LDS a workgroup may allocate on this device (gfx950: 160 KB), queried once
+size_t ar_attn_fused_max_lds() {
+    static size_t v = 0;
+    if (!v) {
+        int dev = 0, optin = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || optin <= 0) optin = 64 * 1024;
+        v = (size_t)optin;
+    }
+    return v;
+}
+
 bool ar_attn_fused_supported(int B, int G, int D, int H) { return D == H * 64 && D % 4 == 0 && D <= 1024 && (G == 1 || G == 2 || G == 4) && B % G == 0; }
 
 void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
@@ -637,8 +755,24 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     if (!a.bias) { a.bias = a.x.base; a.ldbias = 0; }
     BG_REQUIRE(a.G == 1 || a.prefix % 16 == 0, "fused decode attention: a shared prefix must be a multiple of 16 keys (prefix=%d)", a.prefix);
     BG_REQUIRE(!a.vis.has_chunks || a.vis.chunks_ld <= 1025, "fused decode attention: at most 1024 key chunks per row");
-    const size_t lds = pre ? ar_attn_lds_bytes(a.G, a.Lpad) : ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
+    size_t lds = pre ? ar_attn_lds_bytes(a.G, a.Lpad) : ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
+    // K/V staging (fused kernel, G = 1, dense walk): what the CU's LDS has left beyond the kernel's own 24 KB, in whole pipeline steps per wave (gfx950: 160 KB per
+    // workgroup -> 8 pieces per wave = 128 KB).  $BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override the launcher's choice (A/B switches; 0 = off)
+    const bool sp_walk = a.vis.has_chunks;
+    if (!pre && a.G == 1 && !sp_walk && a.pf_bytes[0] == 0) {
+        static const int env_cap = getenv("BEVGEN_KV_STAGE") ? atoi(getenv("BEVGEN_KV_STAGE")) : -1;
+        static const int env_top = getenv("BEVGEN_KV_STAGE_TOP") ? atoi(getenv("BEVGEN_KV_STAGE_TOP")) : -1;
+        const int step_pieces = 2 * (a.kv_dtype == 0 ? 4 : 2);   // K + V pieces of one pipeline step (WalkU)
+        const int room = (int)((ar_attn_fused_max_lds() - lds) / (AF_WAVES * 1024));
+        int cap = a.stage_cap >= 0 ? a.stage_cap : (env_cap >= 0 ? env_cap : 8);
+        cap = std::max(0, std::min(cap, room)) / step_pieces * step_pieces;
+        a.stage_cap = cap;
+        a.stage_top = std::min(cap, a.stage_top >= 0 ? a.stage_top : (env_top >= 0 ? env_top : 4));
+        lds += (size_t)cap * AF_WAVES * 1024;
+    } else {
+        a.stage_cap = a.stage_top = 0;
+    }
     BG_REQUIRE(a.ksplit >= 1 && (a.ksplit == 1 || (pre && a.G == 1 && a.kws)), "decode attention: a key split needs the attention-only kernel, one sequence per workgroup and a workspace");
     dim3 grid(a.H, a.B / a.G, a.ksplit);
     // algorithmic bytes of one launch: K and V rows of the context, once each; the shared prefix once per group
@@ -649,8 +783,10 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     // SP instantiations only when a layout hides something (density < 1): chunk lists are then always present (context.cpp / the operator entry build both)
     const bool sp = a.vis.has_chunks;
     BG_REQUIRE(sp || !a.vis.has_lay, "fused decode attention: a block layout needs its chunk lists");
-#define AF_LAUNCH(DT, GG, WW) do { if (sp) hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG, WW, true>), grid, dim3(1024), lds, s, a); \
-                                   else hipLaunchKernelGGL((ar_attn_fused_kernel<DT, GG, WW, false>), grid, dim3(1024), lds, s, a); } while (0)
+    // (more than 64 KB of dynamic LDS has to be allowed per kernel function, once)
+#define AF_LAUNCH1(K) do { static bool big = false; if (lds > 64 * 1024 && !big) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ar_attn_fused_max_lds())); big = true; } \
+                           hipLaunchKernelGGL(K, grid, dim3(1024), lds, s, a); } while (0)
+#define AF_LAUNCH(DT, GG, WW) do { if (sp) AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, true>)); else AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, false>)); } while (0)
 #define AF_LAUNCH_G(DT, WW) do { if (a.G == 1) AF_LAUNCH(DT, 1, WW); else if (a.G == 2) AF_LAUNCH(DT, 2, WW); else AF_LAUNCH(DT, 4, WW); } while (0)
     if (pre) {
 #define AP_LAUNCH(DT, GG) do { if (sp) hipLaunchKernelGGL((ar_attn_kernel<DT, GG, true>), grid, dim3(1024), lds, s, a); \
@@ -667,6 +803,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     }
 #undef AF_LAUNCH_G
 #undef AF_LAUNCH
+#undef AF_LAUNCH1
     LAUNCH_CHECK();
     if (a.ksplit > 1) {   // merge the key ranges: o / l + ln1(x)
         DecodeAttnArgs c;

@@ -252,6 +252,11 @@ struct ArAttnFusedArgs {
     // list positions and leaves (max, sum, unnormalised output[64]) in kws [B][H][ksplit][66]; launch_ar_attn_fused then runs the combine kernel (+ residual)
     int ksplit = 1;
     float* kws = nullptr;
+    // K/V rows staged in LDS while the prologue runs (fused kernel, one sequence per workgroup, dense walk): every wave requests the leading whole pipeline steps of ITS OWN
+    // share of the key walk - `stage_cap` 1 KiB pieces, K and V of a step together - by LDS-DMA while it computes ln1 and the projection, when HBM has nothing else to
+    // do; the walk reads those steps from LDS and the rest from HBM.  stage_top of the pieces are requested when the x rows have arrived, the others behind the
+    // projection's last row batch.  -1 = the launcher's choice ($BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override), 0 = off
+    int stage_cap = -1, stage_top = -1;
     const void* pf_ptr[2] = {nullptr, nullptr};
     long pf_bytes[2] = {0, 0};
     int has_bias = 0;                  // filled in by the launcher
@@ -280,6 +285,7 @@ int skinny_fused_ksplit(int N, int K);
 bool skinny_fused_supported(int M, int N, int K, bool ln);
 bool skinny_fused_f16_ok(int N, int K, bool ln);   // fp16 weight image: K slice per wave a multiple of 32
 size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad);
+size_t ar_attn_fused_max_lds();   // LDS bytes a workgroup may allocate on the current device
 size_t ar_attn_lds_bytes(int G, int Lpad);   // the attention-only kernel (decode_path = split)
 void launch_skinny_fused(const SkinnyFusedArgs& g, hipStream_t s);
 

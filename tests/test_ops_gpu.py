@@ -373,6 +373,54 @@ def test_ar_attn_fused_operator(gpu_ctx, B, G, H, n, Lmax, blk, sparse, kv, spli
     assert torch.equal(dkc[:, :, keep].float().cpu(), kc[:, :, keep]) and torch.equal(dvc[:, :, keep].float().cpu(), vc[:, :, keep])
 
 
+@pytest.mark.parametrize("form", [0, -1, -2, -3])
+@pytest.mark.parametrize("kv", ["f32", "f16"])
+@pytest.mark.parametrize("B,H,n,Lmax,masked,wf16", [
+    (2, 4, 1, 64, False, False), (2, 4, 2, 64, True, False),             # no / one key in the cache
+    (3, 8, 128, 256, True, False), (3, 8, 129, 256, False, True),        # n - 1 = 127 / 128: below / exactly one pipeline step of the 8 walking waves
+    (2, 16, 257, 2368, True, False), (2, 16, 385, 512, False, False),    # whole steps + a ragged rest
+    (2, 16, 256, 512, False, False), (2, 8, 513, 1024, True, False), (2, 8, 600, 1024, False, True),
+    (16, 16, 1301, 2368, True, True),                                    # BASELINE config 4 mid-decode: 4 (fp16) / 2 (fp32) staged steps, the rest from HBM
+    (16, 16, 2368, 2368, False, False),                                  # n = L
+    (5, 2, 700, 1024, True, False),
+])
+def test_ar_attn_fused2_operator(gpu_ctx, B, H, n, Lmax, masked, wf16, kv, form):
+    """The fused decode kernel for one sequence per workgroup and a dense walk against fp64, with the leading K/V steps of every wave's key walk staged in LDS by LDS-DMA
+    during ln1 / the projection (form 0 = as the sampling path launches it: half of the pieces requested when the x rows have arrived, half behind the projection's last
+    row batch; -2 / -3 = all late / all early; -1 = no staging).  Context lengths around the staging boundaries (a pipeline step of the 16 waves = 256 keys with the fp16
+    cache, 256 with fp32), n = 1 and n = L, element mask (camera-bias visibility) on / off incl. a hidden new key, fp32 / fp16 weights, split-K partial sums + bias folded
+    into the row fetch; the appended rows and "nothing else touched"."""
+    D = H * 64
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    x = torch.randn(B, D, generator=g)
+    partial = torch.randn(4, B, D, generator=g) * 0.3
+    rbias = torch.randn(D, generator=g) * 0.1
+    ln_w, ln_b = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.1
+    wqkv = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
+    bqkv = torch.randn(3 * D, generator=g) * 0.1
+    kc = torch.randn(B, H, Lmax, 64, generator=g)
+    vc = torch.randn(B, H, Lmax, 64, generator=g)
+    bias = torch.randn(Lmax, Lmax, generator=g)
+    mask = None
+    if masked:
+        mask = (torch.rand(Lmax, Lmax, generator=g) > 0.2).float()
+        mask[:, 0] = 1
+        mask[torch.arange(Lmax), torch.arange(Lmax)] = 1 if n % 2 else 0   # the new key itself visible / hidden
+    if kv == "f16":
+        kc, vc = kc.half().float(), vc.half().float()
+    ref, k_new, v_new = _ar_attn_reference(x, partial, rbias, ln_w, ln_b, wqkv.half().float() if wf16 else wqkv, bqkv, kc, vc, n, bias, mask, None, 16, 1, 0)
+    cdt = torch.float16 if kv == "f16" else torch.float32
+    dkc, dvc = dev(kc.to(cdt)), dev(vc.to(cdt))
+    out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dkc, dvc, n, partial=dev(partial), rbias=dev(rbias), bias=dev(bias),
+                                   attn_mask=None if mask is None else dev(mask), kv_dtype=1 if kv == "f16" else 0, w_f16=wf16, split=form)
+    assert rel(out.cpu().double(), ref) < (2e-3 if kv == "f16" else 2e-5)
+    assert rel(dkc[:, :, n - 1].float().cpu().double(), k_new) < (1e-3 if kv == "f16" else 1e-5)
+    assert rel(dvc[:, :, n - 1].float().cpu().double(), v_new) < (1e-3 if kv == "f16" else 1e-5)
+    keep = torch.ones(Lmax, dtype=torch.bool)
+    keep[n - 1] = False
+    assert torch.equal(dkc[:, :, keep].float().cpu(), kc[:, :, keep]) and torch.equal(dvc[:, :, keep].float().cpu(), vc[:, :, keep])
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_ar_attn_fused_operator_f16_weights(gpu_ctx, split):
     B, H, n, Lmax = 16, 16, 700, 1024

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Phase timeline of the fused Route A decode kernels (device timestamps per workgroup, last launch of each kind).
-usage: decode_trace.py [B] [steps] [kv] [samples_per_layout]"""
+usage: decode_trace.py [B] [steps] [kv] [samples_per_layout] [weights]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +12,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1044
 kv = sys.argv[3] if len(sys.argv) > 3 else "f32"
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+WT = sys.argv[5] if len(sys.argv) > 5 else "f32"
 cfg = presets.config4()
-ctx = Context(cfg, route="ar", max_batch=B, kv_cache=kv)
+ctx = Context(cfg, route="ar", max_batch=B, kv_cache=kv, decode_weights=WT, decode_path="fused")
 ctx.load_state_dict(gpt_state_dict(cfg, 1234))
 ctx.set_tables()
 ctx.finalize()
@@ -25,7 +26,7 @@ tr = ctx.trace_end().double() / 100.0   # us (100 MHz)
 names = [("ln1+qkv+attention", ["start", "ln1 done", "qkv done", "append done", "attention done", "end"]),
          ("ln2+MLP-up", ["start", "A tile staged", "MFMA+reduce", "end"]),
          ("MLP-down", ["start", "A tile staged", "MFMA+reduce", "end"])]
-print(f"B={B} S={S} kv={kv}: last step context n={cfg.num_cond_tokens + steps - 1}")
+print(f"B={B} S={S} kv={kv} weights={WT}: last step context n={cfg.num_cond_tokens + steps - 1}")
 for k, (name, pts) in enumerate(names):
     t = tr[k]
     used = t[:, 0] > 0
