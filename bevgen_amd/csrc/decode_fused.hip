@@ -491,6 +491,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     // next to 22-44 MB of K/V; with two rows per batch the same-box A/B gives 1.617 -> 1.560 (fp32 cache), 1.306 -> 1.215 (fp16 cache) and 1.144 -> 1.122
     // ms/step (fp16 cache + weights), and the FETCH_SIZE counter no longer shows MORE traffic at density 0.35 than at density 1.
     constexpr int RB = (G >= 4 ? 1 : 2) * (WT ? 2 : 1), NB = 12 / RB;
+    constexpr bool PRE2 = G == 1;   // both register buffers requested when the x rows have arrived (in front of the staged K/V pieces), the loop refills behind each product
     typedef typename std::conditional<WT == 1, half8_t, f32x4>::type WV;
     const int rot = grp % NB;
     auto wrow = [&](int bi, int r) { return wave * 12 + ((bi + rot) % NB) * RB + r; };
@@ -527,6 +528,9 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     // held across it they push the fp32 variants over the 128-register budget of a 16-wave workgroup)
     const uint16_t* chunk_row = vis.chunks + (long)head * vis.chunks_head_stride + (long)(row / vis.blk) * vis.chunks_ld;
 
+
+    const int jb = wave * 12 + min(lane, 11);
+    float bj_mine;
     // ---- ln1, thread = column
     {
         float s[G];
@@ -541,10 +545,17 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         // the x rows have arrived: only now request the first weight batch (issued earlier, the 50 MB the 256 workgroups ask their L2s for at
         // once would queue in front of the later workgroups' x rows)
         load_batch(0, wb[0]);
-        // ... and behind it the first K/V pieces: they stream from HBM while the statistics run on LDS and registers.  Placement matters - the CU returns loads in issue
-        // order across its waves, an L2 hit queued behind an HBM miss waits for it: requested BEFORE the x rows, the pieces delay them from 1.6 to 6.3 us (measured);
-        // mixed into the projection's weight stream they make every row batch wait an HBM latency.  Hence two bursts: `stage_top` pieces here - they have landed
-        // when the projection asks for its second batch - and the rest behind the LAST row batch, where nothing waits on them but the walk.
+        if (PRE2) load_batch(1, wb[1]);   // (G > 1: two batches across the G rows' statistics spill)
+        // this wave's 12 projection biases, one per lane (added after the row loop).  A bias load INSIDE the row loop sits, in the in-order return stream, behind the next
+        // batch's weight loads just issued: every row then waited for the whole next batch - vmcnt(0) in front of each qkv_s store - and the double buffering was void
+        // (the projection took 8 us with fp32 and with fp16 weights alike)
+        bj_mine = a.bqkv[(long)(jb >> 6) * D + head * 64 + (jb & 63)];
+        // ... and behind them the first `stage_top` K/V pieces; the others go out in equal shares behind each row batch of the projection.  What was measured (MI355X,
+        // same-box A/Bs, profiles/r04_ab_kv_stage.txt): the CU returns loads in issue order across its waves and a wave blocks at a VMEM instruction while the
+        // CU's request queue is full, so (a) pieces requested BEFORE the x rows delay them from 1.6 to 6.3 us; (b) a single 128 KB burst here holds every wave at its
+        // request instructions for ~5 us (HBM feeds one CU 25 GB/s): ln1 is done at 9.3 instead of 4.4 us, the walk 5 us shorter, net -2 us; (c) two row batches deep in
+        // registers in front of the burst keep the multipliers busy while it drains; (d) with fp16 weights (4 rows per batch, 3 batches) two pieces here and two
+        // behind each batch is best: 1.060 vs 1.088 ms/step all-early vs 1.145 without staging; with fp32 weights (6 batches) all-early wins, 1.204 vs 1.225 vs 1.241.
         if (STG) stage_issue(a.stage_top);
         float mean[G], var[G];
 #pragma unroll
@@ -613,22 +624,31 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
                     }
                 }
                 const int j = wrow(bi, r);
-                const float bj = a.bqkv[(long)(j >> 6) * D + head * 64 + (j & 63)];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const float t = wave_sum_dpp(accp[g]);
-                    if (lane == 0) qkv_s[g * 192 + j] = t + bj;
+                    if (lane == 0) qkv_s[g * 192 + j] = t;   // (+ bias below)
                 }
+
             }
         };
+        // pieces not requested before ln1: an equal share behind each row batch (per row instead of per batch: no different, 1.064-1.071 vs 1.059-1.061 ms/step)
+        const int per = STG ? (js * 2 * SU - q_iss + NB - 1) / NB : 0;
 #pragma unroll
         for (int bi = 0; bi < NB; bi += 2) {
-            if (bi + 1 < NB) load_batch(bi + 1, wb[1]);
-            if (STG && bi + 1 == NB - 1) stage_issue(1 << 20);   // behind the last row batch: the pieces not requested before ln1
+            if (!PRE2 && bi + 1 < NB) load_batch(bi + 1, wb[1]);
             dot_batch(bi, wb[0]);
             if (bi + 2 < NB) load_batch(bi + 2, wb[0]);
-            if (STG && bi + 2 == NB - 1) stage_issue(1 << 20);
-            if (bi + 1 < NB) dot_batch(bi + 1, wb[1]);
+            if (STG) stage_issue(per);
+            if (bi + 1 < NB) {
+                dot_batch(bi + 1, wb[1]);
+                if (PRE2 && bi + 3 < NB) load_batch(bi + 3, wb[1]);
+                if (STG) stage_issue(per);
+            }
+        }
+        if (lane < 12) {   // this wave's rows (its own LDS stores above: in order)
+#pragma unroll
+            for (int g = 0; g < G; ++g) qkv_s[g * 192 + jb] += bj_mine;
         }
     }
     lds_barrier();
@@ -768,7 +788,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
         int cap = a.stage_cap >= 0 ? a.stage_cap : (env_cap >= 0 ? env_cap : 8);
         cap = std::max(0, std::min(cap, room)) / step_pieces * step_pieces;
         a.stage_cap = cap;
-        a.stage_top = std::min(cap, a.stage_top >= 0 ? a.stage_top : (env_top >= 0 ? env_top : 4));
+        a.stage_top = a.stage_top >= 0 ? a.stage_top : (env_top >= 0 ? env_top : (a.wqkv_h ? 2 : cap));
         lds += (size_t)cap * AF_WAVES * 1024;
     } else {
         a.stage_cap = a.stage_top = 0;

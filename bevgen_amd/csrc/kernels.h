@@ -254,8 +254,8 @@ struct ArAttnFusedArgs {
     float* kws = nullptr;
     // K/V rows staged in LDS while the prologue runs (fused kernel, one sequence per workgroup, dense walk): every wave requests the leading whole pipeline steps of ITS OWN
     // share of the key walk - `stage_cap` 1 KiB pieces, K and V of a step together - by LDS-DMA while it computes ln1 and the projection, when HBM has nothing else to
-    // do; the walk reads those steps from LDS and the rest from HBM.  stage_top of the pieces are requested when the x rows have arrived, the others behind the
-    // projection's last row batch.  -1 = the launcher's choice ($BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override), 0 = off
+    // do; the walk reads those steps from LDS and the rest from HBM.  stage_top of the pieces are requested when the x rows have arrived, the others in equal shares behind
+    // the projection's row batches.  -1 = the launcher's choice ($BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override), 0 = off
     int stage_cap = -1, stage_top = -1;
     const void* pf_ptr[2] = {nullptr, nullptr};
     long pf_bytes[2] = {0, 0};

@@ -386,8 +386,8 @@ def test_ar_attn_fused_operator(gpu_ctx, B, G, H, n, Lmax, blk, sparse, kv, spli
 ])
 def test_ar_attn_fused2_operator(gpu_ctx, B, H, n, Lmax, masked, wf16, kv, form):
     """The fused decode kernel for one sequence per workgroup and a dense walk against fp64, with the leading K/V steps of every wave's key walk staged in LDS by LDS-DMA
-    during ln1 / the projection (form 0 = as the sampling path launches it: half of the pieces requested when the x rows have arrived, half behind the projection's last
-    row batch; -2 / -3 = all late / all early; -1 = no staging).  Context lengths around the staging boundaries (a pipeline step of the 16 waves = 256 keys with the fp16
+    during ln1 / the projection (form 0 = as the sampling path launches it; -2 / -3 = every piece requested between the projection's row batches / when the x rows have
+    arrived; -1 = no staging).  Context lengths around the staging boundaries (a pipeline step of the 16 waves = 256 keys with the fp16
     cache, 256 with fp32), n = 1 and n = L, element mask (camera-bias visibility) on / off incl. a hidden new key, fp32 / fp16 weights, split-K partial sums + bias folded
     into the row fetch; the appended rows and "nothing else touched"."""
     D = H * 64

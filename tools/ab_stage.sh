@@ -1,5 +1,5 @@
 #!/bin/bash
-# K/V staging in LDS (ArAttnFusedArgs::stage_cap / stage_top): parity subset, same-box A/B over $BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP, phase traces.
+# K/V staging in LDS (ArAttnFusedArgs::stage_cap): parity subset, same-box A/B over $BEVGEN_KV_STAGE, phase traces.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "ar_attn or ln_gemm" 2>&1 | tail -15 > $O/stage_tests.txt
@@ -8,15 +8,15 @@ if grep -q failed $O/stage_tests.txt; then exit 1; fi
 timeout 1500 python -m pytest tests/test_models_gpu.py -x -q -m gpu -k "route_a and not 300_steps and not config5" 2>&1 | tail -4 | tee -a $O/stage_tests.txt
 : > $O/stage_ab.txt
 for i in 1 2; do
-for combo in "0 0" "8 4" "8 0" "8 8" "4 4" "8 2" "8 6"; do set -- $combo
-  BEVGEN_KV_STAGE=$1 BEVGEN_KV_STAGE_TOP=$2 python tools/decode_probe.py 16 2100 fused f16 1 f32,f16 2>/dev/null | grep "ms/step" | sed "s/^/STAGE=$1 TOP=$2 /" | tee -a $O/stage_ab.txt
+for cap in 0 8 4; do
+  BEVGEN_KV_STAGE=$cap python tools/decode_probe.py 16 2100 fused f16 1 f32,f16 2>/dev/null | grep "ms/step" | sed "s/^/STAGE=$cap /" | tee -a $O/stage_ab.txt
 done; done
-for combo in "0 0" "8 8" "8 0"; do set -- $combo
-  BEVGEN_KV_STAGE=$1 BEVGEN_KV_STAGE_TOP=$2 python tools/decode_probe.py 16 2100 fused f32 1 f32 2>/dev/null | grep "ms/step" | sed "s/^/STAGE=$1 TOP=$2 /" | tee -a $O/stage_ab.txt
+for cap in 0 8; do
+  BEVGEN_KV_STAGE=$cap python tools/decode_probe.py 16 2100 fused f32 1 f32 2>/dev/null | grep "ms/step" | sed "s/^/STAGE=$cap /" | tee -a $O/stage_ab.txt
 done
 : > $O/stage_trace.txt
-for combo in "0 0" "8 4" "8 0" "8 8"; do set -- $combo
-  echo "== STAGE=$1 TOP=$2" >> $O/stage_trace.txt
-  BEVGEN_KV_STAGE=$1 BEVGEN_KV_STAGE_TOP=$2 python tools/decode_trace.py 16 1044 f16 2>&1 | grep -v amdgpu.ids | head -8 >> $O/stage_trace.txt
-done
+for cap in 0 8; do for w in f32 f16; do
+  echo "== STAGE=$cap" >> $O/stage_trace.txt
+  BEVGEN_KV_STAGE=$cap python tools/decode_trace.py 16 1044 f16 1 $w 2>&1 | grep -v amdgpu.ids | head -8 >> $O/stage_trace.txt
+done; done
 cat $O/stage_trace.txt
