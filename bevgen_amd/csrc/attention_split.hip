@@ -206,8 +206,16 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
             gload_bias(min(t + 1, ntiles - 1));   // (bacc was consumed by the first MFMA of this tile)
             __builtin_amdgcn_sched_barrier(0);
             mx = fmaxf(mx, xor32(mx));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            // LAZY reference: a row's softmax reference only moves when its tile maximum is more than 2^kLazy above it, so p = 2^(s - m_run) lies in [0, 2^kLazy] instead
+            // of [0, 1] (fp32 exponent range and the f16 range of p's high part both have room: 2^14 < 65504; hi + lo keeps its 22 relative bits at any scale) and
+            // alpha == 1 - no pass over the 64 accumulator registers - on every tile but a row's first and the rare later jump.  With the exact running maximum a
+            // wave of 64 rows sees SOME row's maximum move on almost every tile (P ~ 1 - (1 - 1/t)^64 on random scores): the rescale ran always and took 400-550 of
+            // the V-phase's 1450 clocks (tools/attn_lab phase stamps)
+            constexpr float kLazy = 14.f;
+            const bool jump = mx > m_run + kLazy;
+            const float m_new = jump ? mx : m_run;
+            const float alpha = jump ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+            PP_STAMP(6);
             float psum = 0.f;
             uint32_t hw[8], lw[8];
 #pragma unroll
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
                 ph[s] = __builtin_bit_cast(half8, u32x4{hw[4 * s], hw[4 * s + 1], hw[4 * s + 2], hw[4 * s + 3]});
                 pl[s] = __builtin_bit_cast(half8, u32x4{lw[4 * s], lw[4 * s + 1], lw[4 * s + 2], lw[4 * s + 3]});
             }
+            PP_STAMP(7);
             l_run = l_run * alpha + psum;
             m_run = m_new;
             // rescale the output accumulators only when some row's running maximum moved (alpha == 1 otherwise: skipping is exact); after the

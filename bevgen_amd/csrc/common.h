@@ -160,4 +160,18 @@ __host__ __device__ inline void philox_gumbel_block(long row, int V, int i, unsi
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDS-DMA request the compiler does not see (inline asm): 16 bytes per lane from `src` (per-lane address) to LDS byte address `lds_base` + lane * 16 (wave-uniform base).
+// With the builtin, LLVM's wait-count pass counts the request like a load and - not knowing which LDS bytes it writes - puts `s_waitcnt vmcnt(0)` in front of later LDS
+// writes (in the fused decode kernel the xn / bias row stores of ln1 then waited for every K/V piece: statistics done at 10.0 instead of 5.8 us).  Hidden requests only ever make the compiler's counted
+// waits stricter (loads return in issue order; an uncounted later request means it waits for a few more of the older ones), never weaker; the one reader of the staged bytes
+// (Attend::run_staged) orders itself by an explicit vmcnt wait.
+__device__ __forceinline__ void glds16_hidden(const void* src, unsigned lds_base) {
+    unsigned keep;   // (m0 is the compiler's: saved and restored around the request)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+
 }  // namespace bevgen

@@ -128,10 +128,10 @@ int main() {
             const int nt = Nk_pad / 32;
             for (int w : {0, 4}) {
                 printf("trace Nk=%d wave %d: per tile [M-phase | wait at barrier | LDS store | softmax + loads | wait at barrier] cycles\n", Nk_pad, w);
-                for (int t = 2; t < (nt < 6 ? nt : 6); ++t) {
+                for (int t = (nt > 14 ? 10 : 2); t < (nt > 14 ? 14 : (nt < 6 ? nt : 6)); ++t) {
                     const unsigned long long* e = &tr[(w * 16 + t) * 8];
-                    printf("   t=%2d  start %8lld  M %5llu  bar %5llu  store %5llu  softmax %5llu  bar %5llu\n", t, (long long)(e[0] - tr[(0 * 16 + 2) * 8]), e[1] - e[0], e[2] - e[1],
-                           e[3] - e[2], e[4] - e[3], e[5] - e[4]);
+                    printf("   t=%2d  start %8lld  M %5llu  bar %5llu  store %5llu  softmax %5llu (max+bias req %5llu | exp+split+K/V req %5llu | rescale %5llu)  bar %5llu\n", t,
+                           (long long)(e[0] - tr[(0 * 16 + 2) * 8]), e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3], e[6] - e[3], e[7] - e[6], e[4] - e[7], e[5] - e[4]);
                 }
             }
         }

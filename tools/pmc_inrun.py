@@ -19,6 +19,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CAL_M, CAL_N, CAL_K = 24576, 128, 1024   # calibration GEMM: one column tile
 
 
 def probe():
@@ -38,15 +39,30 @@ def probe():
     ids = torch.full((batch * cams, cfg.num_cam_tokens), cfg.vocab_size, dtype=torch.long, device=ctx.device)
     ctx.muse_forward(ids, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], want_logits=True, want_embed=False)
     torch.cuda.synchronize()
+    # calibration launch (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count in your own access pattern"): the same LDS-DMA GEMM with ONE column tile
+    # (N = 128): every A panel can only be read once, so its memory-side reads are (M K + N K) 4 bytes whatever the tile order - the LAST gemm_split_glds dispatch of the run
+    from bevgen_amd.runtime import _ptr, _stream
+    a = torch.randn(CAL_M, CAL_K, device=ctx.device)
+    w = torch.randn(CAL_N, CAL_K, device=ctx.device)
+    out = torch.empty(CAL_M, CAL_N, device=ctx.device)
+    ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(a), _ptr(w), None, None, _ptr(out), CAL_M, CAL_N, CAL_K, 0, 3, _stream()))
+    torch.cuda.synchronize()
     ctx.close()
 
 
 def _mean_counter(csv_path, counter, kernel_substr):
-    vals = []
+    """-> (mean over the launches of the kernel, their number, value of the calibration launch = the last gemm_split_glds dispatch)"""
+    vals, cal = [], (-1, None)
     for r in csv.DictReader(open(csv_path)):
-        if r.get("Counter_Name") == counter and kernel_substr in r.get("Kernel_Name", ""):
-            vals.append(float(r["Counter_Value"]))
-    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+        if r.get("Counter_Name") != counter:
+            continue
+        name = r.get("Kernel_Name", "")
+        if "gemm_split_glds_kernel" in name and int(r["Dispatch_Id"]) > cal[0]:
+            cal = (int(r["Dispatch_Id"]), float(r["Counter_Value"]))
+        if kernel_substr in name:
+            vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    vals = [v for d, v in vals if d != cal[0]]
+    return (sum(vals) / len(vals), len(vals), cal[1]) if vals else (None, 0, cal[1])
 
 
 def measure(kernel_substr, timeout=240):
@@ -64,16 +80,23 @@ def measure(kernel_substr, timeout=240):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return {"error": f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(files)} csv; {r.stderr[-300:]}"}
-            mean, n = _mean_counter(files[0], counter, kernel_substr)
+            mean, n, cal = _mean_counter(files[0], counter, kernel_substr)
             if mean is None:
                 return {"error": f"no {counter} rows for a kernel containing '{kernel_substr}'"}
-            out[counter] = (mean, n)
+            out[counter] = (mean, n, cal)
         except subprocess.TimeoutExpired:
             return {"error": f"rocprofv3 --pmc {counter}: timeout after {timeout} s"}
         finally:
             shutil.rmtree(d, ignore_errors=True)
     rd, wr = 2.0 * out["FETCH_SIZE"][0] * 1024.0, out["WRITE_SIZE"][0] * 1024.0
-    return {"bytes_per_launch": rd + wr, "read_bytes_corrected": rd, "write_bytes": wr, "launches": out["FETCH_SIZE"][1],
+    res = {}
+    if out["FETCH_SIZE"][2] and out["WRITE_SIZE"][2] is not None:
+        cal_rd_alg, cal_wr_alg = (CAL_M * CAL_K + CAL_N * CAL_K) * 4.0, CAL_M * CAL_N * 4.0
+        res["calibration"] = {"shape": f"same kernel family, M={CAL_M} N={CAL_N} K={CAL_K} (one column tile: every A panel is read exactly once)",
+                              "read_bytes_corrected_over_algorithmic": 2.0 * out["FETCH_SIZE"][2] * 1024.0 / cal_rd_alg,
+                              "write_bytes_over_algorithmic": out["WRITE_SIZE"][2] * 1024.0 / cal_wr_alg,
+                              "note": "a ratio near 2 on the read side means the guide's x2 correction of FETCH_SIZE does not apply to this kernel's 128-byte LDS-DMA lines"}
+    return {**res, "bytes_per_launch": rd + wr, "read_bytes_corrected": rd, "write_bytes": wr, "launches": out["FETCH_SIZE"][1],
             "FETCH_SIZE_KiB": out["FETCH_SIZE"][0], "WRITE_SIZE_KiB": out["WRITE_SIZE"][0],
             "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child passes) over one transformer forward of this workload; "
                       "read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB; mean over the launches of the kernel"}
