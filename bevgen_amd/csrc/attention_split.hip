@@ -206,15 +206,14 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
             gload_bias(min(t + 1, ntiles - 1));   // (bacc was consumed by the first MFMA of this tile)
             __builtin_amdgcn_sched_barrier(0);
             mx = fmaxf(mx, xor32(mx));
-            // LAZY reference: a row's softmax reference only moves when its tile maximum is more than 2^kLazy above it, so p = 2^(s - m_run) lies in [0, 2^kLazy] instead
-            // of [0, 1] (fp32 exponent range and the f16 range of p's high part both have room: 2^14 < 65504; hi + lo keeps its 22 relative bits at any scale) and
-            // alpha == 1 - no pass over the 64 accumulator registers - on every tile but a row's first and the rare later jump.  With the exact running maximum a
-            // wave of 64 rows sees SOME row's maximum move on almost every tile (P ~ 1 - (1 - 1/t)^64 on random scores): the rescale ran always and took 400-550 of
-            // the V-phase's 1450 clocks (tools/attn_lab phase stamps)
-            constexpr float kLazy = 14.f;
-            const bool jump = mx > m_run + kLazy;
-            const float m_new = jump ? mx : m_run;
-            const float alpha = jump ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
+            // (Round 4, measured and rejected: a LAZY reference - a row's reference only moves when its tile maximum is more than 2^14 above it, so that the rescale pass
+            // below almost never runs.  On tools/attn_lab's random scores, where some row of the wave sees a new maximum on nearly every tile and the rescale took
+            // 400-550 of the V-phase's 1450 clocks, 527 -> 483 us; on the bench's model, where maxima settle within the first tiles and the pass is skipped anyway,
+            // 278 -> 248 TF-equiv in same-box A/B (profiles/r04_ab_attn_lazy_reference.txt): same instruction stream, but p no longer lies in [0, 1] - larger hi / lo
+            // operand magnitudes on a power-limited matrix pipe.  Likewise rejected: the bias segment two tiles ahead by LDS-DMA instead of one tile ahead in
+            // registers, 545 -> 596 us - the V-phase is not waiting for that load, and the ring's 8 KiB per wave and tile of extra LDS traffic costs 9 %.)
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             PP_STAMP(6);
             float psum = 0.f;
             uint32_t hw[8], lw[8];
