@@ -359,19 +359,27 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
         BG_REQUIRE(ar_attn_fused_supported(B, G, D, H), "op_ar_attn_fused: unsupported shape B=%d G=%d D=%d H=%d", B, G, D, H);
         BG_REQUIRE(!layout || (block >= 1 && L % block == 0), "op_ar_attn_fused: Lmax %d is not a multiple of the block size %d", L, block);
         const int nb = layout ? L / block : 0, cld = (int)cdiv(L, 16) + 1;
-        ctx->arena.reserve((size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * cld * 2 + (size_t)3 * D * D * 6 + (split ? skinny_packed_floats(3 * D, D) * 4 + (size_t)B * 4 * D * 4 + (size_t)B * H * (split > 1 ? split : 0) * 66 * 4 : 0) + 14 * 256);
+        ctx->arena.reserve((size_t)L * L + (size_t)H * nb * nb + (size_t)H * nb * cld * 2 + (size_t)3 * D * D * 6 + (size_t)6 * D * 4 + (split ? skinny_packed_floats(3 * D, D) * 4 + (size_t)B * 4 * D * 4 + (size_t)B * H * (split > 1 ? split : 0) * 66 * 4 : 0) + 14 * 256);
         ctx->arena.reset();
         ArAttnFusedArgs a;
         a.x.base = x; a.x.ld = D;
         if (partial && ns > 0) { a.x.partial = partial; a.x.ns = ns; a.x.pstride = (long)B * D; a.x.pld = D; }
         a.x.bias = rbias;
         a.ln_w = ln_w; a.ln_b = ln_b; a.wqkv = wqkv; a.bqkv = bqkv;
+        const float* w_rounded = nullptr;
         if (w_f16) {
             void* h = ctx->arena.alloc((size_t)3 * D * D * 2);
             float* tmp = ctx->arena.get<float>((size_t)3 * D * D);   // round_to_f16 rounds in place: work on a copy of the caller's matrix (arena: no allocation, no sync)
             HIP_CHECK(hipMemcpyAsync(tmp, wqkv, (size_t)3 * D * D * 4, hipMemcpyDeviceToDevice, s));
             launch_round_to_f16(tmp, h, 3L * D * D, s);
             a.wqkv_h = h;
+            w_rounded = tmp;
+        }
+        {   // row constants of the folded ln1, on the matrix the kernel multiplies by (the fp16-rounded one with w_f16)
+            float* cs = ctx->arena.get<float>((size_t)3 * D);
+            float* ds = ctx->arena.get<float>((size_t)3 * D);
+            launch_ar_ln_fold(w_f16 ? w_rounded : wqkv, bqkv, ln_w, ln_b, cs, ds, 3 * D, D, s);
+            a.ln_cs = cs; a.ln_ds = ds;
         }
         a.kcache = kc; a.vcache = vc; a.kv_dtype = kv_dtype;
         a.bias = bias; a.ldbias = ldbias;

@@ -362,6 +362,7 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
             a.x = src;
             a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;
             a.wqkv = l.wqkv; a.bqkv = l.bqkv; a.wqkv_h = l.wqkv_h;
+            a.ln_cs = l.ln1_cs; a.ln_ds = l.ln1_ds;
         }
         a.kcache = reinterpret_cast<char*>(st.kcache) + i * layer_bytes + chain_off;
         a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes + chain_off;

@@ -286,6 +286,10 @@ static void finalize_ar(Ctx& c) {
             launch_round_to_f16(const_cast<float*>(l.mlp2_w), nullptr, 4L * D * D, 0);
         }
         if (fused_like) {
+            // (after the rounding above: the constants belong to the matrix the decode step multiplies by)
+            l.ln1_cs = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
+            l.ln1_ds = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
+            launch_ar_ln_fold(l.wqkv, l.bqkv, l.ln1_w, l.ln1_b, l.ln1_cs, l.ln1_ds, 3 * D, D, 0);
             const size_t eb = wf16 ? sizeof(_Float16) : sizeof(float);
             // decode_path = split packs the QKV operand image now; auto packs it on the first call that resolves to the split layer (ctx_pack_split_qkv:
             // 3 D D elements per layer, ~300 MB at config 4 in fp32, that a context whose calls all carry more than four sequences never needs)

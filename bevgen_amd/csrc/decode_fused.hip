@@ -516,9 +516,21 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     const uint16_t* chunk_row = vis.chunks + (long)head * vis.chunks_head_stride + (long)(row / vis.blk) * vis.chunks_ld;
 
 
+    // ---- ln1 FOLDED into the projection (fp16 weight storage).  LN(x) W^T + b = rstd (x o gamma) W^T - rstd mean (W gamma) + (W beta + b): the dot products run on x o gamma, which exists
+    //      the moment the x rows are in, and the row statistics are computed in their shadow; mean / rstd and the two per-row constants cs = W gamma, ds = W beta + b
+    //      (launch_ar_ln_fold, once per layer) only enter a 192-value fix-up after the row loop.  The direct form - statistics (two barrier rounds), normalised row to
+    //      LDS, barrier, THEN the first product - spent 2.8 us between the rows' arrival and the first multiply-add, most of it with every wave blocked at the request
+    //      instructions of its first weight batches (a CU's address pipe takes 64 B per clock: 256 KB = 1.9 us) before it could even start the statistics.
+    //      (Same arithmetic up to fp32 rounding of the re-associated sum: tokens equal to the oracle's on every fixture, tests/test_models_gpu.py.)
+    //      Same-box A/B, ms per decode step: fp16 cache + fp16 weights 1.067 -> 1.050; with fp32 weights 1.208 -> 1.225 and 1.540 -> 1.558 - there the prologue is bound
+    //      by the 786 KB of weight rows + 128 KB of staged pieces every workgroup pushes through its CU's address pipe, the statistics were already in its shadow, and
+    //      the fix-up only adds: the direct form stays for fp32 weights (FOLD below).
+    constexpr bool FOLD = WT == 1;
     const int jb = wave * 12 + min(lane, 11);
-    float bj_mine;
-    // ---- ln1, thread = column
+    float* stat2 = red;                         // scratch inside `red` (free until the key walk): second-pass sums | raw x, gamma, beta of this head's 64 columns
+    float* xh_s = red + NW * G;
+    float* gh_s = xh_s + G * 64;
+    float c_mine, d_mine;
     {
         float s[G];
 #pragma unroll
@@ -527,24 +539,36 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
             for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
         }
+        if (FOLD && tid < D) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) xn_s[g * D + tid] = xv[g] * lw;   // x o gamma: what the row loop multiplies
+        }
+        if (FOLD && (tid >> 6) == head && tid < D) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) xh_s[g * 64 + lane] = xv[g];
+            gh_s[lane] = lw; gh_s[64 + lane] = lb;
+        }
         lds_barrier();   // (from here to the walk every barrier orders LDS only: K/V pieces and weight rows stay in flight across them)
         AF_TRACE(6);
-        // the x rows have arrived: only now request the first weight batch (issued earlier, the 50 MB the 256 workgroups ask their L2s for at
+        // the x rows have arrived: only now request the first weight batches (issued earlier, the 50 MB the 256 workgroups ask their L2s for at
         // once would queue in front of the later workgroups' x rows)
         load_batch(0, wb[0]);
         if (PRE2) load_batch(1, wb[1]);   // (G > 1: two batches across the G rows' statistics spill)
-        // this wave's 12 projection biases, one per lane (added after the row loop).  A bias load INSIDE the row loop sits, in the in-order return stream, behind the next
+        // this wave's 12 pairs of row constants, one per lane (applied after the row loop).  A load INSIDE the row loop sits, in the in-order return stream, behind the next
         // batch's weight loads just issued: every row then waited for the whole next batch - vmcnt(0) in front of each qkv_s store - and the double buffering was void
         // (the projection took 8 us with fp32 and with fp16 weights alike)
-        bj_mine = a.bqkv[(long)(jb >> 6) * D + head * 64 + (jb & 63)];
+        c_mine = (FOLD ? a.ln_cs : a.bqkv)[(long)(jb >> 6) * D + head * 64 + (jb & 63)];   // (direct form: the row's bias)
+        d_mine = FOLD ? a.ln_ds[(long)(jb >> 6) * D + head * 64 + (jb & 63)] : 0.f;
         // ... and behind them the first `stage_top` K/V pieces; the others go out in equal shares behind each row batch of the projection.  What was measured (MI355X,
         // same-box A/Bs, profiles/r04_ab_kv_stage.txt): the CU returns loads in issue order across its waves and a wave blocks at a VMEM instruction while the
         // CU's request queue is full, so (a) pieces requested BEFORE the x rows delay them from 1.6 to 6.3 us; (b) a single 128 KB burst here holds every wave at its
-        // request instructions for ~5 us (HBM feeds one CU 25 GB/s): ln1 is done at 9.3 instead of 4.4 us, the walk 5 us shorter, net -2 us; (c) two row batches deep in
-        // registers in front of the burst keep the multipliers busy while it drains; (d) with fp16 weights (4 rows per batch, 3 batches) two pieces here and two
-        // behind each batch is best: 1.060 vs 1.088 ms/step all-early vs 1.145 without staging; with fp32 weights (6 batches) all-early wins, 1.204 vs 1.225 vs 1.241.
+        // request instructions for ~5 us (HBM feeds one CU 25 GB/s): the walk 5 us shorter, the prologue 3 us longer; (c) two row batches deep in registers in front
+        // of the burst keep the multipliers busy while it drains; (d) with fp16 weights (4 rows per batch, 3 batches) two pieces here and two behind each batch
+        // is best: 1.060 vs 1.088 ms/step all-early vs 1.145 without staging; with fp32 weights (6 batches) all-early wins, 1.204 vs 1.225 vs 1.241.
         if (STG) stage_issue(a.stage_top);
-        float mean[G], var[G];
+        // second statistics pass.  Folded form: in the shadow of the weight loads, read by the fix-up behind the row loop's closing barrier.  Direct form: two more
+        // barrier rounds, then the normalised row goes to LDS
+        float mean[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float t = 0.f;
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
             for (int w = 0; w < NW; ++w) t += stat[w * G + g];
             mean[g] = t / (float)D;
         }
-        lds_barrier();
+        if (!FOLD) lds_barrier();   // (`stat` is rewritten)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float d = tid < D ? xv[g] - mean[g] : 0.f;
@@ -560,32 +584,32 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         }
         if (lane == 0) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
+            for (int g = 0; g < G; ++g) (FOLD ? stat2 : stat)[wave * G + g] = s[g];
         }
-        lds_barrier();
+        if (!FOLD) {
+            lds_barrier();
+            if (tid < D) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float t = 0.f;
+                for (int g = 0; g < G; ++g) {
+                    float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += stat[w * G + g];
-            var[g] = t / (float)D;
+                    for (int w = 0; w < NW; ++w) t += stat[w * G + g];
+                    xn_s[g * D + tid] = (xv[g] - mean[g]) * rsqrtf(t / (float)D + a.eps) * lw + lb;
+                }
+            }
         }
         AF_TRACE(7);
-        if (tid < D) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) xn_s[g * D + tid] = (xv[g] - mean[g]) * rsqrtf(var[g] + a.eps) * lw + lb;
-        }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
             if (tid + 1024 * j < n)
                 bias_s[tid + 1024 * j] = (kraw[j] || !vis.has_allowed) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
         for (int k = tid + 1024 * BR; k < n; k += 1024)   // sequences longer than 3072: the remainder the plain way
             bias_s[k] = (keep_row[k] || !vis.has_allowed) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
-        lds_barrier();
+        if (!FOLD) lds_barrier();
     }
 
     AF_TRACE(1);
-    // ---- q/k/v projection of this head
+    // ---- q/k/v projection of this head (folded form: on x o gamma)
     {
         auto dot_batch = [&](int bi, const WV (&w)[RB][NCH]) {
 #pragma unroll
@@ -614,12 +638,11 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     const float t = wave_sum_dpp(accp[g]);
-                    if (lane == 0) qkv_s[g * 192 + j] = t;   // (+ bias below)
+                    if (lane == 0) qkv_s[g * 192 + j] = t;   // (raw sum: fixed up below)
                 }
-
             }
         };
-        // pieces not requested before ln1: an equal share behind each row batch (per row instead of per batch: no different, 1.064-1.071 vs 1.059-1.061 ms/step)
+        // pieces not requested when the rows arrived: an equal share behind each row batch (per row instead of per batch: no different, 1.064-1.071 vs 1.059-1.061 ms/step)
         const int per = STG ? (js * 2 * SU - q_iss + NB - 1) / NB : 0;
 #pragma unroll
         for (int bi = 0; bi < NB; bi += 2) {
@@ -633,9 +656,25 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
                 if (STG) stage_issue(per);
             }
         }
-        if (lane < 12) {   // this wave's rows (its own LDS stores above: in order)
+        if (!FOLD) {
+            if (lane < 12) {   // this wave's rows (its own LDS stores above: in order)
 #pragma unroll
-            for (int g = 0; g < G; ++g) qkv_s[g * 192 + jb] += bj_mine;
+                for (int g = 0; g < G; ++g) qkv_s[g * 192 + jb] += c_mine;
+            }
+        } else {
+        lds_barrier();   // every wave's raw sums, second-pass statistics and bias row are in LDS
+        // fix-up: the wave's own 12 rows (lanes 0..11) and, by the first 64 G threads, the residual ln1(x) of this head's columns into the (now free) row buffer
+        if (lane < 12 || tid < 64 * G) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { t1 += stat[w * G + g]; t2 += stat2[w * G + g]; }
+                const float mean = t1 / (float)D, rstd = rsqrtf(t2 / (float)D + a.eps);
+                if (lane < 12) qkv_s[g * 192 + jb] = rstd * (qkv_s[g * 192 + jb] - mean * c_mine) + d_mine;
+                if ((tid >> 6) == g) xn_s[g * D + head * 64 + lane] = (xh_s[g * 64 + lane] - mean) * rstd * gh_s[lane] + gh_s[64 + lane];
+            }
+        }
         }
     }
     lds_barrier();
@@ -746,6 +785,25 @@ size_t ar_attn_fused_max_lds() {
     return v;
 }
 
+__global__ __launch_bounds__(256) void ar_ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ cs, float* __restrict__ ds, int N, int K) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per row
+    if (j >= N) return;
+    double c = 0.0, d = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double w = W[(long)j * K + k];
+        c += w * (double)gamma[k];
+        d += w * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { c += __shfl_xor(c, o, 64); d += __shfl_xor(d, o, 64); }
+    if (lane == 0) { cs[j] = (float)c; ds[j] = (float)(d + (double)b[j]); }
+}
+void launch_ar_ln_fold(const float* W, const float* b, const float* gamma, const float* beta, float* cs, float* ds, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(ar_ln_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, b, gamma, beta, cs, ds, N, K);
+    LAUNCH_CHECK();
+}
+
 bool ar_attn_fused_supported(int B, int G, int D, int H) { return D == H * 64 && D % 4 == 0 && D <= 1024 && (G == 1 || G == 2 || G == 4) && B % G == 0; }
 
 void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
@@ -755,6 +813,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     a.Lpad = (int)round_up(a.Lmax, 4);
     const bool pre = a.qkv != nullptr;
     BG_REQUIRE(!pre || a.xn, "decode attention: precomputed q/k/v rows need the ln1(x) rows for the residual");
+    BG_REQUIRE(pre || !a.wqkv_h || (a.ln_cs && a.ln_ds), "fused decode attention: the folded LayerNorm (fp16 weights) needs its row constants (launch_ar_ln_fold)");
     if (pre) { a.x = RowSrc{}; a.x.base = a.qkv; a.x.ld = 3 * a.D; }
     a.x = rowsrc_fix(a.x);
     a.has_bias = a.bias != nullptr;

@@ -234,6 +234,7 @@ struct ArAttnFusedArgs {
     const float* wqkv = nullptr;       // fused [3D, D] (q | k | v), bqkv [3D]
     const void* wqkv_h = nullptr;      // non-null: the same matrix stored as fp16 (decode_weights = f16), read instead of wqkv
     const float* bqkv = nullptr;
+    const float *ln_cs = nullptr, *ln_ds = nullptr;   // [3D] each: W gamma and W beta + b of the fused matrix (launch_ar_ln_fold): the fused kernel folds ln1 into its projection
     void* kcache = nullptr;            // this layer's [B, H, Lmax, 64]
     void* vcache = nullptr;
     int kv_dtype = 0;                  // 0 fp32, 1 fp16 storage
@@ -262,6 +263,8 @@ struct ArAttnFusedArgs {
     int has_bias = 0;                  // filled in by the launcher
 };
 bool ar_attn_fused_supported(int B, int G, int D, int H);
+// per-row constants of LayerNorm folded into a projection: cs[j] = sum_k W[j][k] gamma[k], ds[j] = sum_k W[j][k] beta[k] + b[j]   (W [N, K] row-major; fp64 accumulation)
+void launch_ar_ln_fold(const float* W, const float* b, const float* gamma, const float* beta, float* cs, float* ds, int N, int K, hipStream_t s);
 void launch_ar_attn_fused(const ArAttnFusedArgs& a, hipStream_t s);
 
 struct SkinnyFusedArgs {
