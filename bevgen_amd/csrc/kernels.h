@@ -102,6 +102,10 @@ void launch_ln_colsum(const float* W /* [N, ldw] */, int ldw, const float* gamma
 void launch_geglu_layernorm_planes(const float* h, int ldh, const float* gamma, void* planes, int ldy, int rows, int F, float eps, hipStream_t s);
 // GroupNorm(32 groups, eps) statistics over NHWC [n, hw, C] -> stats[n*32*2] = (mean, rstd)
 size_t groupnorm_ws_bytes(int n, int hw);
+// decoder tail: GroupNorm(32)-apply + swish + 3x3 convolution C -> 3 + denormalise + NCHW (fp32 y or uint8 y8) in one kernel (x NHWC fp32, wgt [3][3][3][C])
+bool vq_out_conv_supported(int C, int cout);
+void launch_vq_out_conv(const float* x, const float* stats, const float* gamma, const float* beta, const float* wgt, const float* bias, const float* mean, const float* stdv, int clamp01,
+                        float* y, uint8_t* y8, int n, int H, int W, int C, int cout, hipStream_t s);
 void launch_groupnorm_stats(const float* x, float* stats, void* ws /*groupnorm_ws_bytes*/, int n, int hw, int C, float eps, hipStream_t s);
 // y = (x-mean)*rstd*gamma+beta, optionally followed by swish (x*sigmoid(x)); NHWC
 void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s);

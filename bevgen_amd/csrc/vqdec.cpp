@@ -277,10 +277,18 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
                 x = Act{y, x.n, x.h * 2, x.w * 2, u.up.cout};
             }
         }
+        const long o_off = (long)i0 * g.vq_out_ch * RH * RW;
+        static const bool tail_off = getenv("BEVGEN_VQ_TAIL") && atoi(getenv("BEVGEN_VQ_TAIL")) == 0;   // (A/B switch: 0 = the three-kernel tail)
+        if (!tail_off && vq_out_conv_supported(x.c, g.vq_out_ch)) {   // norm_out + swish + conv_out + denormalise + layout in one kernel
+            launch_groupnorm_stats(x.p, ws.stats, ws.gn_ws, x.n, x.h * x.w, x.c, 1e-6f, s);
+            launch_vq_out_conv(x.p, ws.stats, c.norm_out_w, c.norm_out_b, c.conv_out.w, c.conv_out.b, denorm ? c.denorm_mean : nullptr, denorm ? c.denorm_std : nullptr, denorm ? 1 : 0,
+                               out_mode == 2 ? nullptr : reinterpret_cast<float*>(out) + o_off, out_mode == 2 ? reinterpret_cast<uint8_t*>(out) + o_off : nullptr, x.n, x.h, x.w, x.c,
+                               g.vq_out_ch, s);
+            continue;
+        }
         gn(x, c.norm_out_w, c.norm_out_b, ws.t, 1, ws, s, planes);
         Act t{ws.t, x.n, x.h, x.w, x.c};
         conv3(t, c.conv_out, img, nullptr, 0, s, planes);  // [n, RH*RW, out_ch]
-        const long o_off = (long)i0 * g.vq_out_ch * RH * RW;
         launch_nhwc_to_nchw(img, out_mode == 2 ? nullptr : reinterpret_cast<float*>(out) + o_off, n, RH * RW, g.vq_out_ch, g.vq_out_ch, denorm ? c.denorm_mean : nullptr,
                             denorm ? c.denorm_std : nullptr, denorm ? 1 : 0, s, out_mode == 2 ? reinterpret_cast<uint8_t*>(out) + o_off : nullptr);
     }
