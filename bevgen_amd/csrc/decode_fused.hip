@@ -563,8 +563,8 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         // same-box A/Bs, profiles/r04_ab_kv_stage.txt): the CU returns loads in issue order across its waves and a wave blocks at a VMEM instruction while the
         // CU's request queue is full, so (a) pieces requested BEFORE the x rows delay them from 1.6 to 6.3 us; (b) a single 128 KB burst here holds every wave at its
         // request instructions for ~5 us (HBM feeds one CU 25 GB/s): the walk 5 us shorter, the prologue 3 us longer; (c) two row batches deep in registers in front
-        // of the burst keep the multipliers busy while it drains; (d) with fp16 weights (4 rows per batch, 3 batches) two pieces here and two behind each batch
-        // is best: 1.060 vs 1.088 ms/step all-early vs 1.145 without staging; with fp32 weights (6 batches) all-early wins, 1.204 vs 1.225 vs 1.241.
+        // of the burst keep the multipliers busy while it drains; (d) with fp16 weights (4 rows per batch, 3 batches; ln1 folded) every piece behind the row batches
+        // is best: 1.040 vs 1.050 (two here) vs 1.062 (four here) vs 1.110 ms/step without staging; with fp32 weights (6 batches) all-early wins, 1.204 vs 1.225 vs 1.241.
         if (STG) stage_issue(a.stage_top);
         // second statistics pass.  Folded form: in the shadow of the weight loads, read by the fix-up behind the row loop's closing barrier.  Direct form: two more
         // barrier rounds, then the normalised row goes to LDS
@@ -834,7 +834,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
         int cap = a.stage_cap >= 0 ? a.stage_cap : (env_cap >= 0 ? env_cap : 8);
         cap = std::max(0, std::min(cap, room)) / step_pieces * step_pieces;
         a.stage_cap = cap;
-        a.stage_top = a.stage_top >= 0 ? a.stage_top : (env_top >= 0 ? env_top : (a.wqkv_h ? 2 : cap));
+        a.stage_top = a.stage_top >= 0 ? a.stage_top : (env_top >= 0 ? env_top : (a.wqkv_h ? 0 : cap));
         lds += (size_t)cap * AF_WAVES * 1024;
     } else {
         a.stage_cap = a.stage_top = 0;
@@ -897,6 +897,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
     __shared__ float4 As[256 * 16];
     __shared__ float red[SF_WAVES][4][64];
     __shared__ float stat[2][SF_WAVES][16];
+    __shared__ __attribute__((aligned(16))) float pf_sink[256];   // (prefetch: the bytes are never read, only their passage through L2 matters)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16, split = blockIdx.y;
@@ -1032,6 +1033,15 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
         }
         __syncthreads();
         SF_TRACE(1);
+        if (LN && !RS && g.pf_ptr && mc == 0) {   // (the barrier above drained this wave's loads: its own weight slice is in)
+            const int i = blockIdx.y * gridDim.x + blockIdx.x, xr = i & 7, j = i >> 3;
+            const int tx = xr + 8 * (j / g.pf_splits), ty = j % g.pf_splits;
+            if (tx < g.pf_tiles) {
+                const char* src = reinterpret_cast<const char*>(g.pf_ptr) + (long)tx * g.pf_tile_bytes + (long)ty * g.pf_slice_bytes;
+                const unsigned sink = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(&pf_sink[0]));
+                for (int o = wave * 1024; o < g.pf_slice_bytes; o += SF_WAVES * 1024) glds16_hidden(src + o + lane * 16, sink);
+            }
+        }
 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (WT) {
@@ -1085,6 +1095,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
         }
         if (mc + 1 < n_mc) __syncthreads();   // As / red are rewritten by the next row chunk
     }
+    if (LN && !RS && g.pf_ptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prefetch writes LDS: it must have landed before the workgroup's LDS is released)
     SF_TRACE(3);
 #undef SF_TRACE
 }

@@ -7,7 +7,7 @@ cd $R && python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${
 tail -c 600 gpurun_out/${TAG}_bench_default.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_bench
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs --no-decode-leg --no-exact-leg > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_bench.err
+BEVGEN_BENCH_NO_PMC=1 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bench -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-legs --no-decode-leg --no-exact-leg > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/prof_bench.err
 DB=$(find $R/gpurun_out/prof_bench -name "*.db" | head -1)
 python $R/tools/rocpd_kernel_stats.py $DB > $R/gpurun_out/${TAG}_bench_kernel_stats.csv
 rm -rf $R/gpurun_out/prof_bench
