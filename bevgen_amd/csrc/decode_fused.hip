@@ -955,15 +955,15 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
     };
     float4 v[8];
     load_a(0, v);
-    float4 gm[LN ? 8 : 1], bt[LN ? 8 : 1];
+    // LayerNorm gamma / beta (K <= 1024 floats each): ONE float4 per thread, parked in LDS behind the first statistics barrier and read back at the normalisation.
+    // (Eight float4 of each per thread were 128 KB of L2 loads per workgroup in front of the weight requests - loads go out and come back in order - 1.4 us of the CU's
+    // address pipe: the weight slice arrived at 5.7 us in this kernel against 3.7-4.0 us in the MLP-down launch that has no LayerNorm.)
+    float4 gb_raw = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LN) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = min(q + 4 * wave + 32 * j, nch - 1);
-            gm[j] = *reinterpret_cast<const float4*>(g.ln_w + 4 * c);
-            bt[j] = *reinterpret_cast<const float4*>(g.ln_b + 4 * c);   // launcher: a missing beta aliases gamma, has_ln_b = 0
-        }
+        const int c = min(tid & 255, nch - 1);
+        gb_raw = *reinterpret_cast<const float4*>((tid < 256 ? g.ln_w : g.ln_b) + 4 * c);   // launcher: a missing beta aliases gamma, has_ln_b = 0
     }
+    float4 (*gb_s)[256] = reinterpret_cast<float4 (*)[256]>(&red[0][0][0]);   // gamma | beta share the 8 KB of `red` (free until the MFMAs are done)
     float4 wv[WT ? 1 : 8];
     half8_t wh[WT ? 4 : 1];
     if (WT) {
@@ -990,6 +990,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
             s += __shfl_xor(s, 16, 64);
             s += xor32(s);
             if (q == 0) stat[0][wave][r] = s;
+            gb_s[tid >> 8][tid & 255] = gb_raw;   // (every row chunk: `red` is rewritten by the chunk's reduction)
             __syncthreads();
             float t = 0.f;
 #pragma unroll
@@ -1014,8 +1015,10 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float fb = g.has_ln_b ? 1.f : 0.f;
-                v[j] = make_float4(fmaf(bt[j].x, fb, (v[j].x - mean) * rstd * gm[j].x), fmaf(bt[j].y, fb, (v[j].y - mean) * rstd * gm[j].y),
-                                   fmaf(bt[j].z, fb, (v[j].z - mean) * rstd * gm[j].z), fmaf(bt[j].w, fb, (v[j].w - mean) * rstd * gm[j].w));
+                const int c = min(q + 4 * wave + 32 * j, nch - 1);
+                const float4 gm = gb_s[0][c], bt = gb_s[1][c];
+                v[j] = make_float4(fmaf(bt.x, fb, (v[j].x - mean) * rstd * gm.x), fmaf(bt.y, fb, (v[j].y - mean) * rstd * gm.y),
+                                   fmaf(bt.z, fb, (v[j].z - mean) * rstd * gm.z), fmaf(bt.w, fb, (v[j].w - mean) * rstd * gm.w));
             }
             // every workgroup holds the same normalised rows: workgroup i writes the chunks c with c % gridDim.x == i (each element once)
             if (RS && g.xn_out) {   // (only the row-source form - the LayerNorm + QKV projection of the split decode path - keeps ln1(x))
