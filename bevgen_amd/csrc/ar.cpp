@@ -325,6 +325,7 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
     const int D = c.D, H = c.H, B = st.B, L = c.L;
     const size_t eb = cache_elem_bytes(c);
     float* x = w.x + (size_t)r0 * D;
+    if (!(st.pick_embeds && tok == w.tok && r0 == 0 && Bc == B))   // (ar_sample's pick launch already wrote the new rows' embeddings)
     launch_ar_step_embed(tok + r0, c.pf("x_tok_emb.weight"), st.img_embed ? st.img_embed + (size_t)r0 * g.num_cams * c.T * D : nullptr, c.pf("x_pos_emb"), c.fwd_idx,
                          st.d_step, x, Bc, g.num_cams, c.T, D, g.vocab_size + 1, s);
     const size_t layer_bytes = (size_t)B * H * L * 64 * eb;
@@ -490,6 +491,7 @@ void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s) {
     BG_REQUIRE(st.step < c.N, "all %d image tokens have already been decoded", c.N);
     c.arena.reset();
     StepWs w = step_ws(c, st.B);
+    st.pick_embeds = false;   // the caller's tokens: embed them here
     decode_step_launch(c, w, tok, s);
     st.step += 1;
 }
@@ -508,10 +510,17 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     // one decode iteration: logits of the newest row -> token -> (optionally) push the token through the stack.
     // Every position-dependent quantity (decode-order index, cache slot, bias row, context length, noise row) is read from the device-side
     // step counter, so the launch sequence is identical for every step and can be captured once and replayed as a hipGraph.
+    // (the token's store into `out` and - fused path, one chain - the new row's embedding ride in the pick launch: two launches per step less)
+    ArPickTail tail;
+    tail.out_all = out; tail.fwd_idx = c.fwd_idx; tail.N = c.N;
+    st.pick_embeds = fused_path(c, B, st.G) && decode_chains(c, B, st.G) == 1 && !(getenv("BEVGEN_PICK_TAIL") && atoi(getenv("BEVGEN_PICK_TAIL")) == 0);
+    if (st.pick_embeds) {
+        tail.tok_emb = c.pf("x_tok_emb.weight"); tail.img_embed = st.img_embed; tail.pos_emb = c.pf("x_pos_emb"); tail.x = w.x;
+        tail.C = c.cfg.num_cams; tail.T = c.T; tail.D = c.D; tail.vocab_rows = c.cfg.vocab_size + 1;
+    }
     auto head_and_pick = [&](float* lg, hipStream_t q) {
         head_logits(c, w, B, lg, q);
-        launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u, st.d_step, forced, w.tok, B, c.V, top_k, temperature, q);
-        launch_store_tokens(w.tok, c.fwd_idx, st.d_step, out, B, c.N, q);
+        launch_ar_pick(lg, c.V, greedy ? nullptr : noise_u, st.d_step, forced, w.tok, B, c.V, top_k, temperature, q, &tail);
     };
 
     const bool use_graph = steps > 2 && !step_logits && !prof_enabled() && !c.disable_graphs;

@@ -340,8 +340,14 @@ void launch_critic_scores(const float* embed, int lde, const float* w, const flo
 void launch_philox_fill(float* out, long n, unsigned long long seed, unsigned iter, unsigned stream, int V /* stream 0: vocabulary size (row layout) */, hipStream_t s);
 // Route A token pick (ar_lm:204-219): logits/temperature, top-k (ties kept), softmax, argmax or inverse-CDF draw with explicit u
 //   forced [steps, rows] (or null): entries >= 0 are emitted instead of a drawn token (partial decoding, ar_lm:161-165,181-182)
+// `tail` (optional): what the decode step does with the token next, done by the same launch - out_all[row, fwd_idx[step]] = token (ar_lm:219) and the new row's embedding
+// x[row, :] = x_tok_emb[token] + img_embed[row, fwd_idx[step]] + x_pos_emb[fwd_idx[step]] (gpt:331-365 for the one new row): two launches per step less
+struct ArPickTail {
+    int64_t* out_all = nullptr; const int64_t* fwd_idx = nullptr; int N = 0;
+    const float *tok_emb = nullptr, *img_embed = nullptr, *pos_emb = nullptr; float* x = nullptr; int C = 0, T = 0, D = 0, vocab_rows = 0;
+};
 void launch_ar_pick(const float* logits, int ldl, const float* u /*[steps, rows] or null*/, const int* d_step /*or null: u is this step's row*/, const int64_t* forced,
-                    int64_t* out, int rows, int V, int top_k, float temperature, hipStream_t s);
+                    int64_t* out, int rows, int V, int top_k, float temperature, hipStream_t s, const ArPickTail* tail = nullptr);
 
 // ---------------------------------------------------------------- vq.hip
 void launch_codebook_gather(const int64_t* ids, const float* codebook, float* out, int rows, int dim, int n_embed, hipStream_t s);

@@ -114,6 +114,7 @@ struct Ctx {
         void *kcache = nullptr, *vcache = nullptr;       // [layers][B,H,L,64]
         float* hidden = nullptr;                         // [B,D] newest row after the last layer
         int* d_step = nullptr;                           // device copy of `step`
+        bool pick_embeds = false;                        // ar_sample: the pick launch also stores the token and writes the new row's embedding (ArPickTail)
     } ars;
 
     // ---- VQGAN decoder

@@ -176,8 +176,39 @@ void launch_critic_scores(const float* embed, int lde, const float* w, const flo
 
 // ---------------------------------------------------------------------------------------------- Route A token pick
 // lane owns the contiguous index range [lane*VPL, lane*VPL + VPL) so that the cumulative distribution runs in index order
+// what follows the pick in a decode step (ArPickTail): every lane holds the row's token
+__device__ __forceinline__ void ar_pick_tail(const ArPickTail& t, const int* d_step, long row, long token, int lane) {
+    if (!t.out_all) return;
+    const long j = t.fwd_idx[*d_step];
+    if (lane == 0) t.out_all[row * t.N + j] = token;
+    if (!t.x) return;
+    const long id = token < 0 ? 0 : (token >= t.vocab_rows ? t.vocab_rows - 1 : token);
+    // (one wave writes the D-wide row: 16-byte loads, four vectors per lane in flight - a scalar loop is 16 dependent L2 round trips and costs more than the launch saved)
+    const float4* te = reinterpret_cast<const float4*>(t.tok_emb + id * t.D);
+    const float4* ie = reinterpret_cast<const float4*>(t.img_embed ? t.img_embed + (row * t.C * t.T + j) * t.D : t.tok_emb);
+    const float4* pe = reinterpret_cast<const float4*>(t.pos_emb + j * t.D);
+    float4* xo = reinterpret_cast<float4*>(t.x + row * t.D);
+    const int nv = t.D >> 2;   // launcher: D % 4 == 0
+    for (int o0 = 0; o0 < nv; o0 += 256) {
+        float4 a[4], b[4], c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = min(o0 + lane + 64 * k, nv - 1);
+            a[k] = te[o]; b[k] = ie[o]; c[k] = pe[o];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = o0 + lane + 64 * k;
+            if (o < nv) {
+                const float f = t.img_embed ? 1.f : 0.f;
+                xo[o] = make_float4((a[k].x + f * b[k].x) + c[k].x, (a[k].y + f * b[k].y) + c[k].y, (a[k].z + f * b[k].z) + c[k].z, (a[k].w + f * b[k].w) + c[k].w);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ u_base, const int* __restrict__ d_step,
-                                                     const int64_t* __restrict__ forced, int64_t* __restrict__ out, int V, int top_k, float temperature) {
+                                                     const int64_t* __restrict__ forced, int64_t* __restrict__ out, int V, int top_k, float temperature, ArPickTail tail) {
     const int lane = threadIdx.x;
     const long row = blockIdx.x;
     // partial decoding (ar_lm:161-165, 181-182): positions of the fixed cameras keep their given token, laid out [steps, rows] like the noise
@@ -185,6 +216,7 @@ __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ l
         const int64_t f = forced[(d_step ? (long)(*d_step) * gridDim.x : 0) + row];
         if (f >= 0) {
             if (lane == 0) out[row] = f;
+            ar_pick_tail(tail, d_step, row, f, lane);
             return;
         }
     }
@@ -216,6 +248,7 @@ __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ l
     wave_argmax(mx, midx);
     if (!u) {
         if (lane == 0) out[row] = midx;
+        ar_pick_tail(tail, d_step, row, midx, lane);
         return;
     }
     // inverse-CDF draw: first index whose cumulative probability exceeds u * total
@@ -252,13 +285,17 @@ __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ l
         cand = min(cand, __shfl_xor(cand, o, 64));
         last = max(last, __shfl_xor(last, o, 64));
     }
-    if (lane == 0) out[row] = cand != 0x7fffffff ? cand : last;   // u * total rounding up to the total: the last token with probability
+    const int picked = cand != 0x7fffffff ? cand : last;   // u * total rounding up to the total: the last token with probability
+    if (lane == 0) out[row] = picked;
+    ar_pick_tail(tail, d_step, row, picked, lane);
 }
 
 void launch_ar_pick(const float* logits, int ldl, const float* u, const int* d_step, const int64_t* forced, int64_t* out, int rows, int V, int top_k, float temperature,
-                    hipStream_t s) {
+                    hipStream_t s, const ArPickTail* tail) {
     BG_REQUIRE(V <= 64 * VPL_MAX, "ar_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
-    hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, d_step, forced, out, V, top_k, temperature);
+    BG_REQUIRE(!tail || !tail->out_all || d_step, "ar_pick: the fused tail reads the step from the device counter");
+    BG_REQUIRE(!tail || !tail->x || tail->D % 4 == 0, "ar_pick: the fused embedding needs D %% 4 == 0");
+    hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, d_step, forced, out, V, top_k, temperature, tail ? *tail : ArPickTail{});
     LAUNCH_CHECK();
 }
 
