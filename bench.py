@@ -663,6 +663,26 @@ def main():
         # ... and the all-fp16-storage model (projection weights rounded to fp16 at load, tokens bit-exact vs the oracle on the rounded weights; fp32 arithmetic)
         h16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16")
         line["decode_f16_kv_cache_f16_weights"] = {k: h16[k] for k in dkeys}
+        # the same kernel timed on the PRODUCT path (hipGraph replay) by a rocprofv3 --kernel-trace child pass: the HIP-event pairs above bracket launch + kernel
+        if not DRY_RUN and os.environ.get("BEVGEN_BENCH_NO_PMC") != "1":
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import ktrace_inrun
+                from bevgen_amd import presets as _presets
+                steps_kt = args.decode_steps or _presets.config4().num_img_tokens
+                kt = ktrace_inrun.measure("ar_attn_fused_kernel", args.decode_batch, steps_kt, "f16", "f16")
+            except Exception as e:
+                kt = {"error": f"{type(e).__name__}: {e}"}
+            ra = line["decode_f16_kv_cache_f16_weights"]["roofline_decode_attention"]
+            if "error" not in kt:
+                cfg4 = _presets.config4()
+                kvb, _ = route_a_bytes(cfg4, args.decode_batch, steps_kt, 2, 1, 2)
+                per_launch = kvb / (steps_kt * cfg4.num_layers)
+                gbs = per_launch / (kt["avg_us"] * 1e-6) / 1e9
+                ra["kernel_trace"] = dict(kt, achieved=gbs, frac_by_survey_8d_fp16_bytes=gbs / HBM_PEAK_GBS, bytes_per_launch=per_launch,
+                                          note="K/V bytes per launch (SURVEY 8d, mean over the decode) / average kernel duration in the replayed graph")
+            else:
+                ra["kernel_trace"] = kt
         if not args.no_extra_legs:
             # SURVEY 8(d) config 4 variant: density 0.35, every layer with its own random per-head block layouts - the key walk follows the chunk lists of present blocks
             d35 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", density=0.35)
@@ -710,7 +730,9 @@ def main():
         ra, rs = d["roofline_decode_attention"], d["decode_step_roofline"]
         return {"ms_step": rnd(d["ms_per_decode_step"]), "median": rnd(d["ms_per_decode_step_median"]), "p99": rnd(d["ms_per_decode_step_p99"]),
                 "attn_frac_8d_fp16_bytes": rnd(ra.get("frac_by_survey_8d_fp16_bytes")), "attn_frac_storage_bytes": rnd(ra["frac"]), "attn_avg_us": rnd(ra["avg_us"], 2),
-                "attn_phase_frac": rnd(ra["attention_phase"]["frac"]), "step_frac": rnd(rs["frac"])}
+                "attn_phase_frac": rnd(ra["attention_phase"]["frac"]), "step_frac": rnd(rs["frac"]),
+                **({"attn_trace_avg_us": rnd(ra["kernel_trace"]["avg_us"], 2), "attn_trace_frac_8d_fp16_bytes": rnd(ra["kernel_trace"]["frac_by_survey_8d_fp16_bytes"])}
+                   if isinstance(ra.get("kernel_trace"), dict) and "avg_us" in ra["kernel_trace"] else {})}
 
     legs = {"ms_per_step_median": rnd(detail["ms_per_step_median"], 2), "ms_per_step_p99": rnd(detail["ms_per_step_p99"], 2), "ms_per_maskgit_iteration": rnd(detail["ms_per_maskgit_iteration"], 3),
             "vqgan_decode_ms_per_scene": rnd(detail["vqgan_decode_ms_per_scene"], 3), "gather_ms_per_step": rnd(detail["gather_ms_per_step"], 3),
