@@ -375,11 +375,6 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
         a.n = c.K + 1; a.d_n = st.d_step; a.n_hint = st.step;
         a.prefix = c.K; a.scale = 0.125f;
         a.trace = c.trace;
-        if (c.prefetch_weights) {   // the MLP weight images of this layer ride into L2 under the tail of the K/V walk
-            const size_t eb_w = wf16 ? 2 : 4;
-            a.pf_ptr[0] = l.mlp0_wp; a.pf_bytes[0] = (long)(skinny_packed_floats(4 * D, D) * eb_w);
-            a.pf_ptr[1] = l.mlp2_wp; a.pf_bytes[1] = c.prefetch_weights == 2 ? 0 : (long)(skinny_packed_floats(D, 4 * D) * eb_w);
-        }
         launch_ar_attn_fused(a, s);
         SkinnyFusedArgs up;
         up.A = x2; up.lda = D;

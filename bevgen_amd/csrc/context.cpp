@@ -204,23 +204,6 @@ static void finalize_muse(Ctx& c) {
             c.split_weight(l.ff_w1_geglu, 2L * c.Fpad * D);
         }
         c.split_weight(l.ff_w4_padded, (long)D * c.Fpad);
-        if (l.ff_w1_geglu) {
-            // LayerNorm folded into the GEMMs: the constants that carry the row mean through each consumer projection - computed AFTER split_weight, which in
-            // weights = f16 mode rounds the matrices in place (the colsum must belong to the matrix the GEMM multiplies by)
-            auto colsum = [&](const float* W, int ldw, const float* gamma, int N, int K) {
-                float* cs = reinterpret_cast<float*>(c.own((size_t)N * sizeof(float)));
-                launch_ln_colsum(W, ldw, gamma, cs, N, K, 0);
-                return cs;
-            };
-            l.cs_q[0] = colsum(l.to_q[0], D, l.norm_g[0], inner, D);
-            l.cs_kv0 = colsum(l.to_kv[0], D, l.norm_g[0], 2 * inner, D);
-            l.cs_q[1] = colsum(l.to_q[1], D, l.norm_g[1], inner, D);
-            l.cs_ff1 = colsum(l.ff_w1_geglu, D, l.ff_g0, 2 * c.Fpad, D);
-            l.cs_ff2 = colsum(l.ff_w4_padded, c.Fpad, l.ff_g3, D, F);
-            l.ff_g3_pad = reinterpret_cast<float*>(c.own((size_t)c.Fpad * sizeof(float)));
-            HIP_CHECK(hipMemset(l.ff_g3_pad, 0, (size_t)c.Fpad * sizeof(float)));
-            HIP_CHECK(hipMemcpy(l.ff_g3_pad, l.ff_g3, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice));
-        }
     }
     c.split_weight(c.pf(p + "to_logits.weight"), (long)g.vocab_size * D);
     // attention bias matrices with the null-key column

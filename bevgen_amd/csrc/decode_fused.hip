@@ -265,7 +265,7 @@ template <int DT, int G> struct WalkU { static constexpr int value = (G == 1 && 
 // STG (G = 1, dense): the walk opens with `js` steps staged in LDS at `st` (Attend::run_staged)
 template <int DT, int G, bool SP, bool STG = false>
 __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a, const float* bias_s, const float* qkv_s, float* red, const uint16_t* walk, int n_pos, int p_pos,
-                                                       int n, int head, int b0, const float* res_s, int ldres, float* pf_sink, const char* st = nullptr, int js = 0) {
+                                                       int n, int head, int b0, const float* res_s, int ldres, const char* st = nullptr, int js = 0) {
     static_assert(!STG || (G == 1 && !SP), "staged steps are defined on the dense walk of one sequence");
     using T = KvRow<DT>;
     constexpr int LPK = T::LPK, DPL = T::DPL, NW = AF_WAVES, TW = NW / G;
@@ -348,20 +348,6 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
             }
         }
     }
-    // ---- this wave's walk is done: while the others finish, request this workgroup's slices of the next two launches' weight images (see ArAttnFusedArgs::pf_ptr)
-    if (a.pf_bytes[0] > 0) {
-        const long nwg = (long)gridDim.x * gridDim.y, wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
-        float* sink = pf_sink;   // ONE 1 KiB sink for all waves and pieces: the bytes are never read, only their passage through L2 matters
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const long share = ((a.pf_bytes[k] + nwg * 16384 - 1) / (nwg * 16384)) * 16384;   // bytes per workgroup, a multiple of 16 waves x 1 KiB
-            const char* base = reinterpret_cast<const char*>(a.pf_ptr[k]);
-            for (long off = wg * share + wave * 1024; off < min((wg + 1) * share, a.pf_bytes[k]); off += 16 * 1024) {
-                const long o = min(off + lane * 16, a.pf_bytes[k] - 16);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + o), (__attribute__((address_space(3))) void*)sink, 16, 0, 0);
-            }
-        }
-    }
     __syncthreads();
     AF_TRACE(4);
 
@@ -412,7 +398,6 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
             a.out[(long)(b0 + g) * a.ldo + head * 64 + d] = o / l + res_s[g * ldres + d];
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prefetch DMA writes LDS: it must have landed before the workgroup's LDS is released)
     AF_TRACE(5);
 }
 
@@ -429,7 +414,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     float* red = qkv_s + G * 192;
     float* stat = red + NW * (G + 1) * 66;
     uint16_t* list_s = reinterpret_cast<uint16_t*>(stat + NW * G);
-    float* pf_sink = reinterpret_cast<float*>(list_s + ((a.Lpad / 16 + 2 + 7) & ~7));   // 1 KiB, 16-byte aligned
+    char* stage = reinterpret_cast<char*>(list_s + ((a.Lpad / 16 + 2 + 7) & ~7));   // staged K/V pieces: [16 waves][stage_cap] KiB, 16-byte aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, grp = blockIdx.y;
@@ -446,7 +431,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     using TS = KvRow<DT>;
     constexpr int KPI = 64 / TS::LPK, PIECE = NW * KPI, SU = WalkU<DT, G>::value, ROWB = 64 * (DT ? 2 : 4);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const char* st_w = reinterpret_cast<const char*>(pf_sink + 256) + (wave_u * a.stage_cap) * 1024;   // this wave's region
+    const char* st_w = stage + (wave_u * a.stage_cap) * 1024;   // this wave's region
     const int js = STG && a.stage_cap > 0 ? min(((n - 1) / PIECE) / SU, a.stage_cap / (2 * SU)) : 0;   // staged steps: whole steps of rows in the cache at kernel start
     int q_iss = 0;
     auto stage_issue = [&](int count) {   // request the next `count` pieces in LDS order (step-major: K pieces of the step, then its V pieces)
@@ -696,7 +681,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         n_pos = (n + 15) >> 4;
         p_pos = G == 1 ? 0 : min((min(a.prefix, n) + 15) >> 4, n_pos);
     }
-    af_append_attend_store<DT, G, SP, STG>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, xn_s + head * 64, D, pf_sink, st_w + lane * 16, js);
+    af_append_attend_store<DT, G, SP, STG>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, xn_s + head * 64, D, st_w + lane * 16, js);
 }
 
 // ----------------------------------------------------------------------------------------------------------------- decode attention proper
@@ -714,7 +699,6 @@ __global__ __launch_bounds__(1024) void ar_attn_kernel(ArAttnFusedArgs a) {
     float* qkv_s = res_s + G * 64;
     float* red = qkv_s + G * 192;
     uint16_t* list_s = reinterpret_cast<uint16_t*>(red + NW * (G + 1) * 66);
-    float* pf_sink = reinterpret_cast<float*>(list_s + ((a.Lpad / 16 + 2 + 7) & ~7));
 
     const int tid = threadIdx.x;
     const int head = blockIdx.x, grp = blockIdx.y;
@@ -759,7 +743,7 @@ __global__ __launch_bounds__(1024) void ar_attn_kernel(ArAttnFusedArgs a) {
     const int n_pos = SP ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < n) : (n + 15) >> 4;
     const int p_pos = G == 1 ? 0 : (SP ? __syncthreads_count(tid < chunk_total && chunk_id * 16 < min(a.prefix, n)) : min((min(a.prefix, n) + 15) >> 4, n_pos));
     AF_TRACE(2);
-    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, res_s, 64, pf_sink);
+    af_append_attend_store<DT, G, SP>(a, bias_s, qkv_s, red, SP ? list_s : nullptr, n_pos, p_pos, n, head, b0, res_s, 64);
 }
 
 #undef AF_TRACE
@@ -770,7 +754,7 @@ size_t ar_attn_lds_bytes(int G, int Lpad) {
 
 size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) {
     return ((size_t)Lpad + (size_t)G * D + (size_t)G * 192 + (size_t)AF_WAVES * (G + 1) * 66 + (size_t)AF_WAVES * G) * sizeof(float) + ((size_t)Lpad / 16 + 2 + 8) * sizeof(uint16_t) +
-           1024;   // + the prefetch sink
+           1024;   // (+ 1 KiB of slack)
 }
 
 // LDS a workgroup may allocate on this device (gfx950: 160 KB), queried once
@@ -826,7 +810,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     // K/V staging (fused kernel, G = 1, dense walk): what the CU's LDS has left beyond the kernel's own 24 KB, in whole pipeline steps per wave (gfx950: 160 KB per
     // workgroup -> 8 pieces per wave = 128 KB).  $BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override the launcher's choice (A/B switches; 0 = off)
     const bool sp_walk = a.vis.has_chunks;
-    if (!pre && a.G == 1 && !sp_walk && a.pf_bytes[0] == 0) {
+    if (!pre && a.G == 1 && !sp_walk) {
         static const int env_cap = getenv("BEVGEN_KV_STAGE") ? atoi(getenv("BEVGEN_KV_STAGE")) : -1;
         static const int env_top = getenv("BEVGEN_KV_STAGE_TOP") ? atoi(getenv("BEVGEN_KV_STAGE_TOP")) : -1;
         const int step_pieces = 2 * (a.kv_dtype == 0 ? 4 : 2);   // K + V pieces of one pipeline step (WalkU)

@@ -282,28 +282,6 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
     if constexpr (TJ == 2) {   // the fused epilogues and the split-K partial store assume 64-column wave patches
-    if (MODE == MODE_PLAIN && g.ln_stats) {
-        // LayerNorm of the A rows, applied to the finished sums (GemmArgs::ln_*): the planes hold x * gamma, so  LN(x) W^T = rstd acc - (mean rstd) colsum.  In place:
-        // every epilogue below then reads (accM + 0) as if the GEMM had run on normalised rows.
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int m = min(m0 + wm * WROWS + i * 32 + r, g.M - 1);
-            const float2 st = *reinterpret_cast<const float2*>(g.ln_stats + 2 * (long)m);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int n = min(n0 + wn * 64 + j * 32 + 8 * qq + 4 * h, g.N - 4);
-                    const f32x4 cs = *reinterpret_cast<const f32x4*>(g.ln_colsum + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int q = qq * 4 + e;
-                        accM[i][j][q] = fmaf(-st.y, cs[e], (accM[i][j][q] + accC[i][j][q] * kGLoInv) * st.x);
-                        accC[i][j][q] = 0.f;
-                    }
-                }
-        }
-    }
     if (g.epi == EPI_MUSE_Q) {
         // Route M query preparation fused into the to_q projection (muse_net:132-137; replaces muse_q_prep_split): the wave's 64 columns are
         // exactly one head, so q = l2norm(8 x) * q_scale is a per-lane reduction over its 32 registers plus one lane-half exchange; the
@@ -441,45 +419,6 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                 if (C) *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + o) = v;
             }
         }
-        if (g.ln_gamma) {
-            // LayerNorm producer (GemmArgs::ln_*): the wave's 32 output columns of a row are one statistics group; planes of (h * gamma) for the down-projection
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int m = m0 + wm * WROWS + i * 32 + r;
-                const int o0 = (n0 >> 1) + wn * 32;
-                float v[16];
-                float sum = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float xa = (accM[i][0][q] + accC[i][0][q] * kGLoInv) * g.alpha;
-                    const float gt = (accM[i][1][q] + accC[i][1][q] * kGLoInv) * g.alpha;
-                    const int col = o0 + 8 * (q >> 2) + 4 * h + (q & 3);
-                    v[q] = col < g.ln_valid ? gt * gelu_erf(xa) : 0.f;
-                    sum += v[q];
-                }
-                sum += xor32(sum);
-                const int cnt = max(0, min(32, g.ln_valid - o0));
-                const float mean = cnt > 0 ? sum / (float)cnt : 0.f;
-                float m2 = 0.f;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int col = o0 + 8 * (q >> 2) + 4 * h + (q & 3);
-                    const float d = col < g.ln_valid ? v[q] - mean : 0.f;
-                    m2 = fmaf(d, d, m2);
-                }
-                m2 += xor32(m2);
-                if (m >= g.M) continue;
-                if (h == 0) *reinterpret_cast<float2*>(g.ln_part + ((long)m * g.ln_ngroups + (o0 >> 5)) * 2) = make_float2(mean, m2);
-                _Float16* prow = reinterpret_cast<_Float16*>(g.ln_planes) + (long)m * 2 * g.ln_ld;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int o = o0 + 8 * qq + 4 * h;
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(g.ln_gamma + o);   // gamma is padded with zeros to the plane width (ln_ld)
-                    const float4 pv = make_float4(v[qq * 4 + 0] * gm[0], v[qq * 4 + 1] * gm[1], v[qq * 4 + 2] * gm[2], v[qq * 4 + 3] * gm[3]);
-                    store_planes4(prow, o, pv);
-                }
-            }
-        }
         return;
     }
     if (KS && ksl > 1) {   // raw tile sums of this k slice; launch_splitk_reduce adds the slices in order and applies the epilogue
@@ -496,60 +435,6 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (n + e < g.N) P[(long)m * g.N + n + e] = accM[i][j][qq * 4 + e] + accC[i][j][qq * 4 + e] * kGLoInv;
-                }
-        }
-        return;
-    }
-    if (MODE == MODE_PLAIN && g.ln_gamma) {
-        // residual-add projection that also PRODUCES the next LayerNorm's operand (GemmArgs::ln_*): C = acc + R as fp32 (the residual stream), planes of
-        // (C row * gamma) for the consumer GEMM, and per row the (mean, M2) of the wave's 64 columns.  Vector path only (launcher: ldc, ldr, N multiples of 4 / 128).
-        float* C = g.C;
-        const float* Rp = g.R;
-        const int ncol = n0 + wn * 64;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int m = m0 + wm * WROWS + i * 32 + r;
-            const int mr = min(m, g.M - 1);
-            float v[2][16];
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int n = ncol + j * 32 + 8 * qq + 4 * h;
-                    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-                    if (Rp) rv = *reinterpret_cast<const f32x4*>(Rp + (long)mr * g.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int q = qq * 4 + e;
-                        v[j][q] = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha + rv[e];
-                        sum += v[j][q];
-                    }
-                }
-            sum += xor32(sum);
-            const float mean = sum * (1.f / 64.f);
-            float m2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float d = v[j][q] - mean;
-                    m2 = fmaf(d, d, m2);
-                }
-            m2 += xor32(m2);
-            if (m >= g.M) continue;
-            if (h == 0) *reinterpret_cast<float2*>(g.ln_part + ((long)m * g.ln_ngroups + (ncol >> 6)) * 2) = make_float2(mean, m2);
-            _Float16* prow = reinterpret_cast<_Float16*>(g.ln_planes) + (long)m * 2 * g.ln_ld;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int n = ncol + j * 32 + 8 * qq + 4 * h;
-                    f32x4 o;
-                    o[0] = v[j][qq * 4]; o[1] = v[j][qq * 4 + 1]; o[2] = v[j][qq * 4 + 2]; o[3] = v[j][qq * 4 + 3];
-                    *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + n) = o;
-                    const f32x4 gm = *reinterpret_cast<const f32x4*>(g.ln_gamma + n);
-                    store_planes4(prow, n, make_float4(o[0] * gm[0], o[1] * gm[1], o[2] * gm[2], o[3] * gm[3]));
                 }
         }
         return;
@@ -617,17 +502,11 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
                        g.epi_ld >= g.epi_rows + 1 && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE && (g.no_row_split || g.M % g.epi_rows == 0),
                    "gemm_split_glds: bad fused k/v-preparation arguments");
     if (g.epi == EPI_GEGLU)
-        BG_REQUIRE(g.mode == MODE_PLAIN && g.N % GBN == 0 && ((g.ldc % 4 == 0 && g.ldc >= g.N / 2) || (!g.C && g.ln_gamma)) && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE,
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.N % GBN == 0 && (g.ldc % 4 == 0 && g.ldc >= g.N / 2) && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE,
                    "gemm_split_glds: bad fused GEGLU arguments (N=%d ldc=%d)", g.N, g.ldc);
     if (g.epi == EPI_MUSE_Q)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");
-    if (g.ln_gamma)
-        BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_planes && g.ln_part && g.ln_ld % 32 == 0 && g.ksplit <= 1 && g.N % GBN == 0 && !g.bias_n && !g.bias_m && g.act == ACT_NONE &&
-                       ((g.epi == 0 && g.C && g.ldc % 4 == 0 && (!g.R || g.ldr % 4 == 0) && g.ln_ngroups >= g.N / 64 && g.ln_ld >= g.N) ||
-                        (g.epi == EPI_GEGLU && g.ln_ngroups >= g.N / 64 && g.ln_ld >= g.N / 2 && g.ln_valid > 0 && g.ln_valid <= g.N / 2)),
-                   "gemm_split_glds: bad LayerNorm-producer arguments (N=%d epi=%d)", g.N, g.epi);
-    if (g.ln_stats) BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_colsum && g.N % 4 == 0 && g.ksplit <= 1, "gemm_split_glds: bad LayerNorm-consumer arguments");
     g.tile_band = 4;   // band height of the XCD-aware tile order (measured optimum for 256 x 128 tiles)
     static const int force_wm = getenv("BEVGEN_GEMM_WM") ? atoi(getenv("BEVGEN_GEMM_WM")) : 0;   // 2 | 4: pins the block rows (128 | 256) for A/B runs
     // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
@@ -640,7 +519,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     // is cut at a row-tile boundary: the first part fills whole rounds, the rest (<= 128 tiles' worth of rows) runs as 128-row blocks, one short round of its own
     // (about 0.45 of a full one).  Same kernels, same per-row arithmetic: results are bit-identical to the single launch.  $BEVGEN_GEMM_ROWSPLIT=0 turns it off (A/B runs)
     static const int rowsplit_env = getenv("BEVGEN_GEMM_ROWSPLIT") ? atoi(getenv("BEVGEN_GEMM_ROWSPLIT")) : 1;
-    if (rowsplit_env && !g.no_row_split && wm == 4 && g.mode == MODE_PLAIN && g.ksplit <= 1 && !g.ln_gamma && !g.ln_stats) {
+    if (rowsplit_env && !g.no_row_split && wm == 4 && g.mode == MODE_PLAIN && g.ksplit <= 1) {
         const long gx = cdiv(g.N, GBN), gy = cdiv(rows, 256), T = gx * gy;
         const long full = T / 256;                       // whole rounds
         const long gy_top = full * 256 / gx;             // row tiles that fit them
@@ -672,7 +551,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     const bool thin = wm == 2 && shape == 8, half = wm == 2 && shape == 16;
     // ... and with the plain epilogue (bias / activation / residual: the fused ones need 64-column wave patches) the 64-row block runs on eight waves of 32x32 patches
     static const int half8_env = getenv("BEVGEN_GEMM_HALF8") ? atoi(getenv("BEVGEN_GEMM_HALF8")) : 1;
-    const bool half8 = half && half8_env && g.epi == 0 && !g.ln_gamma && !g.ln_stats;
+    const bool half8 = half && half8_env && g.epi == 0;
     const int tbm = half ? 64 : wm * 64;
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);

@@ -56,13 +56,6 @@ struct GemmArgs {
     const void* epi_aux = nullptr;
     int epi_ld = 0;
     float epi_post = 1.f;             // EPI_MUSE_Q: extra factor on the prepared query (the attention kernel's score scale, folded in here)
-    // LayerNorm folded into the GEMMs around it (LDS-DMA path, Route M): LN(x) W^T = rstd (x * gamma) W^T - rstd mean colsum,  colsum[n] = sum_k gamma_k W[n,k]
-    //  producer (ln_gamma != null): besides C (+R) the epilogue writes the (hi, lo) planes of (C row * ln_gamma) to ln_planes [M][ln_ld/32][hi 32 | lo 32] - the A operand
-    //    of the consumer - and, per row and column group (64 columns of a wave; 32 output columns in the GEGLU epilogue), the group's (mean, M2 about it) over the
-    //    columns < ln_valid to ln_part [M][ln_ngroups][2]; launch_ln_stats_merge (norm.hip) turns them into ln_stats.  C may be null with EPI_GEGLU
-    //  consumer (ln_stats != null [M][2] = (rstd, mean * rstd), ln_colsum [N]): acc <- rstd acc - (mean rstd) colsum[n] before the epilogue proper
-    const float* ln_gamma = nullptr; void* ln_planes = nullptr; int ln_ld = 0; float* ln_part = nullptr; int ln_ngroups = 0, ln_valid = 0;
-    const float* ln_stats = nullptr; const float* ln_colsum = nullptr;
     // LDS-DMA path, small-M problems (low-latency B = 1 scenes): the k range is cut into `ksplit` slices on gridDim.z, every slice leaves its raw fp32 tile sums in
     // kpart [ksplit][M][N] and splitk_reduce adds them in slice order (deterministic) before alpha / bias / activation / residual.  Plain epilogue only.
     int ksplit = 1;
@@ -95,10 +88,6 @@ void launch_layernorm(const float* x, int ldx, const float* gamma, const float* 
 void launch_geglu_layernorm(const float* h, int ldh, const float* gamma, float* y, int ldy, int rows, int F, float eps, hipStream_t s);
 // Same two, writing the interleaved (hi, lo) f16 plane image [row][ldy/32][2][32] that the LDS-DMA split-precision GEMM reads (ldy % 32 == 0)
 void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const float* beta, void* planes, int ldy, int rows, int D, float eps, hipStream_t s);
-// LayerNorm folded into the surrounding GEMMs (GemmArgs::ln_*): standalone producer (rows that no GEMM produced: the token embedding), partial-statistics merge, colsum
-void launch_ln_prep_planes(const float* x, int ldx, const float* gamma, void* planes, int ldy, float* stats /* [rows][2] = (rstd, mean rstd) */, int rows, int D, float eps, hipStream_t s);
-void launch_ln_stats_merge(const float* part /* [rows][ngroups][2] = (mean, M2) */, int ngroups, int group, int valid, float* stats, int rows, float eps, hipStream_t s);
-void launch_ln_colsum(const float* W /* [N, ldw] */, int ldw, const float* gamma /* [K] */, float* colsum, int N, int K, hipStream_t s);
 void launch_geglu_layernorm_planes(const float* h, int ldh, const float* gamma, void* planes, int ldy, int rows, int F, float eps, hipStream_t s);
 // GroupNorm(32 groups, eps) statistics over NHWC [n, hw, C] -> stats[n*32*2] = (mean, rstd)
 size_t groupnorm_ws_bytes(int n, int hw);
@@ -250,9 +239,6 @@ struct ArAttnFusedArgs {
     int prefix = 0;                    // G > 1: leading keys shared by the G sequences of a group (read from the group's first cache slot)
     float scale = 0.125f;
     long long* trace = nullptr;        // diagnostics: [workgroup][8] device timestamps (100 MHz) at the phase boundaries, or null
-    // cross-kernel prefetch: the weight images the NEXT two launches of the layer stream (ln2 + MLP-up, MLP-down).  Every workgroup pulls "its" 1/nwg slice of each
-    // through the L2 of its XCD while its K/V walk drains (LDS-DMA into a scratch sink: no registers) - workgroup j of the next launch runs on the same XCD (j % 8)
-    // and finds its 64 KB slice in L2 instead of starting with one cold HBM burst.  pf_bytes = 0: off
     // key split (attention-only kernel, G = 1, few sequences): gridDim.z = ksplit workgroups share one (sequence, head), each walks a contiguous range of the
     // list positions and leaves (max, sum, unnormalised output[64]) in kws [B][H][ksplit][66]; launch_ar_attn_fused then runs the combine kernel (+ residual)
     int ksplit = 1;
@@ -262,8 +248,6 @@ struct ArAttnFusedArgs {
     // do; the walk reads those steps from LDS and the rest from HBM.  stage_top of the pieces are requested when the x rows have arrived, the others in equal shares behind
     // the projection's row batches.  -1 = the launcher's choice ($BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override), 0 = off
     int stage_cap = -1, stage_top = -1;
-    const void* pf_ptr[2] = {nullptr, nullptr};
-    long pf_bytes[2] = {0, 0};
     int has_bias = 0;                  // filled in by the launcher
 };
 bool ar_attn_fused_supported(int B, int G, int D, int H);

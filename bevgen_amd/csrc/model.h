@@ -42,7 +42,6 @@ struct MuseLayer {
     float* ff_w1_geglu = nullptr;   // split-precision mode: [2 Fpad, D] rows ordered for the fused GEGLU epilogue (owned)
     // LayerNorm folded into the GEMMs (split-precision mode, GemmArgs::ln_*): colsum[n] = sum_k gamma_k W[n,k] of every consumer projection, gamma of the
     // feed-forward's inner LayerNorm padded with zeros to Fpad (owned)
-    float *cs_q[2] = {nullptr, nullptr}, *cs_kv0 = nullptr, *cs_ff1 = nullptr, *cs_ff2 = nullptr, *ff_g3_pad = nullptr;
 };
 
 struct ArLayer {
@@ -168,7 +167,6 @@ struct Ctx {
     bool disable_graphs = false;
     // experiment switch ($BEVGEN_PREFETCH = 1 both MLP images, 2 the up-projection only): the decode attention kernels pull the layer's MLP weight images through L2
     // under the tail of their K/V walk.  Measured slower on the same box (1.55 -> 1.65 / 1.61 ms/step, profiles/r03_ab_prefetch.txt): default off
-    int prefetch_weights = getenv("BEVGEN_PREFETCH") ? atoi(getenv("BEVGEN_PREFETCH")) : 0;
     long long* trace = nullptr;   // diagnostics (bevgen_set_trace_buffer): phase timestamps of the fused decode kernels, [3 kinds][4096 workgroups][8]
     void retire_graph(hipGraphExec_t e, hipGraph_t g);  // destroyed once the stream has drained (next call or destroy)
 

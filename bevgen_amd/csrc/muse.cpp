@@ -23,7 +23,6 @@ struct MuseWs {
     float *img = nullptr, *c_embed = nullptr, *context = nullptr;
     std::vector<float*> crossK, crossV;
     float *x = nullptr, *xn = nullptr, *qraw = nullptr, *kvraw = nullptr, *Q = nullptr, *Ks = nullptr, *Vs = nullptr, *att = nullptr, *h = nullptr, *g = nullptr;
-    float *ln_part = nullptr, *ln_stats = nullptr;   // LayerNorm folded into the GEMMs: per-row group statistics written by the producer epilogues, merged (rstd, mean rstd)
     float* attn_ws = nullptr; int attn_ks = 1;   // key-split self-attention of the low-latency path (pick_attn_ksplit): partial rows of the key ranges
     float* kpart = nullptr;   // split-K partial tiles of the narrow (N = D) projections when the batch is too small to fill the chip (low-latency path)
 };
@@ -73,7 +72,6 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
     f += (size_t)2 * B * c.H * c.NkS_pad * 64;
     f += rows * 2 * c.F + rows * c.Fpad;
     f += rows * (c.V + 1);               // logits, scores (generate)
-    f += rows * (2 * (size_t)(c.Fpad / 32) + 2) + 64;   // LayerNorm group statistics + merged row statistics
     if (std::max(pick_ksplit((long)rows, c.D, c.D), pick_ksplit((long)rows, c.D, c.Fpad)) > 1) f += (size_t)KSPLIT_MAX * rows * c.D;
     {
         const int ks = pick_attn_ksplit((long)cdiv(c.N, 256) * c.H * B, c.NkS_pad / 32);
@@ -148,8 +146,6 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.Vs = a.get<float>(kvS);
     w.h = a.get<float>((size_t)w.rows * 2 * c.F);
     w.g = a.get<float>((size_t)w.rows * c.Fpad);
-    w.ln_part = a.get<float>((size_t)w.rows * 2 * (c.Fpad / 32));
-    w.ln_stats = a.get<float>((size_t)w.rows * 2);
     w.kpart = std::max(pick_ksplit(w.rows, D, D), pick_ksplit(w.rows, D, c.Fpad)) > 1 ? a.get<float>((size_t)KSPLIT_MAX * w.rows * D) : nullptr;
     w.attn_ks = pick_attn_ksplit((long)cdiv(c.N, 256) * H * B, c.NkS_pad / 32);
     w.attn_ws = w.attn_ks > 1 ? a.get<float>((size_t)attn_split_ws_floats(B, H, c.N, w.attn_ks)) : nullptr;
@@ -195,109 +191,11 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     }
 }
 
-// Split-precision mode at throughput batch sizes: every LayerNorm of the blocks is folded into the GEMMs around it (GemmArgs::ln_*).  The projection that
-// produces a residual-stream row also writes the (hi, lo) planes of (row * gamma_next) - the A operand of the next projection - and the row's group statistics in
-// its epilogue; ln_stats_merge turns them into (rstd, mean rstd); the consuming projection applies  LN(x) W^T = rstd (x gamma) W^T - rstd mean colsum  to its sums.
-// The four LayerNorm passes per layer (one read + one plane write of the activations each, 6.6 % of the step) are gone; what remains per LayerNorm is one extra
-// plane write in a GEMM epilogue and a row-statistics kernel over 3 MB.  Same tokens on every fixture (tests) - and measured SLOWER than the passes it removes
-// (see muse_blocks): an experiment kept behind $BEVGEN_LN_FOLD, not the default.
-void muse_blocks_folded(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s, bool fold_d) {
-    // fold_d: also the three D-wide LayerNorms of a layer (false: only the feed-forward's inner one; the others run as LayerNorm kernels writing normalised planes)
-    const auto& g = c.cfg;
-    const std::string p = "transformer.";
-    const int D = c.D, H = c.H, B = w.B, N = c.N;
-    const int rows = (int)w.rows;
-    launch_token_embed(ids, c.pf(p + "token_emb.weight"), w.img, c.pf(p + "pos_emb.weight"), w.x, B, N, D, g.vocab_size + 1, s);
-    if (fold_d) launch_ln_prep_planes(w.x, D, c.muse[0].norm_g[0], w.xn, D, w.ln_stats, rows, D, 1e-5f, s);   // rows no GEMM produced: layer 0's first LayerNorm
-    const size_t qN = (size_t)rows * D, kvS = (size_t)B * H * c.NkS_pad * 64, kvC = (size_t)(B / w.S) * H * c.NkC_pad * 64;
-    _Float16 *Qh = reinterpret_cast<_Float16*>(w.Q), *Ksh = reinterpret_cast<_Float16*>(w.Ks), *VTsh = reinterpret_cast<_Float16*>(w.Vs);
-    auto planes = [](const void* pl, GemmArgs& a) { a.A_hi = reinterpret_cast<const uint16_t*>(pl); a.A_lo = a.A_hi + 32; };
-    // residual-add projection x += A W^T that also emits the next LayerNorm's operand (planes of x * gamma into w.xn) and statistics
-    auto project_residual = [&](const void* A, int lda, const float* W, int K, const float* gamma_next, const float* stats_in, const float* colsum_in) {
-        GemmArgs a;
-        planes(A, a);
-        a.B = W; a.C = w.x; a.R = w.x;
-        a.M = rows; a.N = D; a.K = K; a.lda = lda; a.ldb = K; a.ldc = D; a.ldr = D;
-        a.ln_stats = stats_in; a.ln_colsum = colsum_in;
-        if (gamma_next && !fold_d) {   // the next LayerNorm runs as a kernel of its own
-            launch_gemm(a, s);
-            launch_layernorm_planes(w.x, D, gamma_next, nullptr, w.xn, D, rows, D, 1e-5f, s);
-            return;
-        }
-        if (gamma_next) { a.ln_gamma = gamma_next; a.ln_planes = w.xn; a.ln_ld = D; a.ln_part = w.ln_part; a.ln_ngroups = D / 64; a.ln_valid = D; }
-        launch_gemm(a, s);
-        if (gamma_next) launch_ln_stats_merge(w.ln_part, D / 64, 64, D, w.ln_stats, rows, 1e-5f, s);
-    };
-    auto project_q = [&](const float* W, const float* q_scale, const float* colsum) {
-        GemmArgs a;
-        planes(w.xn, a);
-        a.B = W;
-        a.M = rows; a.N = H * 64; a.K = D; a.lda = D; a.ldb = D; a.ldc = H * 64;
-        a.epi = EPI_MUSE_Q; a.epi_scale = q_scale; a.epi_hi = Qh; a.epi_lo = Qh + qN; a.epi_rows = N; a.epi_heads = H;
-        a.epi_post = 8.0f * kLog2e;
-        if (fold_d) { a.ln_stats = w.ln_stats; a.ln_colsum = colsum; }
-        launch_gemm(a, s);
-    };
-    for (int i = 0; i < g.num_layers; ++i) {
-        const MuseLayer& l = c.muse[i];
-        // ---- self attention (w.xn = planes of x * norm_g[0], w.ln_stats = its row statistics)
-        if (!fold_d && i == 0) launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
-        project_q(l.to_q[0], l.q_scale[0], l.cs_q[0]);
-        {
-            GemmArgs gk;
-            planes(w.xn, gk);
-            gk.B = l.to_kv[0];
-            gk.M = rows; gk.N = 2 * D; gk.K = D; gk.lda = D; gk.ldb = D; gk.ldc = 2 * D;
-            gk.epi = EPI_MUSE_KV; gk.epi_scale = l.k_scale[0]; gk.epi_hi = Ksh; gk.epi_lo = Ksh + kvS; gk.epi_hi2 = VTsh; gk.epi_lo2 = VTsh + kvS;
-            gk.epi_aux = l.null_self; gk.epi_rows = N; gk.epi_heads = H; gk.epi_ld = c.NkS_pad;
-            if (fold_d) { gk.ln_stats = w.ln_stats; gk.ln_colsum = l.cs_kv0; }
-            launch_gemm(gk, s);
-        }
-        AttnSplitArgs sa{};
-        sa.Qh = Qh; sa.Ql = Qh + qN; sa.Kh = Ksh; sa.Kl = Ksh + kvS; sa.VTh = VTsh; sa.VTl = VTsh + kvS;
-        sa.bias = c.bias_self; sa.bias_pk = c.bias_self_pk; sa.O = w.att; sa.B = B; sa.H = H; sa.Nq = N; sa.Nk_pad = c.NkS_pad;
-        sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f * kLog2e;
-        sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
-        sa.Op = reinterpret_cast<_Float16*>(w.att);
-        sa.ksplit = w.attn_ks; sa.kws = w.attn_ws;
-        launch_attention_split(sa, s);
-        sa.ksplit = 1; sa.kws = nullptr;   // (the cross-attention's 9 key tiles stay one range)
-        project_residual(w.att, D, l.to_out[0], D, l.norm_g[1], nullptr, nullptr);
-        // ---- cross attention
-        project_q(l.to_q[1], l.q_scale[1], l.cs_q[1]);
-        _Float16 *ckh = reinterpret_cast<_Float16*>(w.crossK[i]), *cvh = reinterpret_cast<_Float16*>(w.crossV[i]);
-        sa.Kh = ckh; sa.Kl = ckh + kvC; sa.VTh = cvh; sa.VTl = cvh + kvC;
-        sa.bias = c.bias_cross; sa.bias_pk = c.bias_cross_pk; sa.Nk_pad = c.NkC_pad; sa.ldbias = c.ldC;
-        sa.kv_group = w.S;
-        launch_attention_split(sa, s);
-        project_residual(w.att, D, l.to_out[1], D, l.ff_g0, nullptr, nullptr);
-        // ---- feed forward: up-projection (consumer of ff_g0's LayerNorm; GEGLU; producer of the inner LayerNorm's operand: planes of h * ff_g3 into w.g)
-        {
-            GemmArgs ge;
-            planes(w.xn, ge);
-            ge.B = l.ff_w1_geglu; ge.C = nullptr;
-            ge.M = rows; ge.N = 2 * c.Fpad; ge.K = D; ge.lda = D; ge.ldb = D; ge.ldc = c.Fpad;
-            ge.epi = EPI_GEGLU;
-            if (fold_d) { ge.ln_stats = w.ln_stats; ge.ln_colsum = l.cs_ff1; }
-            ge.ln_gamma = l.ff_g3_pad; ge.ln_planes = w.g; ge.ln_ld = c.Fpad; ge.ln_part = w.ln_part; ge.ln_ngroups = c.Fpad / 32; ge.ln_valid = c.F;
-            launch_gemm(ge, s);
-            launch_ln_stats_merge(w.ln_part, c.Fpad / 32, 32, c.F, w.ln_stats, rows, 1e-5f, s);
-        }
-        // down-projection: consumer of the inner LayerNorm, producer for the next layer's first LayerNorm
-        project_residual(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, i + 1 < g.num_layers ? c.muse[i + 1].norm_g[0] : nullptr, w.ln_stats, l.cs_ff2);
-    }
-    launch_layernorm(w.x, D, c.pf(p + "transformer_blocks.norm.gamma"), nullptr, w.xn, D, rows, D, 1e-5f, s);
-}
-
 // one transformer pass over the current ids: leaves LayerNorm(x) (= `embed`, muse_net:202) in w.xn
 void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
     const auto& g = c.cfg;
-    // $BEVGEN_LN_FOLD = 1: every LayerNorm of the blocks folded into the GEMMs around it, 2: only the feed-forward's inner one.  Token-exact on the full-size
-    // goldens (tests) but SLOWER than the LayerNorm kernels it replaces (same box: 10.12 -> 9.86 / 9.95 scenes/s, profiles/r03_ab_ln_fold.txt): the extra epilogue
-    // work (plane stores, group statistics, colsum fix-up) runs at one workgroup per CU with nothing to hide behind, the LayerNorm kernels run at HBM rate.  Default off
-    const char* fold_env = getenv("BEVGEN_LN_FOLD");
-    const bool can_fold = g.precision == BEVGEN_PRECISION_F16X3 && c.muse[0].ff_w1_geglu;
-    if (can_fold && fold_env && (fold_env[0] == '1' || fold_env[0] == '2')) return muse_blocks_folded(c, w, ids, s, fold_env[0] == '1');
+    // (LayerNorm folded into the GEMMs around it was built in round 3, token-exact, and measured slower than the LayerNorm kernels it replaces - 10.12 -> 9.86 scenes/s,
+    // profiles/r03_ab_ln_fold.txt, EXPERIMENTS.md; the code path was removed in round 4)
     const std::string p = "transformer.";
     const int D = c.D, H = c.H, B = w.B, N = c.N;
     const int rows = (int)w.rows;

@@ -123,94 +123,6 @@ void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const 
     LAUNCH_CHECK();
 }
 
-// ------------------------------------------------------------------------------------------------ LayerNorm folded into the surrounding GEMMs (GemmArgs::ln_*)
-// Standalone producer for rows that no GEMM produced (Route M: the token embedding in front of layer 0): planes of (x * gamma) + (rstd, mean * rstd) per row.
-// D a multiple of 4, one wave per row, two-pass statistics in registers.
-__global__ __launch_bounds__(256) void ln_prep_planes_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, _Float16* __restrict__ planes, int ldy,
-                                                             float* __restrict__ stats, int rows, int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
-    const int nv = D >> 2;
-    float4 v[LN_MAXV];
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        const int i = lane + 64 * j;
-        v[j] = i < nv ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        if (lane + 64 * j < nv) {
-            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (long)row) = make_float2(rstd, mean * rstd);
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    _Float16* prow = planes + (long)row * 2 * ldy;
-#pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < nv) {
-            const float4 g = g4[i];
-            store_planes4(prow, 4 * i, make_float4(v[j].x * g.x, v[j].y * g.y, v[j].z * g.z, v[j].w * g.w));
-        } else if (i < (ldy >> 2)) {
-            store_planes4(prow, 4 * i, make_float4(0.f, 0.f, 0.f, 0.f));
-        }
-    }
-}
-void launch_ln_prep_planes(const float* x, int ldx, const float* gamma, void* planes, int ldy, float* stats, int rows, int D, float eps, hipStream_t s) {
-    if (rows <= 0) return;
-    BG_REQUIRE(D % 4 == 0 && ldx % 4 == 0 && ldx >= D && ldy % 32 == 0 && ldy >= D && ldy <= 256 * LN_MAXV, "ln_prep_planes: unsupported shape D=%d ldx=%d ldy=%d", D, ldx, ldy);
-    hipLaunchKernelGGL(ln_prep_planes_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, reinterpret_cast<_Float16*>(planes), ldy, stats, rows, D, eps);
-    LAUNCH_CHECK();
-}
-
-// (mean, M2) of the column groups of a row (written by the producer GEMM's epilogue) -> (rstd, mean * rstd): Chan's pairwise update in group order - as accurate as
-// a two-pass computation over the row, and deterministic.  Group g covers columns [g * group, (g + 1) * group) intersected with [0, valid).
-__global__ __launch_bounds__(256) void ln_stats_merge_kernel(const float* __restrict__ part, int ngroups, int group, int valid, float* __restrict__ stats, int rows, float eps) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const float2* p = reinterpret_cast<const float2*>(part) + (long)row * ngroups;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int g = 0; g < ngroups; ++g) {
-        const int cnt = min(group, valid - g * group);
-        if (cnt <= 0) break;
-        const float2 v = p[g];
-        const float nb = (float)cnt, tot = n + nb, delta = v.x - mean;
-        mean += delta * (nb / tot);
-        m2 += v.y + delta * delta * (n * nb / tot);
-        n = tot;
-    }
-    const float rstd = rsqrtf(m2 / n + eps);
-    *reinterpret_cast<float2*>(stats + 2 * (long)row) = make_float2(rstd, mean * rstd);
-}
-void launch_ln_stats_merge(const float* part, int ngroups, int group, int valid, float* stats, int rows, float eps, hipStream_t s) {
-    if (rows <= 0) return;
-    hipLaunchKernelGGL(ln_stats_merge_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, part, ngroups, group, valid, stats, rows, eps);
-    LAUNCH_CHECK();
-}
-
-// colsum[n] = sum_k gamma[k] W[n, k] (fp64 accumulation; setup time): the constant that carries the LayerNorm mean through the consumer GEMM
-__global__ __launch_bounds__(64) void ln_colsum_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ gamma, float* __restrict__ colsum, int N, int K) {
-    const int n = blockIdx.x, lane = threadIdx.x;
-    double a = 0.0;
-    for (int k = lane; k < K; k += 64) a += (double)gamma[k] * (double)W[(long)n * ldw + k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (lane == 0) colsum[n] = (float)a;
-}
-void launch_ln_colsum(const float* W, int ldw, const float* gamma, float* colsum, int N, int K, hipStream_t s) {
-    hipLaunchKernelGGL(ln_colsum_kernel, dim3(N), dim3(64), 0, s, W, ldw, gamma, colsum, N, K);
-    LAUNCH_CHECK();
-}
-
 // ------------------------------------------------------------------------------------------------ GEGLU + LayerNorm
 constexpr int GEGLU_MAX_PER_LANE = 48;  // F <= 3072
 
