@@ -687,6 +687,8 @@ def main():
             # SURVEY 8(d) config 4 variant: density 0.35, every layer with its own random per-head block layouts - the key walk follows the chunk lists of present blocks
             d35 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", density=0.35)
             line["decode_density_035_f16_kv_cache"] = {k: d35[k] for k in dkeys}
+            d35h = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16", density=0.35)
+            line["decode_density_035_f16_kv_cache_f16_weights"] = {k: d35h[k] for k in dkeys}
             # the four-launch form: the decode-attention kernel proper (K/V stream only) with the projection as its own MFMA kernel, reported for its attention-kernel roofline
             sp = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16", path="split")
             line["decode_split_path_f16_kv_cache_f16_weights"] = {k: sp[k] for k in dkeys}
@@ -752,7 +754,7 @@ def main():
         legs["f16_weights"] = {"scenes_per_s": rnd(detail["f16_weights_mode"]["value"], 3), "gemm_frac": rnd(detail["f16_weights_mode"]["roofline"]["frac"], 3)}
     if "ms_per_decode_step" in detail:
         legs["decode_config4_B16"] = {"f32_kv": dshort(detail), "prefill_ms": rnd(detail["decode_prefill_ms"], 2)}
-        for name, key in (("f16_kv", "decode_f16_kv_cache"), ("f16_kv_f16_w", "decode_f16_kv_cache_f16_weights"), ("density035_f16_kv", "decode_density_035_f16_kv_cache"),
+        for name, key in (("f16_kv", "decode_f16_kv_cache"), ("f16_kv_f16_w", "decode_f16_kv_cache_f16_weights"), ("density035_f16_kv", "decode_density_035_f16_kv_cache"), ("density035_f16_kv_f16_w", "decode_density_035_f16_kv_cache_f16_weights"),
                           ("split_path_f16_kv_f16_w", "decode_split_path_f16_kv_cache_f16_weights")):
             if key in detail:
                 legs["decode_config4_B16"][name] = dshort(detail[key])

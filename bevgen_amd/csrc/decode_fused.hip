@@ -198,12 +198,21 @@ struct Attend {
     // st + (2 U j + u) KiB (K) / st + (2 U j + U + u) KiB (V), st = the wave's region + lane * 16.  The pieces were requested by LDS-DMA earlier; the walk opens by requesting
     // its first TWO global steps - they queue behind the pieces in the CU's in-order memory pipeline and keep HBM busy - then waits until only those are outstanding (every
     // piece has landed: loads return in issue order), scores the staged steps out of LDS, and continues with the global steps already in flight: no cold start.
-    template <int NSLOTS>
+    // LIST: the same for the chunk-list walk (block-sparse layouts): step j of wave `slot` = the 16 keys of chunk list_s[slot + j NSLOTS] (one chunk per step: SPC == 1),
+    // positions [0, hi); the staged steps are this wave's leading WHOLE chunks below the new key.
+    template <int NSLOTS, bool LIST = false>
     __device__ static __forceinline__ void run_staged(const void* kc, const void* vc, long row0, int slot, int kslot, int k_end, int sub, const float* bias_s, const char* st, int js,
-                                                      const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL]) {
-        constexpr int USTRIDE = NSLOTS * KPI, SPAN = U * NSLOTS * KPI;
-        const int steps = k_end > 0 ? (k_end + SPAN - 1) / SPAN : 0;   // js <= steps: staged steps are whole steps below k_end
-        auto key_of = [&](int j) { return j * SPAN + slot * KPI + kslot; };
+                                                      const float (&q)[NQ][DPL], float (&m)[NQ], float (&l)[NQ], float (&acc)[NQ][DPL], const uint16_t* list_s = nullptr,
+                                                      int hi = 0) {
+        static_assert(!LIST || SPC == 1, "the staged chunk-list walk takes one chunk per pipeline step");
+        constexpr int USTRIDE = LIST ? KPI : NSLOTS * KPI, SPAN = U * NSLOTS * KPI;
+        int steps;
+        if (LIST) steps = hi - slot > 0 ? (hi - slot + NSLOTS - 1) / NSLOTS : 0;
+        else steps = k_end > 0 ? (k_end + SPAN - 1) / SPAN : 0;   // js <= steps: staged steps are whole steps below k_end
+        auto key_of = [&](int j) {
+            if (LIST) return 16 * (int)list_s[slot + j * NSLOTS] + kslot;
+            return j * SPAN + slot * KPI + kslot;
+        };
         Buf b0, b1;
         if (js + 1 < steps) {
             load<USTRIDE>(b0, kc, vc, row0, key_of(js), k_end, sub);
@@ -262,11 +271,11 @@ template <int DT, int G> struct WalkU { static constexpr int value = (G == 1 && 
 // Second half of both attention kernels: this step's k / v rows (qkv_s, LDS) go into the cache, the walk over the visible 16-key chunks, the merge of the
 // 16 waves, + residual (res_s[g * ldres + d], LDS) -> out.  Called by every thread of the workgroup after a barrier that made qkv_s / bias_s / the list visible.
 // SP: the walk follows a chunk list (block-sparse layout); false = the dense interleaved walk with every stride a constant.
-// STG (G = 1, dense): the walk opens with `js` steps staged in LDS at `st` (Attend::run_staged)
+// STG (G = 1): the walk opens with `js` steps staged in LDS at `st` (Attend::run_staged)
 template <int DT, int G, bool SP, bool STG = false>
 __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a, const float* bias_s, const float* qkv_s, float* red, const uint16_t* walk, int n_pos, int p_pos,
                                                        int n, int head, int b0, const float* res_s, int ldres, const char* st = nullptr, int js = 0) {
-    static_assert(!STG || (G == 1 && !SP), "staged steps are defined on the dense walk of one sequence");
+    static_assert(!STG || G == 1, "staged steps are defined on the walk of one sequence");
     using T = KvRow<DT>;
     constexpr int LPK = T::LPK, DPL = T::DPL, NW = AF_WAVES, TW = NW / G;
     constexpr int U = WalkU<DT, G>::value;
@@ -302,7 +311,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
         const int p_lo = (int)((long)kz * n_pos / ksl), p_hi = (int)((long)(kz + 1) * n_pos / ksl);
         // (the dense walk strides over whole 256-key spans: its end must be clipped to this share's last key, or the next share's keys are counted twice)
         const int k_hi = SP ? n_old : min(n_old, 16 * p_hi);
-        if (STG) Attend<DT, 1, U>::template run_staged<NW>(a.kcache, a.vcache, row0, wave, kslot, k_hi, sub, bias_s, st, js, q, m, l, acc);
+        if constexpr (STG) Attend<DT, 1, U>::template run_staged<NW, SP>(a.kcache, a.vcache, row0, wave, kslot, k_hi, sub, bias_s, st, js, q, m, l, acc, walk, p_hi);
         else Attend<DT, 1, U>::template run_as<SP, NW>(a.kcache, a.vcache, row0, walk, p_lo, p_hi, wave, kslot, k_hi, sub, bias_s, q, m, l, acc);
         wave_merge<LPK, DPL>(m[0], l[0], acc[0]);
         if (kslot == 0) {
@@ -427,19 +436,34 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     // pipeline steps of ITS OWN share of the key walk - U K pieces + U V pieces of 1 KiB per step - by LDS-DMA into its region behind the sink, and the walk reads them
     // from there (Attend::run_staged).  HBM has nothing else to do for the 13 us of the prologue; the 128 KB the CU's 160 KB of LDS leave free are 40 % of a
     // (sequence, head)'s fp16 K/V rows at the mean context of a decode.
-    constexpr bool STG = G == 1 && !SP;
+    constexpr bool STG = G == 1;
     using TS = KvRow<DT>;
     constexpr int KPI = 64 / TS::LPK, PIECE = NW * KPI, SU = WalkU<DT, G>::value, ROWB = 64 * (DT ? 2 : 4);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char* st_w = stage + (wave_u * a.stage_cap) * 1024;   // this wave's region
-    const int js = STG && a.stage_cap > 0 ? min(((n - 1) / PIECE) / SU, a.stage_cap / (2 * SU)) : 0;   // staged steps: whole steps of rows in the cache at kernel start
+    // staged steps of this wave.  Dense walk: whole pipeline steps of rows that are in the cache at kernel start.  Chunk-list walk (SP): its leading list positions
+    // wave, wave + 16, ... whose chunks lie WHOLLY below the new key - lane j holds the chunk of the wave's j-th position (one extra row load with the kernel's first)
+    int js = 0, cid_lane = 0;
+    if (STG && a.stage_cap > 0) {
+        if (SP) {
+            const SparseVis& v0 = a.vis;
+            const uint16_t* crow = v0.chunks + (long)head * v0.chunks_head_stride + (long)(row / v0.blk) * v0.chunks_ld;
+            const int total = crow[0], pos = wave_u + NW * lane;
+            cid_lane = crow[1 + min(pos, max(v0.chunks_ld - 2, 0))];
+            const bool ok = pos < total && 16 * cid_lane + 16 <= n - 1 && lane < a.stage_cap / (2 * SU);
+            js = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok));   // (ascending list: the staged positions are a prefix)
+        } else {
+            js = min(((n - 1) / PIECE) / SU, a.stage_cap / (2 * SU));
+        }
+    }
     int q_iss = 0;
     auto stage_issue = [&](int count) {   // request the next `count` pieces in LDS order (step-major: K pieces of the step, then its V pieces)
-        const long wrow = (((long)b0 * a.H + head) * a.Lmax + wave_u * KPI) * ROWB + lane * 16;
+        const long wrow = (((long)b0 * a.H + head) * a.Lmax + (SP ? 0 : wave_u * KPI)) * ROWB + lane * 16;
         const int hi = min(q_iss + count, js * 2 * SU);
         for (; q_iss < hi; ++q_iss) {
             const int j = q_iss / (2 * SU), r = q_iss % (2 * SU);
-            const char* src = reinterpret_cast<const char*>(r >= SU ? a.vcache : a.kcache) + wrow + (long)(j * SU + r % SU) * (PIECE * ROWB);
+            const long koff = SP ? (long)(16 * __builtin_amdgcn_readlane(cid_lane, j) + (r % SU) * KPI) * ROWB : (long)(j * SU + r % SU) * (PIECE * ROWB);
+            const char* src = reinterpret_cast<const char*>(r >= SU ? a.vcache : a.kcache) + wrow + koff;
             glds16_hidden(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(st_w + q_iss * 1024)));
         }
     };
@@ -809,12 +833,11 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
     // K/V staging (fused kernel, G = 1, dense walk): what the CU's LDS has left beyond the kernel's own 24 KB, in whole pipeline steps per wave (gfx950: 160 KB per
     // workgroup -> 8 pieces per wave = 128 KB).  $BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override the launcher's choice (A/B switches; 0 = off)
-    const bool sp_walk = a.vis.has_chunks;
-    if (!pre && a.G == 1 && !sp_walk) {
+    if (!pre && a.G == 1) {
         static const int env_cap = getenv("BEVGEN_KV_STAGE") ? atoi(getenv("BEVGEN_KV_STAGE")) : -1;
         static const int env_top = getenv("BEVGEN_KV_STAGE_TOP") ? atoi(getenv("BEVGEN_KV_STAGE_TOP")) : -1;
         const int step_pieces = 2 * (a.kv_dtype == 0 ? 4 : 2);   // K + V pieces of one pipeline step (WalkU)
-        const int room = (int)((ar_attn_fused_max_lds() - lds) / (AF_WAVES * 1024));
+        const int room = (int)((ar_attn_fused_max_lds() - 1024 - lds) / (AF_WAVES * 1024));   // (1 KiB kept back: the block-sparse variants hold 256 B of static LDS)
         int cap = a.stage_cap >= 0 ? a.stage_cap : (env_cap >= 0 ? env_cap : 8);
         cap = std::max(0, std::min(cap, room)) / step_pieces * step_pieces;
         a.stage_cap = cap;
@@ -834,7 +857,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     const bool sp = a.vis.has_chunks;
     BG_REQUIRE(sp || !a.vis.has_lay, "fused decode attention: a block layout needs its chunk lists");
     // (more than 64 KB of dynamic LDS has to be allowed per kernel function, once)
-#define AF_LAUNCH1(K) do { static bool big = false; if (lds > 64 * 1024 && !big) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ar_attn_fused_max_lds())); big = true; } \
+#define AF_LAUNCH1(K) do { static bool big = false; if (lds > 64 * 1024 && !big) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ar_attn_fused_max_lds() - 1024)); big = true; } \
                            hipLaunchKernelGGL(K, grid, dim3(1024), lds, s, a); } while (0)
 #define AF_LAUNCH(DT, GG, WW) do { if (sp) AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, true>)); else AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, false>)); } while (0)
 #define AF_LAUNCH_G(DT, WW) do { if (a.G == 1) AF_LAUNCH(DT, 1, WW); else if (a.G == 2) AF_LAUNCH(DT, 2, WW); else AF_LAUNCH(DT, 4, WW); } while (0)
