@@ -399,8 +399,6 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
         a.B = B; a.G = G; a.H = H; a.D = D; a.Lmax = Lmax; a.n = n; a.prefix = prefix; a.scale = 0.125f;
         a.trace = ctx->trace;
         if (split == -1) { a.stage_cap = 0; split = 0; }                       // the fused kernel without K/V pieces staged in LDS
-        else if (split == -2) { a.stage_top = 0; split = 0; }                  // every staged piece requested between the projection's row batches
-        else if (split == -3) { a.stage_top = 1 << 20; split = 0; }            // every staged piece requested when the x rows have arrived
         if (split) {
             BG_REQUIRE(skinny_fused_supported(B, 3 * D, D, true) && (!w_f16 || skinny_fused_f16_ok(3 * D, D, true)), "op_ar_attn_fused: the split form does not support B=%d D=%d", B, D);
             float* wp = ctx->arena.get<float>(skinny_packed_floats(3 * D, D));

@@ -456,11 +456,9 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
             js = min(((n - 1) / PIECE) / SU, a.stage_cap / (2 * SU));
         }
     }
-    int q_iss = 0;
-    auto stage_issue = [&](int count) {   // request the next `count` pieces in LDS order (step-major: K pieces of the step, then its V pieces)
+    auto stage_issue = [&]() {   // request the pieces in LDS order (step-major: K pieces of the step, then its V pieces)
         const long wrow = (((long)b0 * a.H + head) * a.Lmax + (SP ? 0 : wave_u * KPI)) * ROWB + lane * 16;
-        const int hi = min(q_iss + count, js * 2 * SU);
-        for (; q_iss < hi; ++q_iss) {
+        for (int q_iss = 0; q_iss < js * 2 * SU; ++q_iss) {
             const int j = q_iss / (2 * SU), r = q_iss % (2 * SU);
             const long koff = SP ? (long)(16 * __builtin_amdgcn_readlane(cid_lane, j) + (r % SU) * KPI) * ROWB : (long)(j * SU + r % SU) * (PIECE * ROWB);
             const char* src = reinterpret_cast<const char*>(r >= SU ? a.vcache : a.kcache) + wrow + koff;
@@ -568,13 +566,6 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         // (the projection took 8 us with fp32 and with fp16 weights alike)
         c_mine = (FOLD ? a.ln_cs : a.bqkv)[(long)(jb >> 6) * D + head * 64 + (jb & 63)];   // (direct form: the row's bias)
         d_mine = FOLD ? a.ln_ds[(long)(jb >> 6) * D + head * 64 + (jb & 63)] : 0.f;
-        // ... and behind them the first `stage_top` K/V pieces; the others go out in equal shares behind each row batch of the projection.  What was measured (MI355X,
-        // same-box A/Bs, profiles/r04_ab_kv_stage.txt): the CU returns loads in issue order across its waves and a wave blocks at a VMEM instruction while the
-        // CU's request queue is full, so (a) pieces requested BEFORE the x rows delay them from 1.6 to 6.3 us; (b) a single 128 KB burst here holds every wave at its
-        // request instructions for ~5 us (HBM feeds one CU 25 GB/s): the walk 5 us shorter, the prologue 3 us longer; (c) two row batches deep in registers in front
-        // of the burst keep the multipliers busy while it drains; (d) with fp16 weights (4 rows per batch, 3 batches; ln1 folded) every piece behind the row batches
-        // is best: 1.040 vs 1.050 (two here) vs 1.062 (four here) vs 1.110 ms/step without staging; with fp32 weights (6 batches) all-early wins, 1.204 vs 1.225 vs 1.241.
-        if (STG) stage_issue(a.stage_top);
         // second statistics pass.  Folded form: in the shadow of the weight loads, read by the fix-up behind the row loop's closing barrier.  Direct form: two more
         // barrier rounds, then the normalised row goes to LDS
         float mean[G];
@@ -651,20 +642,25 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
                 }
             }
         };
-        // pieces not requested when the rows arrived: an equal share behind each row batch (per row instead of per batch: no different, 1.064-1.071 vs 1.059-1.061 ms/step)
-        const int per = STG ? (js * 2 * SU - q_iss + NB - 1) / NB : 0;
+
 #pragma unroll
         for (int bi = 0; bi < NB; bi += 2) {
             if (!PRE2 && bi + 1 < NB) load_batch(bi + 1, wb[1]);
             dot_batch(bi, wb[0]);
             if (bi + 2 < NB) load_batch(bi + 2, wb[0]);
-            if (STG) stage_issue(per);
             if (bi + 1 < NB) {
                 dot_batch(bi + 1, wb[1]);
                 if (PRE2 && bi + 3 < NB) load_batch(bi + 3, wb[1]);
-                if (STG) stage_issue(per);
             }
         }
+        // The staged K/V pieces are requested HERE, behind the last product of the projection.  What was measured about the placement (MI355X, same-box A/Bs,
+        // profiles/r04_ab_kv_stage.txt): the CU returns loads in issue order across its waves and a wave blocks at a VMEM instruction while the CU's request queue is
+        // full, so (a) pieces requested before the x rows delay them from 1.6 to 6.3 us; (b) one 128 KB burst when the rows have arrived holds every wave at its request
+        // instructions for ~5 us (HBM feeds one CU 25 GB/s): the walk 5 us shorter, the prologue 3 us longer; (c) pieces between the row batches: the batch requested
+        // before them is waited for with vmcnt(0) - the compiler does not count hidden requests - and so waits for them.  Requested here nothing waits on them but the
+        // walk, whose own first loads queue behind them: HBM streams without a gap from the end of the projection on.  ms/step, fp16 cache: fp16 weights 1.029-1.034
+        // (between batches 1.031-1.036, all early 1.070, no staging 1.110); fp32 weights 1.197-1.204 (1.225 / 1.203 / 1.241); density 0.35: 0.953 (0.962 / 0.999 / 1.017).
+        if (STG) stage_issue();
         if (!FOLD) {
             if (lane < 12) {   // this wave's rows (its own LDS stores above: in order)
 #pragma unroll
@@ -832,19 +828,17 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     size_t lds = pre ? ar_attn_lds_bytes(a.G, a.Lpad) : ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad);
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
     // K/V staging (fused kernel, G = 1, dense walk): what the CU's LDS has left beyond the kernel's own 24 KB, in whole pipeline steps per wave (gfx950: 160 KB per
-    // workgroup -> 8 pieces per wave = 128 KB).  $BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override the launcher's choice (A/B switches; 0 = off)
+    // workgroup -> 8 pieces per wave = 128 KB).  $BEVGEN_KV_STAGE overrides the launcher's choice (A/B switch; 0 = off)
     if (!pre && a.G == 1) {
         static const int env_cap = getenv("BEVGEN_KV_STAGE") ? atoi(getenv("BEVGEN_KV_STAGE")) : -1;
-        static const int env_top = getenv("BEVGEN_KV_STAGE_TOP") ? atoi(getenv("BEVGEN_KV_STAGE_TOP")) : -1;
         const int step_pieces = 2 * (a.kv_dtype == 0 ? 4 : 2);   // K + V pieces of one pipeline step (WalkU)
         const int room = (int)((ar_attn_fused_max_lds() - 1024 - lds) / (AF_WAVES * 1024));   // (1 KiB kept back: the block-sparse variants hold 256 B of static LDS)
         int cap = a.stage_cap >= 0 ? a.stage_cap : (env_cap >= 0 ? env_cap : 8);
         cap = std::max(0, std::min(cap, room)) / step_pieces * step_pieces;
         a.stage_cap = cap;
-        a.stage_top = a.stage_top >= 0 ? a.stage_top : (env_top >= 0 ? env_top : (a.wqkv_h ? 0 : cap));
         lds += (size_t)cap * AF_WAVES * 1024;
     } else {
-        a.stage_cap = a.stage_top = 0;
+        a.stage_cap = 0;
     }
     BG_REQUIRE(a.ksplit >= 1 && (a.ksplit == 1 || (pre && a.G == 1 && a.kws)), "decode attention: a key split needs the attention-only kernel, one sequence per workgroup and a workspace");
     dim3 grid(a.H, a.B / a.G, a.ksplit);

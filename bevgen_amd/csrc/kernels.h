@@ -243,11 +243,11 @@ struct ArAttnFusedArgs {
     // list positions and leaves (max, sum, unnormalised output[64]) in kws [B][H][ksplit][66]; launch_ar_attn_fused then runs the combine kernel (+ residual)
     int ksplit = 1;
     float* kws = nullptr;
-    // K/V rows staged in LDS while the prologue runs (fused kernel, one sequence per workgroup; dense walk or chunk-list walk): every wave requests the leading whole pipeline steps of ITS OWN
-    // share of the key walk - `stage_cap` 1 KiB pieces, K and V of a step together - by LDS-DMA while it computes ln1 and the projection, when HBM has nothing else to
-    // do; the walk reads those steps from LDS and the rest from HBM.  stage_top of the pieces are requested when the x rows have arrived, the others in equal shares behind
-    // the projection's row batches.  -1 = the launcher's choice ($BEVGEN_KV_STAGE / $BEVGEN_KV_STAGE_TOP override), 0 = off
-    int stage_cap = -1, stage_top = -1;
+    // K/V rows staged in LDS (fused kernel, one sequence per workgroup; dense walk or chunk-list walk): every wave requests the leading whole pipeline steps of ITS OWN
+    // share of the key walk - `stage_cap` 1 KiB pieces, K and V of a step together - by LDS-DMA behind the last product of the projection: a deep, register-free
+    // prefetch that starts as early as the CU's in-order memory pipeline allows without stalling the projection; the walk reads those steps from LDS and the rest
+    // from HBM.  -1 = the launcher's choice ($BEVGEN_KV_STAGE overrides), 0 = off
+    int stage_cap = -1;
     int has_bias = 0;                  // filled in by the launcher
 };
 bool ar_attn_fused_supported(int B, int G, int D, int H);

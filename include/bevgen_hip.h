@@ -252,8 +252,7 @@ int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* d_q, const void* d_
  * Visibility as the reference defines it: d_attn_mask [L, L] fp32 (0 = hidden) AND d_layout int64 [H, L/block, L/block] (0 = block absent, never read);
  * either may be NULL.  G > 1: consecutive groups of G sequences share their first `prefix` keys, read from the group's first cache slot.
  * kv_dtype 0 fp32 / 1 fp16 cache [B, H, Lmax, 64]; w_f16 != 0: the projection weights are rounded to fp16 and streamed as 2-byte values.
- * split = 0: the fused kernel as the sampling path launches it (G = 1 and a dense walk: leading K/V steps staged in LDS by LDS-DMA during the prologue);
- * split = -1: without staged pieces; -2 / -3: every staged piece requested between the projection's row batches / when the x rows have arrived.
+ * split = 0: the fused kernel as the sampling path launches it (G = 1: leading K/V steps of the key walk staged in LDS by LDS-DMA); split = -1: without staged pieces.
  * split > 0: the BEVGEN_DECODE_SPLIT form of the same computation (LayerNorm + QKV projection kernel, then the attention-only kernel); split = k > 1: with the
  * key walk of every (sequence, head) cut into k ranges on k workgroups and merged by the combine kernel (what one- and two-sequence calls run; G = 1). */
 int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* d_x, const float* d_partial, int ns, const float* d_rbias, const float* d_ln_w, const float* d_ln_b,
