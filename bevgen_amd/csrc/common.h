@@ -101,6 +101,22 @@ __device__ __forceinline__ float xor32(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
+// value held by lane ^ 16, same idea: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other
+__device__ __forceinline__ float xor16(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+// a + (a of lane ^ 32) in lanes 0..31 and c + (c of lane ^ 32) in lanes 32..63: ONE swap folds two values over the wave halves
+__device__ __forceinline__ float fold32(float a, float c) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(c), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the same over neighbouring 16-lane rows: a's sum in the even rows, b's in the odd rows
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -92,8 +92,19 @@ __device__ __forceinline__ float lane_group_sum(float d) {
 }
 __device__ __forceinline__ float wave_sum_dpp(float d) {
     d = lane_group_sum<16>(d);
-    d += __shfl_xor(d, 16, 64);
+    d += xor16(d);
     return d + xor32(d);
+}
+// Wave sums of FOUR per-lane values for the price of one and a half: the two cross-half / cross-row steps each fold two values into one register (fold32 / fold16),
+// the four in-row steps then run once.  Lane L ends with the total of v[2 bit5(L) + bit4(L)] (every lane of a 16-lane row holds it).
+__device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v3) {
+    return lane_group_sum<16>(fold16(fold32(v0, v2), fold32(v1, v3)));
+}
+// two values: lane L ends with the total of v[bit5(L)]
+__device__ __forceinline__ float wave_sum2(float v0, float v1) {
+    float t = fold32(v0, v1);
+    t += xor16(t);
+    return lane_group_sum<16>(t);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every global load / LDS-DMA a wave has in flight must land before it passes - in
@@ -612,11 +623,11 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     // ---- q/k/v projection of this head (folded form: on x o gamma)
     {
         auto dot_batch = [&](int bi, const WV (&w)[RB][NCH]) {
+            float accp[RB][G];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
-                float accp[G];
 #pragma unroll
-                for (int g = 0; g < G; ++g) accp[g] = 0.f;
+                for (int g = 0; g < G; ++g) accp[r][g] = 0.f;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int col = c * 64 * EL + lane * EL;
@@ -626,19 +637,40 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
                             for (int e4 = 0; e4 < EL; e4 += 4) {
                                 const float4 x4 = *reinterpret_cast<const float4*>(xn_s + g * D + col + e4);
-                                accp[g] = fmaf((float)w[r][c][e4 + 0], x4.x, accp[g]);
-                                accp[g] = fmaf((float)w[r][c][e4 + 1], x4.y, accp[g]);
-                                accp[g] = fmaf((float)w[r][c][e4 + 2], x4.z, accp[g]);
-                                accp[g] = fmaf((float)w[r][c][e4 + 3], x4.w, accp[g]);
+                                accp[r][g] = fmaf((float)w[r][c][e4 + 0], x4.x, accp[r][g]);
+                                accp[r][g] = fmaf((float)w[r][c][e4 + 1], x4.y, accp[r][g]);
+                                accp[r][g] = fmaf((float)w[r][c][e4 + 2], x4.z, accp[r][g]);
+                                accp[r][g] = fmaf((float)w[r][c][e4 + 3], x4.w, accp[r][g]);
                             }
                         }
                     }
                 }
-                const int j = wrow(bi, r);
+            }
+            // the RB x G wave sums of the batch, four (or two) per reduction pass; the lane a total lands in stores it (raw sum: fixed up below)
+            const int sel = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
+            if constexpr (RB == 4) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const float t = wave_sum_dpp(accp[g]);
-                    if (lane == 0) qkv_s[g * 192 + j] = t;   // (raw sum: fixed up below)
+                    const float t = wave_sum4(accp[0][g], accp[1][g], accp[2][g], accp[3][g]);
+                    if ((lane & 15) == 0) qkv_s[g * 192 + wrow(bi, sel)] = t;
+                }
+            } else if constexpr (RB == 2) {
+#pragma unroll
+                for (int g = 0; g < G; g += 2) {
+                    if (g + 1 < G) {   // rows x two sequences
+                        const float t = wave_sum4(accp[0][g], accp[1][g], accp[0][g + 1], accp[1][g + 1]);
+                        if ((lane & 15) == 0) qkv_s[(g + (sel >> 1)) * 192 + wrow(bi, sel & 1)] = t;
+                    } else {
+                        const float t = wave_sum2(accp[0][g], accp[1][g]);
+                        if ((lane & 31) == 0) qkv_s[g * 192 + wrow(bi, lane >> 5)] = t;
+                    }
+                }
+            } else {
+                static_assert(RB == 1 && G % 4 == 0, "one row per batch: four sequences per reduction pass");
+#pragma unroll
+                for (int g = 0; g < G; g += 4) {
+                    const float t = wave_sum4(accp[0][g], accp[0][g + 1], accp[0][g + 2], accp[0][g + 3]);
+                    if ((lane & 15) == 0) qkv_s[(g + sel) * 192 + wrow(bi, 0)] = t;
                 }
             }
         };
