@@ -263,13 +263,20 @@ int bevgen_op_ln_gemm(bevgen_ctx* ctx, const float* a, const float* ln_w, const 
         BG_REQUIRE(skinny_fused_supported(M, N, K, ln_w != nullptr), "op_ln_gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
         SkinnyFusedArgs g;
         g.A = a; g.lda = K; g.ln_w = ln_w; g.ln_b = ln_b; g.eps = eps;
-        ctx->arena.reserve(skinny_packed_floats(N, K) * sizeof(float) + 4096);
+        ctx->arena.reserve((skinny_packed_floats(N, K) + 2 * (size_t)N) * sizeof(float) + 8192);
         ctx->arena.reset();
         float* wp = ctx->arena.get<float>(skinny_packed_floats(N, K));
         launch_pack_skinny_weight(w, wp, N, K, (hipStream_t)stream);
         g.Wp = wp; g.bias = bias; g.C = c; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.act = act_gelu ? ACT_GELU : ACT_NONE;
         g.ksplit = ksplit > 0 ? ksplit : (ln_w ? 1 : skinny_fused_ksplit(N, K));
+        if (ksplit == -1) {   // the form the decode step launches for ln2 + MLP-up: LayerNorm folded into the product, row constants from launch_ar_ln_fold
+            BG_REQUIRE(ln_w && ln_b && bias, "op_ln_gemm: ksplit = -1 (folded LayerNorm) needs gamma, beta and a bias");
+            float* cs = ctx->arena.get<float>((size_t)N);
+            float* ds = ctx->arena.get<float>((size_t)N);
+            launch_ar_ln_fold(w, bias, ln_w, ln_b, cs, ds, N, K, (hipStream_t)stream);
+            g.ln_cs = cs; g.ln_ds = ds;
+        }
         if (ksplit_out) *ksplit_out = g.ksplit;
         g.trace = ctx->trace ? ctx->trace + 4096 * 8 : nullptr;
         launch_skinny_fused(g, (hipStream_t)stream);

@@ -380,6 +380,10 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
         up.A = x2; up.lda = D;
         up.ln_w = l.ln2_w; up.ln_b = l.ln2_b; up.eps = 1e-5f;
         up.Wp = l.mlp0_wp; up.w_f16 = wf16; up.bias = l.mlp0_b;
+        // ln2 folded into the product (skinny_fused_kernel<.., FD>).  Same-box A/B, ms per decode step, folded vs direct: fp16 cache + fp16 weights 0.989-0.994 vs
+        // 0.992-0.998, fp16 cache + fp32 weights 1.137-1.151 vs 1.154-1.163, fp32 both 1.447-1.454 vs 1.466-1.482 (profiles/r04_ab_ln2_fold.txt).  $BEVGEN_LN2_FOLD=0: direct form
+        static const int ln2_fold = getenv("BEVGEN_LN2_FOLD") ? atoi(getenv("BEVGEN_LN2_FOLD")) : 1;
+        if (ln2_fold) { up.ln_cs = l.mlp0_cs; up.ln_ds = l.mlp0_ds; }
         up.C = m1; up.ldc = 4 * D;
         up.M = Bc; up.N = 4 * D; up.K = D; up.ksplit = 1; up.act = ACT_GELU;
         up.trace = c.trace ? c.trace + 4096 * 8 : nullptr;

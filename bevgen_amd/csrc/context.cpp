@@ -273,6 +273,9 @@ static void finalize_ar(Ctx& c) {
             l.ln1_cs = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
             l.ln1_ds = reinterpret_cast<float*>(c.own((size_t)3 * D * sizeof(float)));
             launch_ar_ln_fold(l.wqkv, l.bqkv, l.ln1_w, l.ln1_b, l.ln1_cs, l.ln1_ds, 3 * D, D, 0);
+            l.mlp0_cs = reinterpret_cast<float*>(c.own((size_t)4 * D * sizeof(float)));
+            l.mlp0_ds = reinterpret_cast<float*>(c.own((size_t)4 * D * sizeof(float)));
+            launch_ar_ln_fold(l.mlp0_w, l.mlp0_b, l.ln2_w, l.ln2_b, l.mlp0_cs, l.mlp0_ds, 4 * D, D, 0);
             const size_t eb = wf16 ? sizeof(_Float16) : sizeof(float);
             // decode_path = split packs the QKV operand image now; auto packs it on the first call that resolves to the split layer (ctx_pack_split_qkv:
             // 3 D D elements per layer, ~300 MB at config 4 in fp32, that a context whose calls all carry more than four sequences never needs)

@@ -920,14 +920,22 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
 // v_mfma_f32_16x16x4_f32 (exact fp32): the four k-slots of one MFMA are the four 16-lane quarters, quarter q owns k = 16c + 4q .. +3.
 constexpr int SF_WAVES = 8;
 
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 ldg_nt4(const float* p) {
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <bool LN, int WT, bool RS = false>   // WT: weight storage of the packed image, 0 fp32 ([K/16][64 lanes][4]), 1 fp16 ([K/32][64 lanes][8]); RS: A is a row source
+// FD (with LN, plain A): the LayerNorm FOLDED into the product, as in the fused attention kernel: LN(x) W^T + b = rstd ((x o gamma) W^T - mean (W gamma)) + (W beta + b).
+//     The raw rows go to LDS the moment they arrive and gamma is multiplied in where the MFMA operand is read; the two-pass row statistics no longer stand between the
+//     rows' arrival and the first MFMA (two barrier rounds + the normalisation: 4.9 us from launch to "A tile staged" against 2.9 us in the MLP-down launch that has no
+//     LayerNorm) - the second pass runs behind the A barrier and mean / rstd only enter the epilogue, with the per-column constants cs = W gamma, ds = W beta + b
+//     (launch_ar_ln_fold, once per layer).
+template <bool LN, int WT, bool RS = false, bool FD = false>   // WT: weight storage of the packed image, 0 fp32 ([K/16][64 lanes][4]), 1 fp16 ([K/32][64 lanes][8]); RS: A is a row source
 __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFusedArgs g) {
+    static_assert(!FD || (LN && !RS), "the folded LayerNorm exists for the plain-A LayerNorm form");
     __shared__ float4 As[256 * 16];
+    __shared__ float4 gm_s[FD ? 256 : 1];   // gamma (FD): read behind the A barrier, while other waves may already write `red`
     __shared__ float red[SF_WAVES][4][64];
     __shared__ float stat[2][SF_WAVES][16];
     __shared__ __attribute__((aligned(16))) float pf_sink[256];   // (prefetch: the bytes are never read, only their passage through L2 matters)
@@ -997,6 +1005,13 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
         gb_raw = *reinterpret_cast<const float4*>((tid < 256 ? g.ln_w : g.ln_b) + 4 * c);   // launcher: a missing beta aliases gamma, has_ln_b = 0
     }
     float4 (*gb_s)[256] = reinterpret_cast<float4 (*)[256]>(&red[0][0][0]);   // gamma | beta share the 8 KB of `red` (free until the MFMAs are done)
+    // epilogue constants of this thread's output column, requested here: fetched in the epilogue they put one more memory round trip behind the last MFMA
+    float e_bias = 0.f, e_cs = 0.f, e_ds = 0.f;
+    if (tid < 256) {
+        const int col = min(n0 + (tid & 15), g.N - 1);
+        if (FD) { e_cs = g.ln_cs[col]; e_ds = g.ln_ds[col]; }
+        else if (g.ksplit == 1 && g.bias) e_bias = g.bias[col];
+    }
     float4 wv[WT ? 1 : 8];
     half8_t wh[WT ? 4 : 1];
     if (WT) {
@@ -1015,16 +1030,27 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
     const int n_mc = RS ? 1 : (g.M + 15) / 16;
     for (int mc = 0; mc < n_mc; ++mc) {
         if (mc > 0) load_a(mc, v);
-        if (LN) {
+        if (LN && FD) {
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (q + 4 * wave + 32 * j < nch) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-            s += __shfl_xor(s, 16, 64);
+            s += xor16(s);
+            s += xor32(s);
+            if (q == 0) stat[0][wave][r] = s;
+            if (tid < 256) gm_s[tid] = gb_raw;
+        } else if (LN) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (q + 4 * wave + 32 * j < nch) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            s += xor16(s);
             s += xor32(s);
             if (q == 0) stat[0][wave][r] = s;
             gb_s[tid >> 8][tid & 255] = gb_raw;   // (every row chunk: `red` is rewritten by the chunk's reduction)
-            __syncthreads();
+            // LDS-only barriers up to the MFMAs: __syncthreads() also waits for every load in flight, i.e. it parks the statistics behind the weight slice
+            // (requested above, 64 KB per workgroup from HBM) instead of running them in its shadow
+            lds_barrier();
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < SF_WAVES; ++w) t += stat[0][w][r];
@@ -1037,10 +1063,10 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                     qq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
                 }
             }
-            qq += __shfl_xor(qq, 16, 64);
+            qq += xor16(qq);
             qq += xor32(qq);
             if (q == 0) stat[1][wave][r] = qq;
-            __syncthreads();
+            lds_barrier();
             t = 0.f;
 #pragma unroll
             for (int w = 0; w < SF_WAVES; ++w) t += stat[1][w][r];
@@ -1067,9 +1093,37 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
             const int c = q + 4 * wave + 32 * j;
             if (c < nch) As[c * 16 + r] = v[j];
         }
-        __syncthreads();
+        lds_barrier();
         SF_TRACE(1);
-        if (LN && !RS && g.pf_ptr && mc == 0) {   // (the barrier above drained this wave's loads: its own weight slice is in)
+        // FD: everything that does not need the weight slice runs in front of the wait for it - the second pass of the statistics from the rows still in registers
+        // (consumed by the epilogue, behind the `red` barrier) and the MFMA A operands x o gamma (k-chunk c4 of the row; LayerNorm launches have one K slice).
+        // (gamma through LDS, one float4 per thread: fetched per operand chunk into registers - 8 more loads per thread, behind the weight requests - the same-box A/B
+        // gave 0.998-1.001 against 0.989-0.994 ms/step: the weight slice is the long pole of this launch and everything else in the CU's request queue delays it)
+        float4 aop[FD ? 8 : 1];
+        if (FD) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < SF_WAVES; ++w) t += stat[0][w][r];
+            const float mean = t / (float)g.K;
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (q + 4 * wave + 32 * j < nch) {
+                    const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                    qq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+            qq += xor16(qq);
+            qq += xor32(qq);
+            if (q == 0) stat[1][wave][r] = qq;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {   // operand i of the MFMA loop below (chunks past the wave's slice: clamped, not used)
+                const int c4 = min(WT ? ((wave * kper + 32 * (i >> 1)) >> 2) + 2 * q + (i & 1) : ((wave * kper + 16 * i) >> 2) + q, nch - 1);
+                aop[i] = mul4(As[c4 * 16 + r], gm_s[c4]);
+            }
+        }
+        if (LN && !RS && g.pf_ptr && mc == 0) {   // (behind this wave's own weight slice: waited for here, the MFMAs below need it anyway)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int i = blockIdx.y * gridDim.x + blockIdx.x, xr = i & 7, j = i >> 3;
             const int tx = xr + 8 * (j / g.pf_splits), ty = j % g.pf_splits;
             if (tx < g.pf_tiles) {
@@ -1085,7 +1139,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
             for (int u = 0; u < 4; ++u) {
                 if (32 * u < kper) {   // quarter q owns k = 32 c + 8 q .. + 7 of the chunk: two A float4 (chunks of 4 k), eight MFMAs
                     const int c4 = ((wave * kper + 32 * u) >> 2) + 2 * q;
-                    const float4 a0 = As[c4 * 16 + r], a1 = As[(c4 + 1) * 16 + r];
+                    const float4 a0 = FD ? aop[FD ? 2 * u : 0] : As[c4 * 16 + r], a1 = FD ? aop[FD ? 2 * u + 1 : 0] : As[(c4 + 1) * 16 + r];
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, (float)wh[u][0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, (float)wh[u][1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, (float)wh[u][2], acc, 0, 0, 0);
@@ -1100,7 +1154,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (16 * u < kper) {
-                    const float4 a4 = As[(((wave * kper + 16 * u) >> 2) + q) * 16 + r];
+                    const float4 a4 = FD ? aop[FD ? u : 0] : As[(((wave * kper + 16 * u) >> 2) + q) * 16 + r];
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv[u].x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv[u].y, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv[u].z, acc, 0, 0, 0);
@@ -1123,7 +1177,16 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                 if (g.ksplit > 1) {
                     g.C[((long)split * g.M + mo) * g.N + col] = o;
                 } else {
-                    o += g.bias ? g.bias[col] : 0.f;
+                    if (FD) {
+                        const int rw = 4 * (ln >> 4) + j;
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < SF_WAVES; ++w) { t1 += stat[0][w][rw]; t2 += stat[1][w][rw]; }
+                        const float mean = t1 / (float)g.K, rstd = rsqrtf(t2 / (float)g.K + g.eps);
+                        o = rstd * (o - mean * e_cs) + e_ds;
+                    } else {
+                        o += e_bias;
+                    }
                     if (g.act == ACT_GELU) o = gelu_erf(o);
                     g.C[(long)mo * g.ldc + col] = o;
                 }
@@ -1217,6 +1280,8 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     if (g.a_src) { g.src = rowsrc_fix(*g.a_src); g.a_src = nullptr; }
     const bool rs = g.src.base != nullptr;
     BG_REQUIRE(rs || g.A, "skinny_fused: no A operand");
+    const bool fd = g.ln_cs != nullptr;
+    BG_REQUIRE(!fd || (ln && !rs && g.ln_ds && g.K <= 1024), "skinny_fused: the folded LayerNorm needs the plain-A LayerNorm form and both row constants");
     dim3 grid(cdiv(g.N, 16), g.ksplit);
     ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);   // work = algorithmic bytes
     if (g.w_f16) BG_REQUIRE((g.K / g.ksplit) % (SF_WAVES * 32) == 0, "skinny_fused: fp16 weights need a K slice that is a multiple of %d (K=%d, ksplit=%d)", SF_WAVES * 32, g.K, g.ksplit);
@@ -1233,10 +1298,12 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
             else hipLaunchKernelGGL((skinny_fused_kernel<true, 0, true>), grid, dim3(SF_WAVES * 64), 0, s, h);
         }
     } else if (g.w_f16) {
-        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (ln && fd) hipLaunchKernelGGL((skinny_fused_kernel<true, 1, false, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
         else hipLaunchKernelGGL((skinny_fused_kernel<false, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
     } else {
-        if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (ln && fd) hipLaunchKernelGGL((skinny_fused_kernel<true, 0, false, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
         else hipLaunchKernelGGL((skinny_fused_kernel<false, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
     }
     LAUNCH_CHECK();

@@ -260,6 +260,7 @@ struct SkinnyFusedArgs {
     const RowSrc* a_src = nullptr;           // non-null: A is this row source (previous layer's split-K partials + bias + residual, added while the tile is fetched)
     float* xn_out = nullptr; int ldxn = 0;   // non-null (with LayerNorm): the normalised rows are also written out [M, K] (the residual Block.forward takes from ln1(x))
     const float *ln_w = nullptr, *ln_b = nullptr; float eps = 1e-5f;   // ln_w != null: LayerNorm over K fused in front of the product
+    const float *ln_cs = nullptr, *ln_ds = nullptr;   // [N] each, non-null (plain A + LayerNorm): W gamma and W beta + bias (launch_ar_ln_fold) - the LayerNorm is folded into the product, `bias` is not read
     const float* Wp = nullptr;               // [N, K] weights in the packed operand layout (launch_pack_skinny_weight / _f16)
     int w_f16 = 0;                           // the packed image holds fp16 values
     const float* bias = nullptr;       // [N] (ksplit == 1 only)

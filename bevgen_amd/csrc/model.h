@@ -50,6 +50,7 @@ struct ArLayer {
     const float *mlp0_w, *mlp0_b, *mlp2_w, *mlp2_b;
     float *mlp0_wp = nullptr, *mlp2_wp = nullptr;   // decode-step operand images of the MLP weights (owned; fused decode path; fp32 or fp16 packed)
     void* wqkv_h = nullptr;                          // decode_weights = f16: fp16 copy of the fused QKV weight [3D, D]
+    float *mlp0_cs = nullptr, *mlp0_ds = nullptr;    // the same for ln2 in front of the MLP up-projection (skinny_fused_kernel<.., FD>)
     float *ln1_cs = nullptr, *ln1_ds = nullptr;      // fused decode kernel: ln1 folded into the projection - W gamma and W beta + b of the fused QKV matrix (launch_ar_ln_fold)
     float* wqkv_wp = nullptr;                        // decode_path = split: operand image of the fused QKV weight (packed like the MLP images)
 };

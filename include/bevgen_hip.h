@@ -228,7 +228,8 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_w, const fl
                    int M, int N, int K, int act_gelu, int skinny, void* stream);            /* C = A W^T (+bias)(gelu)(+res); skinny: 0 tiled fp32, 1 M <= 64, 2-4 split-precision
                                                                                                kernels (tests / probes), 5 = 3 with the k range split over three slices */
 /* Decode-step projection (decode_fused.hip): C = act(LayerNorm?(A) W^T + bias) for M <= 64 rows; d_ln_w NULL = no LayerNorm; ksplit > 1 (no LayerNorm, no bias / act):
- * d_c receives the split-K partial sums [ksplit, M, N] that the consumer adds; ksplit 0 = the library's choice for (N, K), returned through *ksplit_out if non-NULL. */
+ * d_c receives the split-K partial sums [ksplit, M, N] that the consumer adds; ksplit 0 = the library's choice for (N, K), returned through *ksplit_out if non-NULL;
+ * ksplit -1 (LayerNorm with beta and bias): one K slice, the LayerNorm folded into the product the way the decode step launches ln2 + MLP-up. */
 int bevgen_op_ln_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w, const float* d_bias, float* d_c,
                       int M, int N, int K, int act_gelu, int ksplit, int* ksplit_out, void* stream);
 /* d_out[i] = the uniform the MaskGit samplers draw for element i of noise stream `stream_id` (0 gumbel, 1 critic) at iteration `iter` under `seed`. */

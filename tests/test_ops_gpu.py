@@ -484,6 +484,9 @@ def test_ln_gemm_operator(gpu_ctx, M, N, K, ln, gelu):
             ref = F.gelu(ref)
     out = gpu_ctx.op_ln_gemm(dev(a), dev(w), ln_w=dev(lw) if ln else None, ln_b=dev(lb) if ln else None, bias=dev(b) if ln else None, gelu=gelu and ln)
     assert rel(out.cpu().double(), ref) < 6e-6
+    if ln:   # the folded-LayerNorm form the decode step launches (row statistics in the shadow of the product, applied in the epilogue)
+        out = gpu_ctx.op_ln_gemm(dev(a), dev(w), ln_w=dev(lw), ln_b=dev(lb), bias=dev(b), gelu=gelu, ksplit=-1)
+        assert rel(out.cpu().double(), ref) < 6e-6
 
 
 def test_profiler_state_is_per_context(gpu_ctx):
