@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 constexpr int LN_MAXV = 12;  // float4 per lane -> D <= 3072
 
 // PLANES: y is the interleaved (hi, lo) f16 plane image [row][ldy/32][2][32] read by the split-precision GEMM (gemm_split.hip) instead of fp32
-template <bool PLANES>
+// MAXV: float4 per lane the instantiation holds (4: rows up to 1024 wide - 16 row registers instead of 48, eight waves per SIMD instead of five)
+template <bool PLANES, int MAXV = LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ y, int ldy, int rows, int D, float eps) {
     // D need not be a multiple of 4 (Route M: LayerNorm over F = 2730 columns of a row padded to 2752): the last vector of a row is then partly
@@ -45,10 +46,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     if (row >= rows) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
     const int nv = (D + 3) >> 2;
-    float4 v[LN_MAXV];
+    float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int i = lane + 64 * j;
         v[j] = i < nv ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (4 * i + 3 >= D) {   // boundary / padding vector: elements at columns >= D do not exist
@@ -59,11 +60,11 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         }
     }
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    for (int j = 0; j < MAXV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) {
             const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
@@ -75,8 +76,34 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     float4* yr = reinterpret_cast<float4*>(y + (long)row * ldy);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
+    if (PLANES && (D & 255) == 0 && ldy == D) {
+        // Whole rows of full vectors (the transformer widths): neighbouring lanes trade halves so that every lane stores 16 contiguous bytes - the even lane the hi
+        // parts of the pair's 8 columns, the odd lane the lo parts - and a wave's store instruction covers 1 KiB of whole 128-byte lines (the generic path below writes
+        // 8 bytes of each plane per lane: two instructions that each touch half of every line).
+        const bool odd = lane & 1;
+        _Float16* prow = reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+        for (int j = 0; j < MAXV; ++j) {
+            const int i = lane + 64 * j;
+            if (64 * j < nv) {   // (wave-uniform: nv is a multiple of 64)
+                const float4 g = g4[i];
+                float4 o = make_float4((v[j].x - mean) * rstd * g.x, (v[j].y - mean) * rstd * g.y, (v[j].z - mean) * rstd * g.z, (v[j].w - mean) * rstd * g.w);
+                if (beta) { const float4 bb = b4[i]; o.x += bb.x; o.y += bb.y; o.z += bb.z; o.w += bb.w; }
+                half4_t h, l;
+                h[0] = split_hi(o.x); h[1] = split_hi(o.y); h[2] = split_hi(o.z); h[3] = split_hi(o.w);
+                l[0] = split_lo(o.x, h[0]); l[1] = split_lo(o.y, h[1]); l[2] = split_lo(o.z, h[2]); l[3] = split_lo(o.w, h[3]);
+                const uint2 hw = __builtin_bit_cast(uint2, h), lw = __builtin_bit_cast(uint2, l);
+                const uint2 send = odd ? hw : lw;
+                const uint2 recv = make_uint2((unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xf, 0xf, true));
+                const uint4 out = odd ? make_uint4(recv.x, recv.y, lw.x, lw.y) : make_uint4(hw.x, hw.y, recv.x, recv.y);
+                const int c = 8 * (i >> 1);
+                *reinterpret_cast<uint4*>(prow + (c >> 5) * 64 + (c & 31) + (odd ? 32 : 0)) = out;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) {
             float4 o;
@@ -107,7 +134,9 @@ void launch_layernorm(const float* x, int ldx, const float* gamma, const float* 
     if (rows <= 0) return;
     const bool vec = ldx % 4 == 0 && ldy % 4 == 0 && ldx >= round_up(D, 4) && ldy >= round_up(D, 4) && D <= 256 * LN_MAXV && ldy <= 256 * LN_MAXV &&
                      (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0;
-    if (vec)
+    if (vec && D <= 1024 && ldy <= 1024)
+        hipLaunchKernelGGL((layernorm_vec_kernel<false, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+    else if (vec)
         hipLaunchKernelGGL(layernorm_vec_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
     else
         hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
@@ -119,7 +148,10 @@ void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const 
     BG_REQUIRE(ldx % 4 == 0 && ldx >= round_up(D, 4) && ldy % 32 == 0 && ldy >= round_up(D, 4) && ldy <= 256 * LN_MAXV &&
                    (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0,
                "layernorm_planes: unsupported shape D=%d ldx=%d ldy=%d", D, ldx, ldy);
-    hipLaunchKernelGGL(layernorm_vec_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps);
+    if (D <= 1024 && ldy <= 1024)
+        hipLaunchKernelGGL((layernorm_vec_kernel<true, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_vec_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps);
     LAUNCH_CHECK();
 }
 
