@@ -185,6 +185,11 @@ __device__ __forceinline__ void glds16_hidden(const void* src, unsigned lds_base
     unsigned keep;   // (m0 is the compiler's: saved and restored around the request)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
 }
+// the same with the non-temporal hint (streamed once: should not displace what other kernels parked in L2)
+__device__ __forceinline__ void glds16_hidden_nt(const void* src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }

@@ -63,12 +63,15 @@ void launch_rowsrc_materialize(const RowSrc& r0, float* out, int M, int D, int* 
 
 // ----------------------------------------------------------------------------------------------------------------- helpers
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+// K / V rows are read with the NON-TEMPORAL hint (registers and LDS-DMA alike): a decode step streams ~85 MB of them per layer through 8 x 4 MB of L2 exactly once, and
+// without the hint that stream evicts what the step does reuse - the head's q/k/v weight rows its 16 workgroups share, and the weight images the MLP launches park in L2
+// for each other.  Same-box A/B, fp16 cache + fp16 weights: 0.996-0.999 -> 0.959-0.964 ms/step (profiles/r04_ab_kv_nontemporal.txt).
 template <int DT> struct KvRow;
 template <> struct KvRow<0> {  // fp32 rows: 256 B = 16 lanes x 16 B
     static constexpr int LPK = 16, DPL = 4;
     typedef f32x4 Raw;
     __device__ static __forceinline__ Raw load(const void* base, long row, int sub) {
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * 64 + sub * 4);
+        return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + row * 64 + sub * 4));
     }
     __device__ static __forceinline__ float get(const Raw& r, int i) { return r[i]; }
 };
@@ -76,7 +79,7 @@ template <> struct KvRow<1> {  // fp16 rows: 128 B = 8 lanes x 16 B; kept packed
     static constexpr int LPK = 8, DPL = 8;
     typedef half8_t Raw;
     __device__ static __forceinline__ Raw load(const void* base, long row, int sub) {
-        return *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(base) + row * 64 + sub * 8);
+        return __builtin_nontemporal_load(reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(base) + row * 64 + sub * 8));
     }
     __device__ static __forceinline__ float get(const Raw& r, int i) { return (float)r[i]; }
 };
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
             const int j = q_iss / (2 * SU), r = q_iss % (2 * SU);
             const long koff = SP ? (long)(16 * __builtin_amdgcn_readlane(cid_lane, j) + (r % SU) * KPI) * ROWB : (long)(j * SU + r % SU) * (PIECE * ROWB);
             const char* src = reinterpret_cast<const char*>(r >= SU ? a.vcache : a.kcache) + wrow + koff;
-            glds16_hidden(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(st_w + q_iss * 1024)));
+            glds16_hidden_nt(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(st_w + q_iss * 1024)));
         }
     };
 
