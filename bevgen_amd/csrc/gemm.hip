@@ -191,7 +191,8 @@ static GemmArgs conv_defaults(const GemmArgs& g0) {
     return g;
 }
 
-static const std::unordered_map<const float*, SplitPlanes>* g_split_table = nullptr;
+// per calling thread (like the profiler hook): set by every entry point for the context it runs, so two contexts driven from two host threads do not see each other's table
+static thread_local const std::unordered_map<const float*, SplitPlanes>* g_split_table = nullptr;
 void split_registry_set(const void* table) { g_split_table = reinterpret_cast<const std::unordered_map<const float*, SplitPlanes>*>(table); }
 
 void launch_gemm(const GemmArgs& g_in, hipStream_t stream) {
