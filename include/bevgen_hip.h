@@ -14,7 +14,7 @@
  *     data_ptr()), `h_*` are HOST pointers; the library owns weights, KV cache and workspace inside the context
  *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous on it unless stated otherwise,
  *     the library performs no hidden host synchronisation on the sampling path
- *   - one context per (device, model); a context is not thread-safe
+ *   - one context per (device, model); a context is not thread-safe, different contexts may be used from different host threads concurrently
  *   - int64 token ids, fp32 everything else (the arithmetic type is a context property: BEVGEN_PRECISION_*)
  */
 #ifndef BEVGEN_HIP_H
