@@ -362,7 +362,8 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     wall = time.time() - t0
     st = ctx.ar_step_times(steps + 8)
     ctx.ar_step_timing(False)
-    # pass 2: same work launched eagerly with a HIP-event pair around every fused attention / skinny-GEMM launch -> per-kernel rooflines
+    # pass 2: same work launched eagerly with a HIP-event pair ATTACHED to every fused attention / skinny-GEMM launch (hipExtLaunchKernelGGL start / stop events = the
+    # kernel's own begin / end, what rocprofv3 --kernel-trace reports) -> per-kernel rooflines
     ctx.profile_begin()
     sample(steps)
     torch.cuda.synchronize()
@@ -663,7 +664,7 @@ def main():
         # ... and the all-fp16-storage model (projection weights rounded to fp16 at load, tokens bit-exact vs the oracle on the rounded weights; fp32 arithmetic)
         h16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16")
         line["decode_f16_kv_cache_f16_weights"] = {k: h16[k] for k in dkeys}
-        # the same kernel timed on the PRODUCT path (hipGraph replay) by a rocprofv3 --kernel-trace child pass: the HIP-event pairs above bracket launch + kernel
+        # the same kernel timed on the PRODUCT path (hipGraph replay) by a rocprofv3 --kernel-trace child pass: the cross-check of the HIP-event figure above
         if not DRY_RUN and os.environ.get("BEVGEN_BENCH_NO_PMC") != "1":
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -17,6 +17,7 @@
 //
 // Shared condition prefix (BASELINE config 5, several samples per BEV layout): a workgroup serves the G sequences of one layout
 // and one head; the K prefix rows are streamed ONCE and scored against the G queries, the private suffixes are split over wave teams.
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 #include "common.h"
@@ -881,22 +882,25 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     const double n_host = a.d_n ? a.n + a.n_hint : a.n;
     const double eb = a.kv_dtype == 0 ? 4 : 2;
     const double pfx = a.G > 1 ? (double)a.prefix : 0.0;
-    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pfx) + (double)(a.B / a.G) * pfx), s);
+    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pfx) + (double)(a.B / a.G) * pfx), s, a.ksplit == 1);   // (one launch: events attached to it)
     // SP instantiations only when a layout hides something (density < 1): chunk lists are then always present (context.cpp / the operator entry build both)
     const bool sp = a.vis.has_chunks;
     BG_REQUIRE(sp || !a.vis.has_lay, "fused decode attention: a block layout needs its chunk lists");
     // (more than 64 KB of dynamic LDS has to be allowed per kernel function, once)
 #define AF_LAUNCH1(K) do { static bool big = false; if (lds > 64 * 1024 && !big) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ar_attn_fused_max_lds() - 1024)); big = true; } \
-                           hipLaunchKernelGGL(K, grid, dim3(1024), lds, s, a); } while (0)
+                           if (prof.attached()) hipExtLaunchKernelGGL(K, grid, dim3(1024), lds, s, prof.ev_a(), prof.ev_b(), 0, a); \
+                           else hipLaunchKernelGGL(K, grid, dim3(1024), lds, s, a); } while (0)
 #define AF_LAUNCH(DT, GG, WW) do { if (sp) AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, true>)); else AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, false>)); } while (0)
 #define AF_LAUNCH_G(DT, WW) do { if (a.G == 1) AF_LAUNCH(DT, 1, WW); else if (a.G == 2) AF_LAUNCH(DT, 2, WW); else AF_LAUNCH(DT, 4, WW); } while (0)
     if (pre) {
-#define AP_LAUNCH(DT, GG) do { if (sp) hipLaunchKernelGGL((ar_attn_kernel<DT, GG, true>), grid, dim3(1024), lds, s, a); \
-                               else hipLaunchKernelGGL((ar_attn_kernel<DT, GG, false>), grid, dim3(1024), lds, s, a); } while (0)
+#define AP_LAUNCH1(K) do { if (prof.attached()) hipExtLaunchKernelGGL(K, grid, dim3(1024), lds, s, prof.ev_a(), prof.ev_b(), 0, a); \
+                           else hipLaunchKernelGGL(K, grid, dim3(1024), lds, s, a); } while (0)
+#define AP_LAUNCH(DT, GG) do { if (sp) AP_LAUNCH1((ar_attn_kernel<DT, GG, true>)); else AP_LAUNCH1((ar_attn_kernel<DT, GG, false>)); } while (0)
 #define AP_LAUNCH_G(DT) do { if (a.G == 1) AP_LAUNCH(DT, 1); else if (a.G == 2) AP_LAUNCH(DT, 2); else AP_LAUNCH(DT, 4); } while (0)
         if (a.kv_dtype == 0) AP_LAUNCH_G(0); else AP_LAUNCH_G(1);
 #undef AP_LAUNCH_G
 #undef AP_LAUNCH
+#undef AP_LAUNCH1
     } else if (a.wqkv_h) {
         BG_REQUIRE(a.D % 8 == 0, "fused decode attention: fp16 weights need D %% 8 == 0");
         if (a.kv_dtype == 0) AF_LAUNCH_G(0, 1); else AF_LAUNCH_G(1, 1);
@@ -1286,8 +1290,10 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     const bool fd = g.ln_cs != nullptr;
     BG_REQUIRE(!fd || (ln && !rs && g.ln_ds && g.K <= 1024), "skinny_fused: the folded LayerNorm needs the plain-A LayerNorm form and both row constants");
     dim3 grid(cdiv(g.N, 16), g.ksplit);
-    ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s);   // work = algorithmic bytes
+    ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s, !rs || g.M <= 16);   // work = algorithmic bytes; one launch: events attached to it
     if (g.w_f16) BG_REQUIRE((g.K / g.ksplit) % (SF_WAVES * 32) == 0, "skinny_fused: fp16 weights need a K slice that is a multiple of %d (K=%d, ksplit=%d)", SF_WAVES * 32, g.K, g.ksplit);
+#define SF_LAUNCH(K, ARGS) do { if (prof.attached()) hipExtLaunchKernelGGL(K, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, ARGS); \
+                                else hipLaunchKernelGGL(K, grid, dim3(SF_WAVES * 64), 0, s, ARGS); } while (0)
     if (rs) {   // 16 rows per launch
         const int M = g.M;
         for (int m0 = 0; m0 < M; m0 += 16) {
@@ -1297,18 +1303,19 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
             h.src.partial += (long)m0 * g.src.pld;   // (aliases base when there are no partials: any valid address will do)
             h.C = g.C + (long)m0 * g.ldc;
             if (g.xn_out) h.xn_out = g.xn_out + (long)m0 * g.ldxn;
-            if (g.w_f16) hipLaunchKernelGGL((skinny_fused_kernel<true, 1, true>), grid, dim3(SF_WAVES * 64), 0, s, h);
-            else hipLaunchKernelGGL((skinny_fused_kernel<true, 0, true>), grid, dim3(SF_WAVES * 64), 0, s, h);
+            if (g.w_f16) SF_LAUNCH((skinny_fused_kernel<true, 1, true>), h);
+            else SF_LAUNCH((skinny_fused_kernel<true, 0, true>), h);
         }
     } else if (g.w_f16) {
-        if (ln && fd) hipLaunchKernelGGL((skinny_fused_kernel<true, 1, false, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
-        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
-        else hipLaunchKernelGGL((skinny_fused_kernel<false, 1>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (ln && fd) SF_LAUNCH((skinny_fused_kernel<true, 1, false, true>), g);
+        else if (ln) SF_LAUNCH((skinny_fused_kernel<true, 1>), g);
+        else SF_LAUNCH((skinny_fused_kernel<false, 1>), g);
     } else {
-        if (ln && fd) hipLaunchKernelGGL((skinny_fused_kernel<true, 0, false, true>), grid, dim3(SF_WAVES * 64), 0, s, g);
-        else if (ln) hipLaunchKernelGGL((skinny_fused_kernel<true, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
-        else hipLaunchKernelGGL((skinny_fused_kernel<false, 0>), grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (ln && fd) SF_LAUNCH((skinny_fused_kernel<true, 0, false, true>), g);
+        else if (ln) SF_LAUNCH((skinny_fused_kernel<true, 0>), g);
+        else SF_LAUNCH((skinny_fused_kernel<false, 0>), g);
     }
+#undef SF_LAUNCH
     LAUNCH_CHECK();
 }
 

@@ -25,18 +25,21 @@ Profiler* prof_set_current(Profiler* p) {
 
 bool prof_enabled() { return t_current && t_current->on; }
 
-ProfScope::ProfScope(int kind, double work, hipStream_t s) : p(nullptr), idx(-1), stream(s) {
+ProfScope::ProfScope(int kind, double work, hipStream_t s, bool attach_) : attach(attach_), p(nullptr), idx(-1), stream(s) {
     if (!t_current || !t_current->on) return;
     p = t_current;
     Profiler::Rec r{kind, work, get_event(*p), get_event(*p)};
-    HIP_CHECK(hipEventRecord(r.a, s));
+    if (!attach) HIP_CHECK(hipEventRecord(r.a, s));
     idx = (int)p->recs.size();
     p->recs.push_back(r);
 }
 
 ProfScope::~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(p->recs[idx].b, stream);
+    if (idx >= 0 && !attach) (void)hipEventRecord(p->recs[idx].b, stream);
 }
+
+hipEvent_t ProfScope::ev_a() const { return p->recs[idx].a; }
+hipEvent_t ProfScope::ev_b() const { return p->recs[idx].b; }
 
 Profiler::~Profiler() {
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);

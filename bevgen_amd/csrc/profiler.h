@@ -28,9 +28,15 @@ struct Profiler {
 Profiler* prof_set_current(Profiler* p);
 
 struct ProfScope {
-    // records an event pair around the enclosed launch(es) when the calling thread's current profiler is enabled
-    ProfScope(int kind, double work, hipStream_t s);
+    // records an event pair around the enclosed launch(es) when the calling thread's current profiler is enabled.
+    // attach = true: the pair is NOT recorded on the stream; the launcher hands ev_a() / ev_b() to hipExtLaunchKernelGGL instead, which stamps them with the kernel's own
+    // begin / end (what rocprofv3 --kernel-trace reports), without the two marker packets whose processing a stream-recorded pair adds to every short launch (~2 us)
+    ProfScope(int kind, double work, hipStream_t s, bool attach = false);
     ~ProfScope();
+    bool attached() const { return idx >= 0 && attach; }
+    hipEvent_t ev_a() const;
+    hipEvent_t ev_b() const;
+    bool attach = false;
     Profiler* p;
     int idx;
     hipStream_t stream;
