@@ -387,14 +387,6 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
         up.C = m1; up.ldc = 4 * D;
         up.M = Bc; up.N = 4 * D; up.K = D; up.ksplit = 1; up.act = ACT_GELU;
         up.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
-        static const bool mlp_pf = !(getenv("BEVGEN_MLP_PREFETCH") && atoi(getenv("BEVGEN_MLP_PREFETCH")) == 0);   // (A/B switch)
-        if (mlp_pf && ks >= 1) {   // MLP-down's weight image rides into L2 under this launch's MFMA phase
-            const size_t ebw = wf16 ? 2 : 4;
-            up.pf_ptr = l.mlp2_wp;
-            up.pf_tile_bytes = (long)(4 * D) * 16 * ebw;                 // one 16-column tile over the whole K = 4 D
-            up.pf_slice_bytes = (int)((4 * D / ks) * 16 * ebw);          // one workgroup's K slice of it
-            up.pf_splits = ks; up.pf_tiles = (D + 15) / 16;
-        }
         launch_skinny_fused(up, s);
         SkinnyFusedArgs dn;
         dn.A = m1; dn.lda = 4 * D;

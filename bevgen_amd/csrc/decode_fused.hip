@@ -945,7 +945,6 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
     __shared__ float4 gm_s[FD ? 256 : 1];   // gamma (FD): read behind the A barrier, while other waves may already write `red`
     __shared__ float red[SF_WAVES][4][64];
     __shared__ float stat[2][SF_WAVES][16];
-    __shared__ __attribute__((aligned(16))) float pf_sink[256];   // (prefetch: the bytes are never read, only their passage through L2 matters)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16, split = blockIdx.y;
@@ -1129,17 +1128,6 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                 aop[i] = mul4(As[c4 * 16 + r], gm_s[c4]);
             }
         }
-        if (LN && !RS && g.pf_ptr && mc == 0) {   // (behind this wave's own weight slice: waited for here, the MFMAs below need it anyway)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int i = blockIdx.y * gridDim.x + blockIdx.x, xr = i & 7, j = i >> 3;
-            const int tx = xr + 8 * (j / g.pf_splits), ty = j % g.pf_splits;
-            if (tx < g.pf_tiles) {
-                const char* src = reinterpret_cast<const char*>(g.pf_ptr) + (long)tx * g.pf_tile_bytes + (long)ty * g.pf_slice_bytes;
-                const unsigned sink = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(&pf_sink[0]));
-                for (int o = wave * 1024; o < g.pf_slice_bytes; o += SF_WAVES * 1024) glds16_hidden(src + o + lane * 16, sink);
-            }
-        }
-
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (WT) {
 #pragma unroll
@@ -1201,7 +1189,6 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
         }
         if (mc + 1 < n_mc) __syncthreads();   // As / red are rewritten by the next row chunk
     }
-    if (LN && !RS && g.pf_ptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the prefetch writes LDS: it must have landed before the workgroup's LDS is released)
     SF_TRACE(3);
 #undef SF_TRACE
 }

@@ -269,13 +269,6 @@ struct SkinnyFusedArgs {
     long long* trace = nullptr;        // diagnostics, as above
     int has_ln_b = 0;                  // filled in by the launcher
     RowSrc src;                        // filled in by the launcher from a_src
-    // Prefetch for the NEXT launch of the layer (ln2 + MLP-up prefetches MLP-down's weight image): once its own weight slice has arrived (memory idle: the MFMA phase
-    // issues no loads), every workgroup pulls "its" slice of the next kernel's packed image through the L2 of its XCD by hidden LDS-DMA into a sink - workgroup i runs on
-    // XCD i % 8 (observed placement, used for speed only): it takes the slice of the next launch's j-th workgroup on that XCD.  The next kernel then finds its 32-64 KB
-    // in L2 (~1 us) instead of opening with a cold HBM burst (~4 us).  pf_ptr = null: off
-    const void* pf_ptr = nullptr;
-    long pf_tile_bytes = 0;            // bytes of one 16-column tile row of the next image (its K / 32 KiB with fp16, K / 16 with fp32)
-    int pf_slice_bytes = 0, pf_splits = 1, pf_tiles = 0;   // bytes one workgroup of the next launch reads (a K slice of one tile), K slices per tile, column tiles
 };
 size_t skinny_packed_floats(int N, int K);
 void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStream_t s);
