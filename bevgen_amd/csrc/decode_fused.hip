@@ -538,16 +538,14 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     const uint16_t* chunk_row = vis.chunks + (long)head * vis.chunks_head_stride + (long)(row / vis.blk) * vis.chunks_ld;
 
 
-    // ---- ln1 FOLDED into the projection (fp16 weight storage).  LN(x) W^T + b = rstd (x o gamma) W^T - rstd mean (W gamma) + (W beta + b): the dot products run on x o gamma, which exists
-    //      the moment the x rows are in, and the row statistics are computed in their shadow; mean / rstd and the two per-row constants cs = W gamma, ds = W beta + b
-    //      (launch_ar_ln_fold, once per layer) only enter a 192-value fix-up after the row loop.  The direct form - statistics (two barrier rounds), normalised row to
-    //      LDS, barrier, THEN the first product - spent 2.8 us between the rows' arrival and the first multiply-add, most of it with every wave blocked at the request
-    //      instructions of its first weight batches (a CU's address pipe takes 64 B per clock: 256 KB = 1.9 us) before it could even start the statistics.
+    // ---- ln1 FOLDED into the projection.  LN(x) W^T + b = rstd (x o gamma) W^T - rstd mean (W gamma) + (W beta + b): the dot products run on x o gamma, which exists the moment
+    //      the x rows are in, and the row statistics are computed in their shadow; mean / rstd and the two per-row constants cs = W gamma, ds = W beta + b (launch_ar_ln_fold,
+    //      once per layer) only enter a 192-value fix-up after the row loop.  The direct form - statistics (two barrier rounds), normalised row to LDS, barrier, THEN the first
+    //      product - spent 2.8 us between the rows' arrival and the first multiply-add, most of it with every wave blocked at the request instructions of its first weight
+    //      batches (a CU's address pipe takes 64 B per clock: 256 KB = 1.9 us) before it could even start the statistics.
     //      (Same arithmetic up to fp32 rounding of the re-associated sum: tokens equal to the oracle's on every fixture, tests/test_models_gpu.py.)
-    //      Same-box A/B, ms per decode step: fp16 cache + fp16 weights 1.067 -> 1.050; with fp32 weights 1.208 -> 1.225 and 1.540 -> 1.558 - there the prologue is bound
-    //      by the 786 KB of weight rows + 128 KB of staged pieces every workgroup pushes through its CU's address pipe, the statistics were already in its shadow, and
-    //      the fix-up only adds: the direct form stays for fp32 weights (FOLD below).
-    constexpr bool FOLD = WT == 1;
+    //      Same-box A/Bs, ms per decode step: fp16 cache + fp16 weights 1.067 -> 1.050 when it was introduced; with fp32 weights it lost then (1.208 -> 1.225: the prologue
+    //      was bound by the weight rows + staged pieces in the CU's request queue) and wins at the end of the round (1.103-1.105 -> 1.092, 1.398-1.408 -> 1.395-1.397): one form.
     const int jb = wave * 12 + min(lane, 11);
     float* stat2 = red;                         // scratch inside `red` (free until the key walk): second-pass sums | raw x, gamma, beta of this head's 64 columns
     float* xh_s = red + NW * G;
@@ -561,11 +559,11 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
 #pragma unroll
             for (int g = 0; g < G; ++g) stat[wave * G + g] = s[g];
         }
-        if (FOLD && tid < D) {
+        if (tid < D) {
 #pragma unroll
             for (int g = 0; g < G; ++g) xn_s[g * D + tid] = xv[g] * lw;   // x o gamma: what the row loop multiplies
         }
-        if (FOLD && (tid >> 6) == head && tid < D) {
+        if ((tid >> 6) == head && tid < D) {
 #pragma unroll
             for (int g = 0; g < G; ++g) xh_s[g * 64 + lane] = xv[g];
             gh_s[lane] = lw; gh_s[64 + lane] = lb;
@@ -579,10 +577,9 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         // this wave's 12 pairs of row constants, one per lane (applied after the row loop).  A load INSIDE the row loop sits, in the in-order return stream, behind the next
         // batch's weight loads just issued: every row then waited for the whole next batch - vmcnt(0) in front of each qkv_s store - and the double buffering was void
         // (the projection took 8 us with fp32 and with fp16 weights alike)
-        c_mine = (FOLD ? a.ln_cs : a.bqkv)[(long)(jb >> 6) * D + head * 64 + (jb & 63)];   // (direct form: the row's bias)
-        d_mine = FOLD ? a.ln_ds[(long)(jb >> 6) * D + head * 64 + (jb & 63)] : 0.f;
-        // second statistics pass.  Folded form: in the shadow of the weight loads, read by the fix-up behind the row loop's closing barrier.  Direct form: two more
-        // barrier rounds, then the normalised row goes to LDS
+        c_mine = a.ln_cs[(long)(jb >> 6) * D + head * 64 + (jb & 63)];
+        d_mine = a.ln_ds[(long)(jb >> 6) * D + head * 64 + (jb & 63)];
+        // second statistics pass: in the shadow of the weight loads, read by the fix-up behind the row loop's closing barrier
         float mean[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -591,7 +588,6 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
             for (int w = 0; w < NW; ++w) t += stat[w * G + g];
             mean[g] = t / (float)D;
         }
-        if (!FOLD) lds_barrier();   // (`stat` is rewritten)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float d = tid < D ? xv[g] - mean[g] : 0.f;
@@ -599,19 +595,7 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         }
         if (lane == 0) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) (FOLD ? stat2 : stat)[wave * G + g] = s[g];
-        }
-        if (!FOLD) {
-            lds_barrier();
-            if (tid < D) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) t += stat[w * G + g];
-                    xn_s[g * D + tid] = (xv[g] - mean[g]) * rsqrtf(t / (float)D + a.eps) * lw + lb;
-                }
-            }
+            for (int g = 0; g < G; ++g) stat2[wave * G + g] = s[g];
         }
         AF_TRACE(7);
 #pragma unroll
@@ -620,7 +604,6 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
                 bias_s[tid + 1024 * j] = (kraw[j] || !vis.has_allowed) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
         for (int k = tid + 1024 * BR; k < n; k += 1024)   // sequences longer than 3072: the remainder the plain way
             bias_s[k] = (keep_row[k] || !vis.has_allowed) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
-        if (!FOLD) lds_barrier();
     }
 
     AF_TRACE(1);
@@ -697,12 +680,6 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
         // walk, whose own first loads queue behind them: HBM streams without a gap from the end of the projection on.  ms/step, fp16 cache: fp16 weights 1.029-1.034
         // (between batches 1.031-1.036, all early 1.070, no staging 1.110); fp32 weights 1.197-1.204 (1.225 / 1.203 / 1.241); density 0.35: 0.953 (0.962 / 0.999 / 1.017).
         if (STG) stage_issue();
-        if (!FOLD) {
-            if (lane < 12) {   // this wave's rows (its own LDS stores above: in order)
-#pragma unroll
-                for (int g = 0; g < G; ++g) qkv_s[g * 192 + jb] += c_mine;
-            }
-        } else {
         lds_barrier();   // every wave's raw sums, second-pass statistics and bias row are in LDS
         // fix-up: the wave's own 12 rows (lanes 0..11) and, by the first 64 G threads, the residual ln1(x) of this head's columns into the (now free) row buffer
         if (lane < 12 || tid < 64 * G) {
@@ -715,7 +692,6 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
                 if (lane < 12) qkv_s[g * 192 + jb] = rstd * (qkv_s[g * 192 + jb] - mean * c_mine) + d_mine;
                 if ((tid >> 6) == g) xn_s[g * D + head * 64 + lane] = (xh_s[g * 64 + lane] - mean) * rstd * gh_s[lane] + gh_s[64 + lane];
             }
-        }
         }
     }
     lds_barrier();
@@ -853,7 +829,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     a.Lpad = (int)round_up(a.Lmax, 4);
     const bool pre = a.qkv != nullptr;
     BG_REQUIRE(!pre || a.xn, "decode attention: precomputed q/k/v rows need the ln1(x) rows for the residual");
-    BG_REQUIRE(pre || !a.wqkv_h || (a.ln_cs && a.ln_ds), "fused decode attention: the folded LayerNorm (fp16 weights) needs its row constants (launch_ar_ln_fold)");
+    BG_REQUIRE(pre || (a.ln_cs && a.ln_ds), "fused decode attention: the folded LayerNorm needs its row constants (launch_ar_ln_fold)");
     if (pre) { a.x = RowSrc{}; a.x.base = a.qkv; a.x.ld = 3 * a.D; }
     a.x = rowsrc_fix(a.x);
     a.has_bias = a.bias != nullptr;
