@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from ... import weights as W
 from ...runtime import Context
+from ..options import RuntimeOptionsMixin
 from ..params import ParamNode, build_tree, module_device
 
 
@@ -37,11 +38,13 @@ class VectorQuantizer2(ParamNode):
         return z_q
 
 
-class VQModel(nn.Module):
+class VQModel(RuntimeOptionsMixin, nn.Module):
     def __init__(self, ddconfig, lossconfig=None, n_embed=None, embed_dim=None, cam_res=None, cam_latent_res=None, cam_emd_dim=None,
                  geometric_embedding=False, ckpt_path=None, ignore_keys=(), image_key="image", colorize_nlabels=None, monitor=None, remap=None,
                  sane_index_shape=False, denormalize=True, legacy=True, **kwargs):
         super().__init__()
+        self._ctx: Optional[Context] = None
+        self._init_runtime_options(kwargs)    # precision / weights (bevgen_amd/modules/options.py)
         if geometric_embedding:
             raise NotImplementedError("geometric_embedding=True is not used by the released checkpoints (configs/model/stage_2_argoverse.yaml:8,11)")
         self.ddconfig = dict(ddconfig)
@@ -61,7 +64,6 @@ class VQModel(nn.Module):
                 nn.init.kaiming_uniform_(p, a=5 ** 0.5)
             elif name.endswith("weight"):
                 p.data.fill_(1.0)
-        self._ctx: Optional[Context] = None
         if ckpt_path is not None:
             from ...checkpoint import init_from_ckpt
 
@@ -84,7 +86,7 @@ class VQModel(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("VQModel must live on a ROCm device before decode(); libbevgen_hip has no CPU path")
             ctx = Context(None, vq_ddconfig=self.ddconfig, vq_n_embed=self.n_embed, vq_embed_dim=self.embed_dim,
-                          device=dev.index if dev.index is not None else torch.cuda.current_device())
+                          device=dev.index if dev.index is not None else torch.cuda.current_device(), **self.runtime_options("vq"))
             sd = {k: v for k, v in self.state_dict().items() if k != "colorize"}
             ctx.load_state_dict(sd, prefix="first_stage_model.")
             ctx.finalize()

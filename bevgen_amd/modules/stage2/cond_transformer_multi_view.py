@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from ..options import pop_runtime_options
 from .cond_transformer_multi_view_muse import _Base, denormalize_tensor
 
 log = logging.getLogger(__name__)
@@ -23,21 +24,35 @@ class Net2NetTransformer(_Base):
                  bbox_ce_weight: float = 0.0, reset_random_mask: int = 0, debug_viz: bool = False, partial_decoding: Optional[int] = None,
                  bbox_weight_epoch: int = -1, top_k: Optional[int] = None, warmup_steps: int = 500, lr_decay: bool = False, **kwargs):
         super().__init__()
+        runtime = pop_runtime_options(kwargs)     # precision / weights / kv_cache / decode_weights / decode_path: handed down to the modules that own a Context
         for k, v in kwargs.items():
             if k != "self":
                 setattr(self, k, v)
         if permuter is not None:
             raise NotImplementedError("a non-identity stage-1 permuter is not used by any shipped configuration")
+        if downsample_cond_size > -1:
+            raise NotImplementedError("downsample_cond_size > -1 (ar_lm:253-257: F.interpolate of the condition before the cond-stage encoder) is set by no shipped "
+                                      "configuration and is not implemented; refusing rather than ignoring it")
         self.first_stage_key, self.cond_stage_key = first_stage_key, cond_stage_key
         self.skip_sampling, self.partial_decoding, self.top_k = skip_sampling, partial_decoding, top_k
         self.first_stage_model = first_stage.eval() if first_stage is not None else None
         self.cond_stage_model = cond_stage.eval() if cond_stage is not None else None
         self.transformer = transformer
         self.cfg = transformer.cfg
+        if runtime:
+            self.set_runtime_options(_inherit=True, **runtime)
         if ckpt_path is not None:
             from ...checkpoint import init_from_ckpt
 
             init_from_ckpt(self, ckpt_path, ignore_keys=list(ignore_keys), unfrozen_keys=list(unfrozen_keys))
+
+    def set_runtime_options(self, _inherit: bool = False, **opts):
+        """Modes of the HIP library for the modules this one owns (bevgen_amd/modules/options.py); keys a sub-module was given itself win at construction."""
+        self.transformer.set_runtime_options(inherit=_inherit, **opts)
+        stage1 = {k: v for k, v in opts.items() if k in ("precision", "weights")}
+        for m in (self.first_stage_model, self.cond_stage_model):
+            if m is not None and stage1:
+                m.set_runtime_options(inherit=_inherit, **stage1)
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from ...modules.stage1.vqgan import VQModel
+from ..options import pop_runtime_options
 from .muse_maskgit_pytorch import MaskGit
 
 log = logging.getLogger(__name__)
@@ -49,11 +50,15 @@ class Net2NetTransformer(_Base):
                  partial_decoding: Optional[int] = None, bbox_warmup_steps: int = -1, top_k: Optional[int] = None, warmup_steps: int = 500,
                  lr_decay: bool = False, sample_iterations: int = 18, **kwargs):
         super().__init__()
+        runtime = pop_runtime_options(kwargs)     # precision / weights: handed down to the modules that own a Context (bevgen_amd/modules/options.py)
         for k, v in kwargs.items():
             if k != "self":
                 setattr(self, k, v)
         if permuter is not None:
             raise NotImplementedError("a non-identity stage-1 permuter is not used by any shipped configuration (muse_lm:82-85)")
+        if downsample_cond_size > -1:
+            raise NotImplementedError("downsample_cond_size > -1 (muse_lm:149-152: F.interpolate of the condition before the cond-stage encoder) is set by no shipped "
+                                      "configuration and is not implemented; refusing rather than ignoring it")
         self.first_stage_key, self.cond_stage_key = first_stage_key, cond_stage_key
         self.skip_sampling, self.partial_decoding, self.top_k = skip_sampling, partial_decoding, top_k
         self.sample_iterations = sample_iterations
@@ -62,6 +67,8 @@ class Net2NetTransformer(_Base):
         self.cond_stage_model = cond_stage.eval() if cond_stage is not None else None
         self.cfg = cfg
         self.maskgit = maskgit
+        if runtime:
+            self.set_runtime_options(_inherit=True, **runtime)
         if ckpt_path is not None:
             from ...checkpoint import init_from_ckpt
 
@@ -73,6 +80,13 @@ class Net2NetTransformer(_Base):
 
     def combine_all_images(self, arr):
         return arr.reshape(-1, *arr.shape[2:])
+
+    def set_runtime_options(self, _inherit: bool = False, **opts):
+        """Modes of the HIP library for the modules this one owns (bevgen_amd/modules/options.py); keys a sub-module was given itself win at construction."""
+        opts = {k: v for k, v in opts.items() if k in ("precision", "weights")}
+        for m in (self.maskgit, self.first_stage_model, self.cond_stage_model):
+            if m is not None and opts:
+                m.set_runtime_options(inherit=_inherit, **opts)
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)

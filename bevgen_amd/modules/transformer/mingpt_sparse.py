@@ -18,12 +18,19 @@ from ... import weights as W
 from ...config import Cameras, Dataset, GPTConfig  # noqa: F401  (re-exported for the YAML `_target_`)
 from ...runtime import Context
 from ...tables import generate_grid, get_bev_grid  # noqa: F401
+from ..options import RuntimeOptionsMixin
 from ..params import build_tree, module_device
 
 
-class GPT(nn.Module):
+class GPT(RuntimeOptionsMixin, nn.Module):
+    """``GPT(cfg, **kwargs)`` (gpt:270).  Keys of ``kwargs`` this drop-in understands (next to the ``_target_`` in configs/model/stage_2.yaml:7-9, or
+    ``+model.transformer.kv_cache=f16`` on the command line): ``precision``, ``weights``, ``kv_cache``, ``decode_weights``, ``decode_path`` - see
+    bevgen_amd/modules/options.py; unset keys fall back to $BEVGEN_* and then to the bit-exact defaults (fp32 KV cache, fp32 decode weights)."""
+
     def __init__(self, cfg: GPTConfig, **kwargs):
         super().__init__()
+        self._ctx: Optional[Context] = None
+        self._init_runtime_options(kwargs)
         self.cfg = cfg
         if cfg.hidden_size // cfg.num_heads != 64 or cfg.hidden_size != cfg.num_embed:
             raise ValueError("libbevgen_hip needs hidden_size == num_embed and hidden_size / num_heads == 64")
@@ -39,7 +46,6 @@ class GPT(nn.Module):
         for name, b in self.named_buffers():
             if name.endswith("master_layout"):
                 b.copy_(cfg.layout)
-        self._ctx: Optional[Context] = None
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
@@ -56,7 +62,7 @@ class GPT(nn.Module):
             dev = module_device(self)
             if dev.type != "cuda":
                 raise RuntimeError("GPT must live on a ROCm device before sampling; libbevgen_hip has no CPU path")
-            ctx = Context(self.cfg, route="ar", device=dev.index if dev.index is not None else torch.cuda.current_device())
+            ctx = Context(self.cfg, route="ar", device=dev.index if dev.index is not None else torch.cuda.current_device(), **self.runtime_options("ar"))
             # every blocks.{i}...master_layout buffer travels as int64: the reference draws one layout PER attention layer when density < 1
             # (gpt:176, maskgen:217-251) and finalize_ar reads each layer's own buffer (csrc/context.cpp); table.layout only backs absent ones
             sd = self.state_dict()

@@ -52,7 +52,7 @@ class Context:
     """Owns a ``bevgen_ctx`` (weights, KV cache, workspace live on the device inside it)."""
 
     def __init__(self, cfg=None, *, route: str = "maskgit", vq_ddconfig: Optional[Mapping] = None, vq_n_embed: int = 0, vq_embed_dim: int = 0,
-                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: str = "f32", decode_path: str = "auto", decode_weights: str = "f32",
+                 device: Optional[int] = None, max_batch: int = 0, precision: Optional[str] = None, kv_cache: Optional[str] = None, decode_path: Optional[str] = None, decode_weights: Optional[str] = None,
                  weights: Optional[str] = None, decode_chains: Optional[int] = None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
@@ -63,8 +63,16 @@ class Context:
         c = bevgen_cfg()
         c.abi_version = _lib.ABI_VERSION
         c.route = _lib.ROUTE_MASKGIT if route == "maskgit" else _lib.ROUTE_AR
-        # arithmetic mode of the matrix products: explicit argument, else $BEVGEN_PRECISION (how the drop-in modules are switched), else exact fp32
-        precision = precision or os.environ.get("BEVGEN_PRECISION", "fp32")
+        # every mode: explicit argument, else its environment variable, else this low-level class's default (exact fp32 everywhere; the drop-in modules
+        # resolve their own defaults - f16x3 products - in bevgen_amd/modules/options.py and always pass explicit values)
+        precision = precision or os.environ.get("BEVGEN_PRECISION") or "fp32"
+        kv_cache = kv_cache or os.environ.get("BEVGEN_KV_CACHE") or "f32"
+        decode_path = decode_path or os.environ.get("BEVGEN_DECODE_PATH") or "auto"
+        decode_weights = decode_weights or os.environ.get("BEVGEN_DECODE_WEIGHTS") or "f32"
+        for key, val, ok in (("kv_cache", kv_cache, ("f32", "f16")), ("decode_path", decode_path, ("auto", "fused", "split", "per_op")),
+                             ("decode_weights", decode_weights, ("f32", "f16"))):
+            if val not in ok:
+                raise ValueError(f"{key} must be one of {ok}, got {val!r}")
         if precision not in ("fp32", "f16x3"):
             raise ValueError(f"precision must be 'fp32' or 'f16x3', got {precision!r}")
         self.precision = precision
@@ -84,7 +92,9 @@ class Context:
         # Route A fused decode step: number of independent sequence groups enqueued on separate streams (0 = the library's choice; $BEVGEN_DECODE_CHAINS)
         c.decode_chains = int(os.environ.get("BEVGEN_DECODE_CHAINS", "0")) if decode_chains is None else int(decode_chains)
         # weights='f16' (or $BEVGEN_WEIGHTS): the GEMM / convolution matrices are rounded to f16 at finalize - two MFMAs per product instead of three
-        weights = weights or os.environ.get("BEVGEN_WEIGHTS", "f32")
+        weights = weights or os.environ.get("BEVGEN_WEIGHTS") or "f32"
+        if weights not in ("f32", "f16"):
+            raise ValueError(f"weights must be 'f32' or 'f16', got {weights!r}")
         c.weight_dtype = {"f32": _lib.W_F32, "f16": _lib.W_F16}[weights]
         self.weights = weights
         if cfg is not None:

@@ -243,3 +243,75 @@ def test_maskgit_dropin_generate_without_token_critic():
     bare = build(False)   # no critic at all: use_token_critic is False without the flag (muse_net:553)
     x = bare.generate(cond_images=cond, fmap_size=cfg.cam_latent_res, batch=batch, timesteps=case.timesteps, noise="greedy").cpu()
     assert torch.equal(x, torch.from_numpy(g["gen_nocritic_greedy"]).long())
+
+
+def test_net2net_sample_in_the_fp16_decode_mode_through_the_dropin_boundary(monkeypatch):
+    """The benchmarked decode mode (fp16 KV cache + fp16 decode weights, fused layer) is reachable from the reference's plugin boundary: as constructor keys next to the
+    `_target_` (GPT(cfg, **kwargs), gpt:270 / Net2NetTransformer(..., **kwargs), ar_lm:55) and by $BEVGEN_KV_CACHE / $BEVGEN_DECODE_WEIGHTS.  Tokens through
+    Net2NetTransformer.sample (ar_lm:154-227) = the tokens of a Context built directly in that mode = the rounded-weights oracle's up to the first near-tie."""
+    from bevgen_amd.modules import options as O
+    from bevgen_amd.modules.stage2.cond_transformer_multi_view import Net2NetTransformer
+    from bevgen_amd.modules.transformer.mingpt_sparse import GPT
+    from bevgen_amd.runtime import Context
+
+    for v in O.ENV.values():
+        monkeypatch.delenv(v, raising=False)
+    cfg = presets.route_a(3, num_layers=2, dim=256, heads=4, vocab=64, cam_res=(64, 64), cam_latent_res=(4, 5), bev_latent_res=(4, 4), block=16, window_len=8)
+    sd = W.gpt_state_dict(cfg, 1234)
+    B = 3
+    bt = synthetic.make_batch(cfg, B, seed=3)
+    batch = {"intrinsics_inv": bt["intrinsics_inv"].cuda(), "extrinsics_inv": bt["extrinsics_inv"].cuda()}
+    direct = Context(cfg, route="ar", precision="f16x3", kv_cache="f16", decode_weights="f16", decode_path="fused")
+    direct.load_state_dict(sd)
+    direct.set_tables()
+    direct.finalize()
+    want = direct.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], greedy=True).cpu()
+    direct.close()
+
+    # (1) keys on the outer module, as `+model.kv_cache=f16 +model.decode_weights=f16 +model.decode_path=fused` would put them
+    gpt = GPT(cfg)
+    gpt.load_state_dict(sd)
+    model = Net2NetTransformer(gpt.to("cuda"), None, None, kv_cache="f16", decode_weights="f16", decode_path="fused")
+    x = model.sample(None, bt["cond_ids"].cuda(), batch, sample=False).cpu()
+    c = gpt.context()
+    assert (c.kv_cache, c.decode_weights, c.decode_path, c.precision) == ("f16", "f16", "fused", "f16x3")
+    assert torch.equal(x, want)
+    # (2) keys on the transformer's own `_target_` node
+    gpt2 = GPT(cfg, kv_cache="f16", decode_weights="f16", decode_path="fused")
+    gpt2.load_state_dict(sd)
+    x2 = Net2NetTransformer(gpt2.to("cuda"), None, None).sample(None, bt["cond_ids"].cuda(), batch, sample=False).cpu()
+    assert torch.equal(x2, want)
+    # (3) process-wide by environment
+    monkeypatch.setenv("BEVGEN_KV_CACHE", "f16")
+    monkeypatch.setenv("BEVGEN_DECODE_WEIGHTS", "f16")
+    monkeypatch.setenv("BEVGEN_DECODE_PATH", "fused")
+    gpt3 = GPT(cfg)
+    gpt3.load_state_dict(sd)
+    x3 = Net2NetTransformer(gpt3.to("cuda"), None, None).sample(None, bt["cond_ids"].cuda(), batch, sample=False).cpu()
+    assert gpt3.context().kv_cache == "f16" and torch.equal(x3, want)
+    # and the mode is the rounded-weights model: with the fp32 cache the oracle on the rounded state_dict is reproduced token for token
+    sdr = dict(sd)
+    for k, v in sd.items():
+        if k == "head.weight" or (k.startswith("blocks.") and k.endswith(".weight") and any(t in k for t in (".attention.query.", ".attention.key.", ".attention.value.", ".mlp.0.", ".mlp.2."))):
+            sdr[k] = v.half().float()
+    model.set_runtime_options(kv_cache="f32")
+    xe = model.sample(None, bt["cond_ids"].cuda(), batch, sample=False).cpu()
+    assert gpt.context().kv_cache == "f32"
+    assert torch.equal(xe, R.ar_sample_cached(sdr, cfg, bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"]))
+
+
+def test_dropin_default_precision_is_the_benchmarked_one(monkeypatch):
+    """The drop-in modules default to the split-precision products (f16x3: the mode bench.py's headline runs in; token-exact on every fixture); the exact fp32 MFMA mode
+    is `precision: fp32` / $BEVGEN_PRECISION=fp32."""
+    from bevgen_amd.modules import options as O
+    from bevgen_amd.modules.stage2.muse_maskgit_pytorch import MaskGit, MaskGitTransformerMultiView
+
+    for v in O.ENV.values():
+        monkeypatch.delenv(v, raising=False)
+    cfg = presets.tiny_route_m(3, legacy=False, latent=(8, 8))
+    tr = MaskGitTransformerMultiView(num_tokens=cfg.vocab_size, dim=cfg.num_embed, seq_len=cfg.cam_latent_res, depth=cfg.num_layers, dim_head=64,
+                                     heads=cfg.num_heads, ff_mult=4, cfg=cfg)
+    mg = MaskGit(image_size=cfg.cam_latent_res, transformer=tr, self_token_critic=True).to("cuda")
+    assert mg.context().precision == "f16x3"
+    mg.set_runtime_options(precision="fp32")
+    assert mg.context().precision == "fp32"
