@@ -391,8 +391,10 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
                                       "frac_by_survey_8d_fp16_bytes": ach / HBM_PEAK_GBS * (2.0 / kvb),   # SURVEY 8(d) counts 98 304 n bytes per sequence-step (fp16 K/V) whatever the storage
 
                                       "traffic": pmc_traffic("ar_attn_fused_kernel") if kv_cache == "f32" and weights == "f32" and S == 1 else None, "kernel": "ar_attn_fused_kernel (ln1 + q/k/v projection + decode attention in one launch; achieved = K/V bytes / WHOLE kernel time)",
-                                      "attention_phase": {"GBs": phase_bytes / (phase_us * 1e-6) / 1e9 if phase_us else None, "frac": phase_bytes / (phase_us * 1e-6) / 1e9 / HBM_PEAK_GBS if phase_us else None,
-                                                          "us": phase_us, "context": n_last, "note": "K/V streaming phase alone, device timestamps of one launch"},
+                                      # (no bandwidth is derived from this window any more: since the K/V staging, the leading pieces of every wave's key walk are requested
+                                      #  by LDS-DMA during the prologue, i.e. BEFORE the window's first timestamp - bytes / window came out above the HBM peak)
+                                      "attention_phase": {"us": phase_us, "context": n_last, "kv_bytes_of_the_launch": phase_bytes, "staged_pieces_per_wave": "up to 8 x 1 KiB, requested before the window opens",
+                                                          "note": "duration of the key-walk phase alone (device timestamps of the last launch); a duration, not a bandwidth"},
                                       "launches": int(da["launches"]), "avg_us": da["ms"] * 1e3 / max(da["launches"], 1),
                                       "config": f"Route A config4: B={batch}, H=16, all contexts 257..{256 + steps} of the decode, {kv_cache} KV cache, {weights} projection weights, L=2368" + (f", {S} samples per layout (shared prefix read once per group)" if S > 1 else "")},
         "decode_step_roofline": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_ach / HBM_PEAK_GBS,
@@ -655,6 +657,17 @@ def main():
         e1, _, p1, _ = run_route_m(args.precision, 3, 1, args.cams, 1)
         line["single_scene_latency"] = {"value": e1 * 1e3 / 3, "unit": "ms per scene", "higher_is_better": False, "ms_per_maskgit_iteration": float(np.mean(p1["generate"])) / args.timesteps,
                                         "config": f"Route M, {args.cams}x256x256, batch 1, 3 steps"}
+    if world == 1 and (DRY_RUN or not args.no_extra_legs) and args.batch == 16:
+        # No multi-GPU node has been available to builder or driver: the 16-scene STRONG-scaling leg at N GPUs puts 16 / N scenes on each GPU with no data-path
+        # collective, so one GPU running batch 16 / N is that leg's per-GPU load.  prediction(N) = N x scenes/s at batch 16 / N (an upper bound: the gather of 19 MB
+        # of uint8 pixels to rank 0 and launch skew come on top); N = 1 is the headline itself.
+        proxy = {}
+        for n in (2, 4, 8):
+            ep, _, pp, _ = run_route_m(args.precision, 2, 1, args.cams, 16 // n)
+            proxy[str(n)] = {"scenes_per_gpu": 16 // n, "single_gpu_scenes_per_s": (16 // n) * 2 / ep, "ms_per_step": ep * 1e3 / 2, "predicted_strong_scaling_scenes_per_s": n * (16 // n) * 2 / ep}
+        line["strong_scaling_single_gpu_proxy"] = {"by_n_gpus": proxy, "weak_scaling_prediction_scenes_per_s": {str(n): n * scenes / elapsed for n in (2, 4, 8)},
+                                                   "note": "measured on ONE GPU at the per-GPU batch of the N-GPU strong leg (16 scenes in total); scene-parallel with one final gather, so N x this is "
+                                                           "the stated prediction until a node exists; weak scaling (16 scenes per GPU) predicts N x the headline"}
     dkeys = ("ms_per_decode_step", "ms_per_decode_step_median", "ms_per_decode_step_p99", "decode_scenes_per_s", "roofline_decode_attention", "decode_step_roofline", "visible_fraction_of_causal_keys")
     if world == 1 and not args.no_decode_leg:
         line.update(decode_leg(local_rank, args.decode_batch, args.decode_steps))
@@ -664,6 +677,9 @@ def main():
         # ... and the all-fp16-storage model (projection weights rounded to fp16 at load, tokens bit-exact vs the oracle on the rounded weights; fp32 arithmetic)
         h16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f16", weights="f16")
         line["decode_f16_kv_cache_f16_weights"] = {k: h16[k] for k in dkeys}
+        # ... and fp32 KV cache + fp16 weights: BIT-EXACT greedy tokens vs the oracle on the rounded weights (tests) with the 2-byte weight stream
+        e16 = decode_leg(local_rank, args.decode_batch, args.decode_steps, kv_cache="f32", weights="f16")
+        line["decode_f32_kv_cache_f16_weights"] = {k: e16[k] for k in dkeys}
         # the same kernel timed on the PRODUCT path (hipGraph replay) by a rocprofv3 --kernel-trace child pass: the cross-check of the HIP-event figure above
         if not DRY_RUN and os.environ.get("BEVGEN_BENCH_NO_PMC") != "1":
             try:
@@ -675,6 +691,10 @@ def main():
             except Exception as e:
                 kt = {"error": f"{type(e).__name__}: {e}"}
             ra = line["decode_f16_kv_cache_f16_weights"]["roofline_decode_attention"]
+            try:
+                ra["traffic_inrun"] = ktrace_inrun.measure_traffic("ar_attn_fused_kernel", args.decode_batch, 16, "f16", "f16", timeout=150)
+            except Exception as e:
+                ra["traffic_inrun"] = {"error": f"{type(e).__name__}: {e}"}
             if "error" not in kt:
                 cfg4 = _presets.config4()
                 kvb, _ = route_a_bytes(cfg4, args.decode_batch, steps_kt, 2, 1, 2)
@@ -724,16 +744,34 @@ def main():
         c = detail["cpu_baseline"]
         short["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
                                  "sample": f"1 scene end to end, {c['sample'].split('MaskGit generate with ')[1].split(' =')[0]} of {args.timesteps} scaled linearly, {c['host']['threads_used']} torch threads on {c['host']['cpu_model']}"[:118]}
-    short["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
-
     def rnd(x, n=4):
         return None if x is None else round(float(x), n)
+
+    # the HBM roofline the north star names (decode attention, BASELINE config 4, fp16 storage), a first-class sibling of `roofline`
+    hd = detail.get("decode_f16_kv_cache_f16_weights")
+    if hd is not None:
+        ra = hd["roofline_decode_attention"]
+        kt = ra.get("kernel_trace") if isinstance(ra.get("kernel_trace"), dict) and "avg_us" in ra.get("kernel_trace", {}) else None
+        tr = ra.get("traffic_inrun") or {}
+        short["roofline_decode_attention"] = {
+            "bound": "hbm", "kernel": "ar_attn_fused_kernel<kv=f16, G=1, w=f16> (ln1 + q/k/v projection + decode attention; K/V bytes / WHOLE kernel time)",
+            "achieved": rnd(ra["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rnd(ra["frac"]), "launches": ra["launches"], "avg_us": rnd(ra["avg_us"], 2),
+            "traffic": tr.get("bytes_per_launch"), "traffic_over_algorithmic": rnd(tr.get("traffic_over_algorithmic")), "traffic_context": tr.get("context"),
+            "trace_avg_us": rnd(kt["avg_us"], 2) if kt else None, "trace_frac": rnd(kt["frac_by_survey_8d_fp16_bytes"]) if kt else None,
+            "workload": "BASELINE configs[3]: Route A, 6 x 224x400, 24 layers, L=2368, B=16, all contexts of the 2100-token decode; achieved = SURVEY 8(d) bytes (4096 n per "
+                        "sequence-layer) / HIP-event time attached to each launch; trace_* = rocprofv3 kernel trace of the replayed graph; whole step: legs.decode_config4_B16.f16_kv_f16_w.step_frac"}
+        if "error" in tr:
+            short["roofline_decode_attention"]["traffic_note"] = str(tr["error"])[:100]
+    elif DRY_RUN:
+        short["roofline_decode_attention"] = {"bound": "hbm", "kernel": "ar_attn_fused_kernel<kv=f16, G=1, w=f16>", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                                              "launches": 0, "avg_us": None, "traffic": None}
+    short["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
 
     def dshort(d):
         ra, rs = d["roofline_decode_attention"], d["decode_step_roofline"]
         return {"ms_step": rnd(d["ms_per_decode_step"]), "median": rnd(d["ms_per_decode_step_median"]), "p99": rnd(d["ms_per_decode_step_p99"]),
                 "attn_frac_8d_fp16_bytes": rnd(ra.get("frac_by_survey_8d_fp16_bytes")), "attn_frac_storage_bytes": rnd(ra["frac"]), "attn_avg_us": rnd(ra["avg_us"], 2),
-                "attn_phase_frac": rnd(ra["attention_phase"]["frac"]), "step_frac": rnd(rs["frac"]),
+                "attn_walk_phase_us": rnd(ra["attention_phase"]["us"], 2), "step_frac": rnd(rs["frac"]),
                 **({"attn_trace_avg_us": rnd(ra["kernel_trace"]["avg_us"], 2), "attn_trace_frac_8d_fp16_bytes": rnd(ra["kernel_trace"]["frac_by_survey_8d_fp16_bytes"])}
                    if isinstance(ra.get("kernel_trace"), dict) and "avg_us" in ra["kernel_trace"] else {})}
 
@@ -745,6 +783,11 @@ def main():
     if c5_multi is not None:
         legs["config5"] = {"sequences_per_s": rnd(c5_multi["sequences_per_s"], 2), "ms_per_decode_step": rnd(c5_multi["ms_per_decode_step"]), "sequences_per_gpu": 64, "decode_steps": c5_multi["decode_steps"],
                            "per_rank_ms_per_decode_step": [rnd(x) for x in c5_multi["per_rank_ms_per_decode_step"]]}
+    if "strong_scaling_single_gpu_proxy" in detail:
+        px = detail["strong_scaling_single_gpu_proxy"]
+        legs["scaling_prediction_from_one_gpu"] = {"strong_16_scenes": {n: rnd(v["predicted_strong_scaling_scenes_per_s"], 2) for n, v in px["by_n_gpus"].items()},
+                                                   "per_gpu_scenes_per_s_at_batch": {str(v["scenes_per_gpu"]): rnd(v["single_gpu_scenes_per_s"], 3) for v in px["by_n_gpus"].values()},
+                                                   "weak_16_per_gpu": {n: rnd(v, 2) for n, v in px["weak_scaling_prediction_scenes_per_s"].items()}}
     if "single_scene_latency" in detail:
         legs["single_scene_latency_ms"] = rnd(detail["single_scene_latency"]["value"], 2)
     if "released_3_camera_shape" in detail:
@@ -755,7 +798,7 @@ def main():
         legs["f16_weights"] = {"scenes_per_s": rnd(detail["f16_weights_mode"]["value"], 3), "gemm_frac": rnd(detail["f16_weights_mode"]["roofline"]["frac"], 3)}
     if "ms_per_decode_step" in detail:
         legs["decode_config4_B16"] = {"f32_kv": dshort(detail), "prefill_ms": rnd(detail["decode_prefill_ms"], 2)}
-        for name, key in (("f16_kv", "decode_f16_kv_cache"), ("f16_kv_f16_w", "decode_f16_kv_cache_f16_weights"), ("density035_f16_kv", "decode_density_035_f16_kv_cache"), ("density035_f16_kv_f16_w", "decode_density_035_f16_kv_cache_f16_weights"),
+        for name, key in (("f16_kv", "decode_f16_kv_cache"), ("f32_kv_f16_w", "decode_f32_kv_cache_f16_weights"), ("f16_kv_f16_w", "decode_f16_kv_cache_f16_weights"), ("density035_f16_kv", "decode_density_035_f16_kv_cache"), ("density035_f16_kv_f16_w", "decode_density_035_f16_kv_cache_f16_weights"),
                           ("split_path_f16_kv_f16_w", "decode_split_path_f16_kv_cache_f16_weights")):
             if key in detail:
                 legs["decode_config4_B16"][name] = dshort(detail[key])

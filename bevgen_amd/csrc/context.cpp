@@ -197,6 +197,11 @@ static void finalize_muse(Ctx& c) {
         if (g.precision == BEVGEN_PRECISION_F16X3) {
             l.null_self = c.own((size_t)4 * H * 64 * sizeof(_Float16));
             launch_muse_null_kv_prep(l.null_kv[0], l.k_scale[0], l.null_self, H, 0);
+            // to_q | to_kv of the self-attention (muse_net:126-132: both read LayerNorm(x)) as one matrix: one projection per layer instead of two
+            l.to_qkv_self = reinterpret_cast<float*>(c.own((size_t)3 * inner * D * sizeof(float)));
+            HIP_CHECK(hipMemcpy(l.to_qkv_self, l.to_q[0], (size_t)inner * D * sizeof(float), hipMemcpyDeviceToDevice));
+            HIP_CHECK(hipMemcpy(l.to_qkv_self + (size_t)inner * D, l.to_kv[0], (size_t)2 * inner * D * sizeof(float), hipMemcpyDeviceToDevice));
+            c.split_weight(l.to_qkv_self, 3L * inner * D);
         }
         if (g.precision == BEVGEN_PRECISION_F16X3 && c.Fpad % 64 == 0) {
             l.ff_w1_geglu = reinterpret_cast<float*>(c.own((size_t)2 * c.Fpad * D * sizeof(float)));
@@ -277,9 +282,11 @@ static void finalize_ar(Ctx& c) {
             l.mlp0_ds = reinterpret_cast<float*>(c.own((size_t)4 * D * sizeof(float)));
             launch_ar_ln_fold(l.mlp0_w, l.mlp0_b, l.ln2_w, l.ln2_b, l.mlp0_cs, l.mlp0_ds, 4 * D, D, 0);
             const size_t eb = wf16 ? sizeof(_Float16) : sizeof(float);
-            // decode_path = split packs the QKV operand image now; auto packs it on the first call that resolves to the split layer (ctx_pack_split_qkv:
-            // 3 D D elements per layer, ~300 MB at config 4 in fp32, that a context whose calls all carry more than four sequences never needs)
-            if (g.decode_path == BEVGEN_DECODE_SPLIT) pack_split_qkv_layer(c, l, 0);
+            // The split layer's QKV operand image (3 D D elements per layer, ~300 MB at config 4 in fp32) is packed NOW - at load time, where allocation failures
+            // belong and no timed region is open - for decode_path = split and for auto unless the context was created for batches the auto rule never sends down
+            // the split layer (cfg.max_batch > 4).  Only such a context, when it is later called with <= 4 sequences after all, packs on that first call
+            // (ctx_pack_split_qkv: one allocation per layer + one stream synchronisation, once per context; documented in include/bevgen_hip.h)
+            if (g.decode_path == BEVGEN_DECODE_SPLIT || (g.decode_path == BEVGEN_DECODE_AUTO && g.max_batch <= 4)) pack_split_qkv_layer(c, l, 0);
             l.mlp0_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(4 * D, D) * eb));
             l.mlp2_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(D, 4 * D) * eb));
             if (wf16) {
@@ -368,7 +375,13 @@ static void finalize_ar(Ctx& c) {
 
 void ctx_pack_split_qkv(Ctx& c, hipStream_t s) {
     if (c.ar.empty() || c.ar[0].wqkv_wp) return;
-    for (ArLayer& l : c.ar) pack_split_qkv_layer(c, l, s);
+    try {
+        for (ArLayer& l : c.ar) pack_split_qkv_layer(c, l, s);
+    } catch (const std::exception& e) {
+        for (ArLayer& l : c.ar) l.wqkv_wp = nullptr;   // (buffers already taken stay in c.owned and are freed with the context)
+        BG_REQUIRE(false, "decode_path = auto: packing the split decode layer's q/k/v operand image on the first call with <= 4 sequences failed (%s); create the context "
+                          "with max_batch <= 4 or decode_path = split to take this memory at bevgen_finalize instead", e.what());
+    }
     HIP_CHECK(hipStreamSynchronize(s));   // once per context, before the first split-path step is captured
 }
 

@@ -17,6 +17,7 @@
 //
 // Shared condition prefix (BASELINE config 5, several samples per BEV layout): a workgroup serves the G sequences of one layout
 // and one head; the K prefix rows are streamed ONCE and scored against the G queries, the private suffixes are split over wave teams.
+#include <atomic>
 #include <hip/hip_ext.h>
 #include <type_traits>
 
@@ -789,16 +790,25 @@ size_t ar_attn_fused_lds_bytes(int G, int D, int Lpad) {
            1024;   // (+ 1 KiB of slack)
 }
 
-// LDS a workgroup may allocate on this device (gfx950: 160 KB), queried once
+// LDS a workgroup may allocate on the CURRENT device (gfx950: 160 KB), queried once per device: one process may drive contexts on several GPUs, and both this limit
+// and the > 64 KB opt-in below (hipFuncSetAttribute) are per-device state
+constexpr int MAX_DEVICES = 64;
+static int current_device_slot() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < MAX_DEVICES ? dev : 0;
+}
 size_t ar_attn_fused_max_lds() {
-    static size_t v = 0;
-    if (!v) {
-        int dev = 0, optin = 0;
-        (void)hipGetDevice(&dev);
+    static std::atomic<size_t> v[MAX_DEVICES];
+    const int dev = current_device_slot();
+    size_t got = v[dev].load(std::memory_order_relaxed);
+    if (!got) {
+        int optin = 0;
         if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || optin <= 0) optin = 64 * 1024;
-        v = (size_t)optin;
+        got = (size_t)optin;
+        v[dev].store(got, std::memory_order_relaxed);
     }
-    return v;
+    return got;
 }
 
 __global__ __launch_bounds__(256) void ar_ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -858,12 +868,15 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     const double n_host = a.d_n ? a.n + a.n_hint : a.n;
     const double eb = a.kv_dtype == 0 ? 4 : 2;
     const double pfx = a.G > 1 ? (double)a.prefix : 0.0;
-    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pfx) + (double)(a.B / a.G) * pfx), s, a.ksplit == 1);   // (one launch: events attached to it)
     // SP instantiations only when a layout hides something (density < 1): chunk lists are then always present (context.cpp / the operator entry build both)
     const bool sp = a.vis.has_chunks;
     BG_REQUIRE(sp || !a.vis.has_lay, "fused decode attention: a block layout needs its chunk lists");
-    // (more than 64 KB of dynamic LDS has to be allowed per kernel function, once)
-#define AF_LAUNCH1(K) do { static bool big = false; if (lds > 64 * 1024 && !big) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ar_attn_fused_max_lds() - 1024)); big = true; } \
+    BG_REQUIRE(pre || !a.wqkv_h || a.D % 8 == 0, "fused decode attention: fp16 weights need D %% 8 == 0");
+    // (every argument check is above: a ProfScope whose launch never happens would leave an unrecorded event pair behind)
+    ProfScope prof(PROF_DECODE_ATTN, 2.0 * a.H * 64 * eb * ((double)a.B * (n_host - pfx) + (double)(a.B / a.G) * pfx), s, a.ksplit == 1);   // (one launch: events attached to it)
+    const int dev_slot = current_device_slot();
+    // (more than 64 KB of dynamic LDS has to be allowed per kernel function AND per device, once each; the flags are atomics: contexts may launch from several host threads)
+#define AF_LAUNCH1(K) do { static std::atomic<bool> big[MAX_DEVICES]; if (lds > 64 * 1024 && !big[dev_slot].load(std::memory_order_acquire)) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ar_attn_fused_max_lds() - 1024)); big[dev_slot].store(true, std::memory_order_release); } \
                            if (prof.attached()) hipExtLaunchKernelGGL(K, grid, dim3(1024), lds, s, prof.ev_a(), prof.ev_b(), 0, a); \
                            else hipLaunchKernelGGL(K, grid, dim3(1024), lds, s, a); } while (0)
 #define AF_LAUNCH(DT, GG, WW) do { if (sp) AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, true>)); else AF_LAUNCH1((ar_attn_fused_kernel<DT, GG, WW, false>)); } while (0)
@@ -878,7 +891,6 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
 #undef AP_LAUNCH
 #undef AP_LAUNCH1
     } else if (a.wqkv_h) {
-        BG_REQUIRE(a.D % 8 == 0, "fused decode attention: fp16 weights need D %% 8 == 0");
         if (a.kv_dtype == 0) AF_LAUNCH_G(0, 1); else AF_LAUNCH_G(1, 1);
     } else {
         if (a.kv_dtype == 0) AF_LAUNCH_G(0, 0); else AF_LAUNCH_G(1, 0);
@@ -1253,8 +1265,8 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     const bool fd = g.ln_cs != nullptr;
     BG_REQUIRE(!fd || (ln && !rs && g.ln_ds && g.K <= 1024), "skinny_fused: the folded LayerNorm needs the plain-A LayerNorm form and both row constants");
     dim3 grid(cdiv(g.N, 16), g.ksplit);
-    ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s, !rs || g.M <= 16);   // work = algorithmic bytes; one launch: events attached to it
     if (g.w_f16) BG_REQUIRE((g.K / g.ksplit) % (SF_WAVES * 32) == 0, "skinny_fused: fp16 weights need a K slice that is a multiple of %d (K=%d, ksplit=%d)", SF_WAVES * 32, g.K, g.ksplit);
+    ProfScope prof(PROF_GEMM_SKINNY, (double)g.N * g.K * (g.w_f16 ? 2 : 4) + ((double)g.M * g.K + (double)g.M * g.N) * sizeof(float), s, !rs || g.M <= 16);   // work = algorithmic bytes; one launch: events attached to it
 #define SF_LAUNCH(K, ARGS) do { if (prof.attached()) hipExtLaunchKernelGGL(K, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, ARGS); \
                                 else hipLaunchKernelGGL(K, grid, dim3(SF_WAVES * 64), 0, s, ARGS); } while (0)
     if (rs) {   // 16 rows per launch

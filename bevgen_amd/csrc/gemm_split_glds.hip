@@ -282,12 +282,14 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
     if constexpr (TJ == 2) {   // the fused epilogues and the split-K partial store assume 64-column wave patches
-    if (g.epi == EPI_MUSE_Q) {
+    const bool qkv = MODE == MODE_PLAIN && g.epi == EPI_MUSE_QKV;
+    if (g.epi == EPI_MUSE_Q || (qkv && n0 + wn * 64 < g.epi_heads * 64)) {
         // Route M query preparation fused into the to_q projection (muse_net:132-137; replaces muse_q_prep_split): the wave's 64 columns are
         // exactly one head, so q = l2norm(8 x) * q_scale is a per-lane reduction over its 32 registers plus one lane-half exchange; the
         // result leaves as the (hi, lo) f16 planes [B, H, Nq, 64] the attention kernel reads.
-        _Float16* Qh = reinterpret_cast<_Float16*>(g.epi_hi);
-        _Float16* Ql = reinterpret_cast<_Float16*>(g.epi_lo);
+        _Float16* Qh = reinterpret_cast<_Float16*>(qkv ? g.epi_qh : g.epi_hi);
+        _Float16* Ql = reinterpret_cast<_Float16*>(qkv ? g.epi_ql : g.epi_lo);
+        const float* qsc = qkv ? g.epi_qscale : g.epi_scale;
         const int head = (n0 + wn * 64) >> 6;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int d = j * 32 + 8 * qq + 4 * h;
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(g.epi_scale + d);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(qsc + d);
                     half4_t hi4, lo4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -325,12 +327,12 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
         }
         return;
     }
-    if (MODE == MODE_PLAIN && g.epi == EPI_MUSE_KV) {
+    if (MODE == MODE_PLAIN && (g.epi == EPI_MUSE_KV || qkv)) {
         // Route M key / value preparation fused into the to_kv projection (muse_net:132-146; replaces muse_kv_prep_split and its pass over the raw projection):
         // the wave's 64 columns are one head of k (columns < H*64) or of v.  k: l2norm (eps 1e-12) * k_scale, hi/lo planes [B, H, ld, 64] at key row 1 + token.
         // v: hi/lo planes written TRANSPOSED [B, H, 64, ld] (column 1 + token): 32 consecutive tokens of a lane half are 64 contiguous bytes.
         const int HD = g.epi_heads * 64;
-        const int ncol = n0 + wn * 64;
+        const int ncol = n0 + wn * 64 - (qkv ? HD : 0);   // (q | k | v: the k / v columns start behind the H 64 query columns)
         const bool is_v = ncol >= HD;
         const int head = (is_v ? ncol - HD : ncol) >> 6;
         const _Float16* aux = reinterpret_cast<const _Float16*>(g.epi_aux);
@@ -504,10 +506,17 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     if (g.epi == EPI_GEGLU)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % GBN == 0 && (g.ldc % 4 == 0 && g.ldc >= g.N / 2) && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE,
                    "gemm_split_glds: bad fused GEGLU arguments (N=%d ldc=%d)", g.N, g.ldc);
+    if (g.epi == EPI_MUSE_QKV)
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.N == 3 * g.epi_heads * 64 && g.epi_hi && g.epi_lo && g.epi_hi2 && g.epi_lo2 && g.epi_aux && g.epi_scale && g.epi_qh && g.epi_ql &&
+                       g.epi_qscale && g.epi_rows > 0 && g.epi_ld >= g.epi_rows + 1 && !g.R && !g.bias_n && !g.bias_m && g.act == ACT_NONE &&
+                       (g.no_row_split || g.M % g.epi_rows == 0) && g.ksplit <= 1,
+                   "gemm_split_glds: bad fused q/k/v-preparation arguments");
     if (g.epi == EPI_MUSE_Q)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");
     g.tile_band = 4;   // band height of the XCD-aware tile order (measured optimum for 256 x 128 tiles)
+    static const int band_env = getenv("BEVGEN_GEMM_BAND") ? atoi(getenv("BEVGEN_GEMM_BAND")) : 0;   // A/B switch (tools/ab.sh m env BEVGEN_GEMM_BAND=2,4,8)
+    if (band_env > 0) g.tile_band = band_env;
     static const int force_wm = getenv("BEVGEN_GEMM_WM") ? atoi(getenv("BEVGEN_GEMM_WM")) : 0;   // 2 | 4: pins the block rows (128 | 256) for A/B runs
     // 256-row tiles (8 waves, 3 stages, one block per CU) unless the problem is too small to give every CU one of them; then 128-row tiles
     // with 2 stages (64 KiB) so that two independent 4-wave blocks share a CU

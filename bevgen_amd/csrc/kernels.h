@@ -8,7 +8,7 @@ namespace bevgen {
 // ---------------------------------------------------------------- gemm.hip
 enum { MODE_PLAIN = 0, MODE_CONV3 = 1 };
 enum { ACT_NONE = 0, ACT_GELU = 1 };
-enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1, EPI_GEGLU = 2, EPI_MUSE_KV = 3 };
+enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1, EPI_GEGLU = 2, EPI_MUSE_KV = 3, EPI_MUSE_QKV = 4 };
 
 struct GemmArgs {
     const float* A = nullptr;  // [M,K] row-major (lda)   | MODE_CONV3: NHWC input [n, Hin, Win, Cin]
@@ -56,6 +56,12 @@ struct GemmArgs {
     const void* epi_aux = nullptr;
     int epi_ld = 0;
     float epi_post = 1.f;             // EPI_MUSE_Q: extra factor on the prepared query (the attention kernel's score scale, folded in here)
+    // EPI_MUSE_QKV (Route M self-attention): to_q and to_kv as ONE projection [rows, 3 H 64] = q | k | v over the concatenated weight - the LayerNorm planes are read once
+    // instead of twice and a launch disappears.  Column tiles below H 64 take the EPI_MUSE_Q epilogue with (epi_qh, epi_ql, epi_qscale), the rest the EPI_MUSE_KV one
+    // with the fields above (columns counted from H 64)
+    void* epi_qh = nullptr;
+    void* epi_ql = nullptr;
+    const float* epi_qscale = nullptr;
     // LDS-DMA path, small-M problems (low-latency B = 1 scenes): the k range is cut into `ksplit` slices on gridDim.z, every slice leaves its raw fp32 tile sums in
     // kpart [ksplit][M][N] and splitk_reduce adds them in slice order (deterministic) before alpha / bias / activation / residual.  Plain epilogue only.
     int ksplit = 1;

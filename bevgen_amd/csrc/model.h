@@ -40,6 +40,7 @@ struct MuseLayer {
     float* ff_w4_padded;  // [D, Fpad], owned
     void* null_self = nullptr;      // split-precision mode: prepared null key / value of the self-attention ([k_hi|k_lo|v_hi|v_lo][H][64] halves, owned)
     float* ff_w1_geglu = nullptr;   // split-precision mode: [2 Fpad, D] rows ordered for the fused GEGLU epilogue (owned)
+    float* to_qkv_self = nullptr;   // split-precision mode: to_q | to_kv of the self-attention as one [3 H 64, D] matrix (owned): one projection with the EPI_MUSE_QKV epilogue
     // LayerNorm folded into the GEMMs (split-precision mode, GemmArgs::ln_*): colsum[n] = sum_k gamma_k W[n,k] of every consumer projection, gamma of the
     // feed-forward's inner LayerNorm padded with zeros to Fpad (owned)
 };

@@ -207,16 +207,25 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         const bool split = g.precision == BEVGEN_PRECISION_F16X3;
         if (split) {
             launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw);
+            // to_q and to_kv read the same LayerNorm planes (muse_net:126-132): ONE projection over the concatenated weight, query / key / value preparation in its
+            // epilogue ($BEVGEN_QKV_MERGE=0: the two launches of rounds 2-4, for A/B runs)
+            static const int qkv_merge = getenv("BEVGEN_QKV_MERGE") ? atoi(getenv("BEVGEN_QKV_MERGE")) : 1;
+            const bool merged = qkv_merge && l.to_qkv_self;
+            if (!merged) gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw);
             {   // to_kv with the key / value preparation in its epilogue: k planes [B, H, NkS_pad, 64], v planes transposed [B, H, 64, NkS_pad]
                 const size_t kvS_ = (size_t)B * H * c.NkS_pad * 64;
                 _Float16 *Kp = reinterpret_cast<_Float16*>(w.Ks), *Vp = reinterpret_cast<_Float16*>(w.Vs);
                 GemmArgs gk;
                 gk.A_hi = reinterpret_cast<const uint16_t*>(w.xn); gk.A_lo = gk.A_hi + 32;
-                gk.B = l.to_kv[0];
-                gk.M = rows; gk.N = 2 * D; gk.K = D; gk.lda = D; gk.ldb = D; gk.ldc = 2 * D;
-                gk.epi = EPI_MUSE_KV; gk.epi_scale = l.k_scale[0]; gk.epi_hi = Kp; gk.epi_lo = Kp + kvS_; gk.epi_hi2 = Vp; gk.epi_lo2 = Vp + kvS_;
+                gk.B = merged ? l.to_qkv_self : l.to_kv[0];
+                gk.M = rows; gk.N = (merged ? 3 : 2) * D; gk.K = D; gk.lda = D; gk.ldb = D; gk.ldc = gk.N;
+                gk.epi = merged ? EPI_MUSE_QKV : EPI_MUSE_KV;
+                gk.epi_scale = l.k_scale[0]; gk.epi_hi = Kp; gk.epi_lo = Kp + kvS_; gk.epi_hi2 = Vp; gk.epi_lo2 = Vp + kvS_;
                 gk.epi_aux = l.null_self; gk.epi_rows = N; gk.epi_heads = H; gk.epi_ld = c.NkS_pad;
+                if (merged) {
+                    gk.epi_qh = w.Q; gk.epi_ql = reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D; gk.epi_qscale = l.q_scale[0];
+                    gk.epi_post = 8.0f * kLog2e;   // sim = 8 q.k (muse_net:150) in the base-2 domain of the split attention kernel
+                }
                 launch_gemm(gk, s);
             }
         } else {

@@ -2,6 +2,8 @@
 
 #include "common.h"
 
+#include <exception>
+
 namespace bevgen {
 
 namespace {
@@ -25,7 +27,7 @@ Profiler* prof_set_current(Profiler* p) {
 
 bool prof_enabled() { return t_current && t_current->on; }
 
-ProfScope::ProfScope(int kind, double work, hipStream_t s, bool attach_) : attach(attach_), p(nullptr), idx(-1), stream(s) {
+ProfScope::ProfScope(int kind, double work, hipStream_t s, bool attach_) : attach(attach_), p(nullptr), idx(-1), stream(s), uncaught(std::uncaught_exceptions()) {
     if (!t_current || !t_current->on) return;
     p = t_current;
     Profiler::Rec r{kind, work, get_event(*p), get_event(*p)};
@@ -35,7 +37,14 @@ ProfScope::ProfScope(int kind, double work, hipStream_t s, bool attach_) : attac
 }
 
 ProfScope::~ProfScope() {
-    if (idx >= 0 && !attach) (void)hipEventRecord(p->recs[idx].b, stream);
+    if (idx < 0) return;
+    if (std::uncaught_exceptions() > uncaught) {
+        // unwinding: the enclosed launch did not happen (or failed) - forget the record instead of leaving a pair whose events were never recorded
+        // (bevgen_profile_end would fail in hipEventElapsedTime and mask the original error).  Records are appended in order, so it is the last one.
+        if ((size_t)idx + 1 == p->recs.size()) { p->recs.pop_back(); p->pool_used -= 2; }
+        return;
+    }
+    if (!attach) (void)hipEventRecord(p->recs[idx].b, stream);
 }
 
 hipEvent_t ProfScope::ev_a() const { return p->recs[idx].a; }

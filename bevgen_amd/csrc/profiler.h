@@ -40,6 +40,7 @@ struct ProfScope {
     Profiler* p;
     int idx;
     hipStream_t stream;
+    int uncaught;   // std::uncaught_exceptions() at construction: a destructor that runs during unwinding drops its record
 };
 
 bool prof_enabled();

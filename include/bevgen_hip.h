@@ -13,7 +13,10 @@
  *   - the CALLER owns every buffer passed in; `const T* d_*` / `T* d_*` are DEVICE pointers (e.g. torch tensor
  *     data_ptr()), `h_*` are HOST pointers; the library owns weights, KV cache and workspace inside the context
  *   - `stream` is a hipStream_t (0 = default stream); calls are asynchronous on it unless stated otherwise,
- *     the library performs no hidden host synchronisation on the sampling path
+ *     the library performs no hidden host synchronisation on the sampling path.  One documented exception: a Route-A context created with decode_path = AUTO
+ *     and max_batch > 4 that is nevertheless called with <= 4 sequences packs the split decode layer's q/k/v operand image on that FIRST such call
+ *     (one device allocation per layer, ~300 MB at BASELINE config 4 in fp32, and one stream synchronisation, once per context); every other
+ *     configuration (max_batch 0 or <= 4, decode_path = SPLIT) takes it at bevgen_finalize
  *   - one context per (device, model); a context is not thread-safe, different contexts may be used from different host threads concurrently
  *   - int64 token ids, fp32 everything else (the arithmetic type is a context property: BEVGEN_PRECISION_*)
  */

@@ -46,6 +46,26 @@ def test_bench_world_2_control_flow_under_gloo():
     assert detail["config5"]["gathered_token_ids"][0] == 128 and detail["strong_scaling"]["scaling"] == "strong"
 
 
+def test_bench_world_8_control_flow_under_gloo():
+    """The real rank count of BASELINE configs[2] / configs[4]: 8 ranks (gloo, stub context): weak leg 16 scenes per rank, the strong leg 16 / 8 = 2 scenes per rank,
+    config 5 with 64 sequences per rank gathered to rank 0 (512 rows)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    r = _run(cmd, {"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["rccl_world_size"] == 8 and d["config"]["global_batch"] == 128 and len(d["per_rank_ms_per_step"]) == 8
+    assert abs(d["value"] - 8 * 16 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    s = d["legs"]["strong_scaling"]
+    assert s["global_batch"] == 16 and len(s["per_rank_ms_per_step"]) == 8
+    c5 = d["legs"]["config5"]
+    assert c5["sequences_per_gpu"] == 64 and len(c5["per_rank_ms_per_decode_step"]) == 8
+    detail = json.load(open(os.path.join(ROOT, d["detail_file"])))
+    assert detail["strong_scaling"]["scenes_per_gpu"] == 2 and detail["config5"]["gathered_token_ids"][0] == 512
+
+
 def test_bench_self_launch_and_world_size_mismatch():
     # without a launcher: --gpus 2 re-executes itself under torch.distributed.run with 2 ranks
     r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2"])
@@ -65,3 +85,18 @@ def test_bench_single_rank_dry_run_line_shape():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["metric"].startswith("multi-view scenes/sec") and d["unit"] == "scenes/s" and d["vs_baseline"] is None
     assert "strong_scaling" not in d["legs"] and "config5" not in d["legs"] and d["rccl_world_size"] == 1 and d["roofline"]["traffic"] is None
+    # the HBM roofline of the north star is a first-class sibling of `roofline` (values only on a GPU), and no leg prints a "fraction of peak" that a window artefact
+    # can push above 1
+    ra = d["roofline_decode_attention"]
+    assert ra["bound"] == "hbm" and ra["unit"] == "GB/s" and {"kernel", "launches", "avg_us", "frac", "traffic", "achieved", "peak"} <= set(ra)
+    assert "attn_phase_frac" not in json.dumps(d)
+
+
+def test_bench_single_gpu_predictions_of_the_scaling_legs():
+    """At the default batch (16) the N = 1 line states what one GPU does at the per-GPU load of the 2 / 4 / 8-GPU strong-scaling legs (batch 8 / 4 / 2)."""
+    r = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    p = d["legs"]["scaling_prediction_from_one_gpu"]
+    assert set(p["strong_16_scenes"]) == {"2", "4", "8"} and set(p["per_gpu_scenes_per_s_at_batch"]) == {"8", "4", "2"} and set(p["weak_16_per_gpu"]) == {"2", "4", "8"}
+    assert abs(p["weak_16_per_gpu"]["8"] - 8 * d["value"]) / d["value"] < 1e-2

@@ -51,3 +51,10 @@ def test_hot_kernels_do_not_spill():
             assert hits, f"{src}: no kernel matching {frag} (renamed? update tests/test_kernel_resources.py)"
             for k, v in hits.items():
                 assert v.get("VGPRs Spill", 0) <= max_spill, f"{k}: {v.get('VGPRs Spill')} VGPRs spilled (limit {max_spill}): {v}"
+    # The staged K/V walk (Attend::run_staged, every G = 1 instantiation of the fused decode kernel) decides that its hidden LDS-DMA pieces have landed by COUNTING the
+    # compiler-visible VMEM operations issued after them (s_waitcnt vmcnt(4 U / 2 U)).  A scratch reload or spill store between the two would also be counted and let the
+    # walk read LDS before the DMA wrote it - silently wrong attention.  So these instantiations must not touch scratch at all: a build that does fails here.
+    staged = {k: v for k, v in results["decode_fused.hip"].items() if re.search(r"ar_attn_fused_kernelILi[01]ELi1ELi[01]ELb[01]E", k)}
+    assert len(staged) == 8, sorted(staged)
+    for k, v in staged.items():
+        assert v.get("ScratchSize [bytes/lane]", 0) == 0 and v.get("VGPRs Spill", 0) == 0, f"{k} uses scratch ({v}): the vmcnt-counted K/V staging is not safe with scratch traffic"
