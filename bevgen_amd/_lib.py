@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVGEN_LIB_PATH") or os.path.join(_HERE, "csrc", "libbevgen_hip.so")   # override: A/B runs of two builds on one GPU box
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevgen_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
@@ -72,6 +72,7 @@ SIGNATURES = {
     "bevgen_vq_encode": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "bevgen_op_gemm": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "bevgen_op_ln_gemm": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _p]),
+    "bevgen_op_mlp_fused": (_i, [_p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p, _i, _i, _p]),
     "bevgen_op_layernorm": (_i, [_p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "bevgen_op_geglu_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "bevgen_op_attention": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),

@@ -283,6 +283,65 @@ int bevgen_op_ln_gemm(bevgen_ctx* ctx, const float* a, const float* ln_w, const 
     });
 }
 
+int bevgen_op_mlp_fused(bevgen_ctx* ctx, const float* x, const float* ln_w, const float* ln_b, float eps, const float* w1, const float* b1, const float* w2, const float* b2,
+                        int w_f16, float* out, int M, int D, void* stream) {
+    return guarded(ctx, [&] {
+        hipStream_t s = (hipStream_t)stream;
+        BG_REQUIRE(x && ln_w && ln_b && w1 && b1 && w2 && b2 && out, "op_mlp_fused: missing operand");
+        BG_REQUIRE(mlp_fused_supported(M, D, w_f16 != 0), "op_mlp_fused: unsupported shape M=%d D=%d (or a device with fewer CUs than workgroups / BEVGEN_MLP_FUSE=0)", M, D);
+        const size_t eb = w_f16 ? sizeof(_Float16) : sizeof(float);
+        const size_t wbytes = (skinny_packed_floats(4 * D, D) + skinny_packed_floats(D, 4 * D)) * eb;
+        const size_t fl = (size_t)8 * D + (size_t)M * 4 * D + (size_t)MLP_FUSED_PLANES * M * D + (size_t)M * D + 2 * (size_t)4 * D * D;
+        ctx->arena.reserve(wbytes + fl * sizeof(float) + mlp_fused_sync_words() * sizeof(unsigned) + 64 * 256);
+        ctx->arena.reset();
+        void* w1p = ctx->arena.alloc(skinny_packed_floats(4 * D, D) * eb);
+        void* w2p = ctx->arena.alloc(skinny_packed_floats(D, 4 * D) * eb);
+        float* cs = ctx->arena.get<float>((size_t)4 * D);
+        float* ds = ctx->arena.get<float>((size_t)4 * D);
+        float* hidden = ctx->arena.get<float>((size_t)M * 4 * D);
+        float* part = ctx->arena.get<float>((size_t)MLP_FUSED_PLANES * M * D);
+        float* zero = ctx->arena.get<float>((size_t)M * D);
+        unsigned* sync = ctx->arena.get<unsigned>(mlp_fused_sync_words());
+        const float *w1u = w1, *w2u = w2;
+        if (w_f16) {   // the model decode_weights = f16 defines: matrices rounded to fp16-representable values (row constants from the rounded matrix, as bevgen_finalize does)
+            float* w1r = ctx->arena.get<float>((size_t)4 * D * D);
+            float* w2r = ctx->arena.get<float>((size_t)4 * D * D);
+            HIP_CHECK(hipMemcpyAsync(w1r, w1, (size_t)4 * D * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(w2r, w2, (size_t)4 * D * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+            launch_round_to_f16(w1r, nullptr, (long)4 * D * D, s);
+            launch_round_to_f16(w2r, nullptr, (long)4 * D * D, s);
+            w1u = w1r; w2u = w2r;
+            launch_pack_skinny_weight_f16(w1u, w1p, 4 * D, D, s);
+            launch_pack_skinny_weight_f16(w2u, w2p, D, 4 * D, s);
+        } else {
+            launch_pack_skinny_weight(w1u, reinterpret_cast<float*>(w1p), 4 * D, D, s);
+            launch_pack_skinny_weight(w2u, reinterpret_cast<float*>(w2p), D, 4 * D, s);
+        }
+        launch_ar_ln_fold(w1u, b1, ln_w, ln_b, cs, ds, 4 * D, D, s);
+        HIP_CHECK(hipMemsetAsync(zero, 0, (size_t)M * D * sizeof(float), s));
+        HIP_CHECK(hipMemsetAsync(sync, 0, mlp_fused_sync_words() * sizeof(unsigned), s));
+        unsigned *err_h = nullptr, *err_d = nullptr;
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_h), 64, hipHostMallocMapped));
+        *err_h = 0;
+        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&err_d), err_h, 0));
+        MlpFusedArgs g;
+        g.A = x; g.lda = D; g.ln_w = ln_w; g.ln_cs = cs; g.ln_ds = ds; g.eps = eps;
+        g.Wup = reinterpret_cast<const float*>(w1p); g.Wdn = reinterpret_cast<const float*>(w2p); g.w_f16 = w_f16;
+        g.hidden = hidden; g.C = part; g.sync = sync; g.err = err_d; g.M = M; g.D = D;
+        g.trace = ctx->trace ? ctx->trace + 4096 * 8 : nullptr;
+        // (twice: the second launch runs on the barrier state the first one left behind - the self-cleaning property the hipGraph replay of the decode step relies on)
+        launch_ar_mlp_fused(g, s);
+        launch_ar_mlp_fused(g, s);
+        RowSrc r;
+        r.base = zero; r.ld = D; r.partial = part; r.ns = MLP_FUSED_PLANES; r.pstride = (long)M * D; r.pld = D; r.bias = b2;
+        launch_rowsrc_materialize(r, out, M, D, nullptr, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+        const unsigned e = *err_h;
+        (void)hipHostFree(err_h);
+        BG_REQUIRE(e == 0, "op_mlp_fused: the launch reported error word %u (1 = barrier timeout, 2 = a workgroup off the XCD its index implies)", e);
+    });
+}
+
 int bevgen_op_layernorm(bevgen_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, int rows, int D, float eps, void* stream) {
     return guarded(ctx, [&] { launch_layernorm(x, D, gamma, beta, y, D, rows, D, eps, (hipStream_t)stream); });
 }

@@ -8,10 +8,37 @@
 // order and condition rows only see condition columns (mask_generator.py:148, 202-206), so the logits of step s depend only on
 // rows <= K-1+s: we compute the K condition rows once (prefill), keep K/V of every layer, and per step push exactly one new
 // row through the stack (validity verified against the reference).
+#include <atomic>
+#include <mutex>
 #include "model.h"
 #include "profiler.h"
 
 namespace bevgen {
+
+// Decode steps that contain a launch whose workgroups wait for each other (ar_mlp_fused_kernel: every workgroup of an XCD must be resident at once) must not interleave
+// with another such stream of launches on the same device: two half-resident grids could starve each other until the bounded spin gives up.  One context is one stream
+// of strictly ordered launches; with SEVERAL Route-A contexts alive in the process, their decode calls are chained on the device by one event per device (the second
+// call's launches wait until the first call's have drained) and on the host by a mutex held while a call enqueues.  Nothing happens with a single context.
+std::atomic<int> g_live_ar_contexts{0};
+namespace {
+std::mutex g_spin_mu;
+hipEvent_t g_spin_ev[64] = {};
+struct SpinSerial {
+    std::unique_lock<std::mutex> lk;
+    hipEvent_t ev = nullptr;
+    hipStream_t q = nullptr;
+    SpinSerial(const Ctx& c, hipStream_t stream) {
+        if (!c.mlpf_sync || g_live_ar_contexts.load(std::memory_order_relaxed) < 2) return;
+        lk = std::unique_lock<std::mutex>(g_spin_mu);
+        hipEvent_t& e = g_spin_ev[c.device >= 0 && c.device < 64 ? c.device : 0];
+        if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev = e; q = stream;
+        HIP_CHECK(hipStreamWaitEvent(q, ev, 0));   // (never recorded yet: a no-op)
+    }
+    void rebind(hipStream_t stream) { if (ev) { HIP_CHECK(hipStreamWaitEvent(stream, ev, 0)); q = stream; } }
+    ~SpinSerial() { if (ev) (void)hipEventRecord(ev, q); }
+};
+}  // namespace
 
 namespace {
 
@@ -57,7 +84,15 @@ bool fused_path(const Ctx& c, int B, int G) {
            (c.cfg.decode_weight_dtype != BEVGEN_W_F16 || (skinny_fused_f16_ok(4 * D, D, true) && skinny_fused_f16_ok(D, 4 * D, false) && skinny_fused_f16_ok(c.V, D, true)));
 }
 
-size_t part_floats(const Ctx& c, int B) { return (size_t)skinny_fused_ksplit(c.D, 4 * c.D) * B * c.D; }
+size_t part_floats(const Ctx& c, int B) { return (size_t)std::max(skinny_fused_ksplit(c.D, 4 * c.D), MLP_FUSED_PLANES) * B * c.D; }
+
+// Both MLP projections of a layer in one launch (ar_mlp_fused_kernel): the fused three-launch layer, one chain, at most 16 rows, ln2 folded, a device whose CUs hold the
+// whole grid at once.  Otherwise the two skinny launches.
+bool mlp_fused_step(const Ctx& c, int Bc, bool split, int chains) {
+    static const int ln2_fold = getenv("BEVGEN_LN2_FOLD") ? atoi(getenv("BEVGEN_LN2_FOLD")) : 1;
+    return !split && chains == 1 && ln2_fold && c.mlpf_sync && skinny_fused_ksplit(c.D, 4 * c.D) > 1 &&
+           mlp_fused_supported(Bc, c.D, c.cfg.decode_weight_dtype == BEVGEN_W_F16);
+}
 
 StepWs step_ws(Ctx& c, int B) {
     // fixed layout at the start of the per-call arena (so a captured graph keeps seeing the same addresses)
@@ -154,6 +189,7 @@ void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const floa
 // samples_per_layout = S > 1 (BASELINE config 5): consecutive groups of S sequences share their condition (BEV ids and cameras), so the condition
 // prefix is pushed through the stack once per LAYOUT (B / S sequences) and its K/V rows are then replicated into the S cache slots of the group.
 void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s, int samples_per_layout) {
+    c.check_mlpf_error();   // (a fused MLP launch of an EARLIER call that reported a timeout: the host-visible word is read without synchronising)
     const auto& g = c.cfg;
     BG_REQUIRE(g.route == BEVGEN_ROUTE_AR, "context was not created for the autoregressive route");
     BG_REQUIRE(B >= 1, "batch must be positive");
@@ -335,6 +371,7 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
     float* part = w.part + (size_t)ks * r0 * D;               // [ks][Bc][D] per chain, chains back to back
     float* m1 = w.m1 + (size_t)r0 * 4 * D;
     const bool split = effective_decode_path(c, B, st.G) == BEVGEN_DECODE_SPLIT;
+    const bool mlpf = mlp_fused_step(c, Bc, split, Bc == B ? 1 : 2);
     float* qkv = w.qkv + (size_t)r0 * 3 * D;
     float* xn = w.xn + (size_t)r0 * D;
     RowSrc src;
@@ -376,6 +413,20 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
         a.prefix = c.K; a.scale = 0.125f;
         a.trace = c.trace;
         launch_ar_attn_fused(a, s);
+        if (mlpf) {   // ln2 + MLP up + GELU + MLP down in one launch: 8 partial planes (one per XCD) for the next consumer's row fetch
+            MlpFusedArgs mf;
+            mf.A = x2; mf.lda = D;
+            mf.ln_w = l.ln2_w; mf.ln_cs = l.mlp0_cs; mf.ln_ds = l.mlp0_ds; mf.eps = 1e-5f;
+            mf.Wup = l.mlp0_wp; mf.Wdn = l.mlp2_wp; mf.w_f16 = wf16;
+            mf.hidden = m1; mf.C = part;
+            mf.sync = c.mlpf_sync; mf.err = c.mlpf_err_dev;
+            mf.M = Bc; mf.D = D;
+            mf.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
+            launch_ar_mlp_fused(mf, s);
+            src = RowSrc{};
+            src.base = x2; src.ld = D; src.partial = part; src.ns = MLP_FUSED_PLANES; src.pstride = (long)Bc * D; src.pld = D; src.bias = l.mlp2_b;
+            continue;
+        }
         SkinnyFusedArgs up;
         up.A = x2; up.lda = D;
         up.ln_w = l.ln2_w; up.ln_b = l.ln2_b; up.eps = 1e-5f;
@@ -480,9 +531,11 @@ void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s) {
     auto& st = c.ars;
     BG_REQUIRE(st.B > 0, "bevgen_ar_prefill must be called first");
     BG_REQUIRE(st.step < c.N, "all %d image tokens have already been decoded", c.N);
+    c.check_mlpf_error();
     c.arena.reset();
     StepWs w = step_ws(c, st.B);
     st.pick_embeds = false;   // the caller's tokens: embed them here
+    SpinSerial serial(c, s);
     decode_step_launch(c, w, tok, s);
     st.step += 1;
 }
@@ -515,6 +568,7 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     };
 
     const bool use_graph = steps > 2 && !step_logits && !prof_enabled() && !c.disable_graphs;
+    SpinSerial serial(c, s);
     if (!use_graph) {
         for (int step = 0; step < steps; ++step) {
             head_and_pick(step_logits ? step_logits + (size_t)step * B * c.V : w.logits, s);
@@ -536,6 +590,7 @@ void ar_sample(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_i
     hipStream_t q = c.graph_stream;
     HIP_CHECK(hipEventRecord(c.graph_ev_in, s));
     HIP_CHECK(hipStreamWaitEvent(q, c.graph_ev_in, 0));
+    serial.q = s;   // (the call's last launches rejoin the caller's stream below: the chain event is recorded there)
     Ctx::GraphKey key;
     key.B = B; key.G = st.G; key.chains = fused_path(c, B, st.G) ? decode_chains(c, B, st.G) : 1; key.top_k = top_k; key.greedy = greedy; key.kv = cache_dtype(c); key.temperature = temperature;
     key.noise = greedy ? nullptr : noise_u; key.forced = forced; key.out = out; key.arena = c.arena.base; key.persist = c.persist.base; key.trace = c.trace;

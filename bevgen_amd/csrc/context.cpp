@@ -72,6 +72,15 @@ Ctx::~Ctx() {
     for (void* p : owned) (void)hipFree(p);
     arena.release();
     persist.release();
+    if (mlpf_err_host) { (void)hipHostFree(mlpf_err_host); g_live_ar_contexts.fetch_sub(1, std::memory_order_relaxed); }
+}
+
+void Ctx::check_mlpf_error() {
+    if (!mlpf_err_host || !*mlpf_err_host) return;
+    const unsigned e = *mlpf_err_host;
+    *mlpf_err_host = 0;
+    fail(BEVGEN_ERR_INTERNAL, "fused MLP launch of the decode step failed (%s%s): the tokens of the affected call are invalid.  Set BEVGEN_MLP_FUSE=0 to run the two-launch form",
+         (e & 1u) ? "an XCD-local barrier timed out - the launch did not have the GPU to itself" : "", (e & 2u) ? " a workgroup was not placed on the XCD its index implies" : "");
 }
 const DevTensor* Ctx::find(const std::string& name) const {
     auto it = params.find(name);
@@ -302,6 +311,16 @@ static void finalize_ar(Ctx& c) {
         c.split_weight(l.mlp2_w, 4L * D * D);
     }
     if (wf16) launch_round_to_f16(const_cast<float*>(c.pf("head.weight")), nullptr, (long)g.vocab_size * D, 0);
+    if (fused_like) {   // state of the fused MLP launch (both projections of a layer in one launch, XCD-local exchange)
+        c.mlpf_sync = reinterpret_cast<unsigned*>(c.own(mlp_fused_sync_words() * sizeof(unsigned)));
+        HIP_CHECK(hipMemset(c.mlpf_sync, 0, mlp_fused_sync_words() * sizeof(unsigned)));
+        if (!c.mlpf_err_host) {
+            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.mlpf_err_host), 64, hipHostMallocMapped));
+            *c.mlpf_err_host = 0;
+            HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c.mlpf_err_dev), c.mlpf_err_host, 0));
+            g_live_ar_contexts.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
     if (fused_like) {
         c.head_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(g.vocab_size, D) * (wf16 ? sizeof(_Float16) : sizeof(float))));
         if (wf16) launch_pack_skinny_weight_f16(c.pf("head.weight"), c.head_wp, g.vocab_size, D, 0);

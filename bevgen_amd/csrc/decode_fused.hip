@@ -31,7 +31,8 @@ namespace bevgen {
 // Every load of an element is requested before the first one is used, and UNCONDITIONALLY: a predicated load (`k < ns ? p[k] : 0`) becomes a
 // divergent branch whose join point waits for the load, i.e. one serialised memory round trip per partial.  The launchers therefore make every
 // pointer valid (rowsrc_fix: absent partials / bias alias `base`) and the kernel only selects which values count.
-constexpr int ROWSRC_MAX_SPLITS = 4;
+constexpr int ROWSRC_MAX_SPLITS = 8;   // (4 K slices of the MLP-down launch; 8 XCD planes of the fused MLP launch)
+constexpr int ROWSRC_RS_SPLITS = 4;    // the row-source form of skinny_fused_kernel (decode_path = split) keeps its register budget: at most 4 partials
 inline RowSrc rowsrc_fix(RowSrc r) {
     if (!r.partial || r.ns == 0) { r.partial = r.base; r.ns = 0; r.pstride = 0; r.pld = r.ld; }
     r.has_bias = r.bias != nullptr;
@@ -952,19 +953,19 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
             const RowSrc& rs = g.src;
             constexpr int PJ = 2;
             // wave-uniform bases + ONE 32-bit element offset per chunk (48 full 64-bit lane addresses kept live across the row-chunk loop were the spill)
-            const float* pb[ROWSRC_MAX_SPLITS];
+            const float* pb[ROWSRC_RS_SPLITS];
 #pragma unroll
-            for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) pb[k] = rs.partial + (long)(k < rs.ns ? k : 0) * rs.pstride;
+            for (int k = 0; k < ROWSRC_RS_SPLITS; ++k) pb[k] = rs.partial + (long)(k < rs.ns ? k : 0) * rs.pstride;
 #pragma unroll
             for (int half = 0; half < 8 / PJ; ++half) {
-                float4 p[PJ][ROWSRC_MAX_SPLITS], b[PJ], x[PJ];
+                float4 p[PJ][ROWSRC_RS_SPLITS], b[PJ], x[PJ];
 #pragma unroll
                 for (int jj = 0; jj < PJ; ++jj) {
                     const int c = min(q + 4 * wave + 32 * (half * PJ + jj), nch - 1);   // clamped, never predicated (see rowsrc_at)
                     const unsigned col = (unsigned)(kbase + 4 * c);
                     const unsigned po = (unsigned)mr * (unsigned)rs.pld + col, xo = (unsigned)mr * (unsigned)rs.ld + col;
 #pragma unroll
-                    for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) p[jj][k] = *reinterpret_cast<const float4*>(pb[k] + po);
+                    for (int k = 0; k < ROWSRC_RS_SPLITS; ++k) p[jj][k] = *reinterpret_cast<const float4*>(pb[k] + po);
                     b[jj] = *reinterpret_cast<const float4*>(rs.bias + (rs.has_bias ? col : 0u));
                     x[jj] = *reinterpret_cast<const float4*>(rs.base + xo);
                 }
@@ -972,7 +973,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
                 for (int jj = 0; jj < PJ; ++jj) {
                     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int k = 0; k < ROWSRC_MAX_SPLITS; ++k) {   // absent partials alias valid memory (rowsrc_fix): loaded, not counted
+                    for (int k = 0; k < ROWSRC_RS_SPLITS; ++k) {   // absent partials alias valid memory (rowsrc_fix): loaded, not counted
                         sum.x += k < rs.ns ? p[jj][k].x : 0.f; sum.y += k < rs.ns ? p[jj][k].y : 0.f; sum.z += k < rs.ns ? p[jj][k].z : 0.f; sum.w += k < rs.ns ? p[jj][k].w : 0.f;
                     }
                     v[half * PJ + jj] = make_float4((sum.x + (rs.has_bias ? b[jj].x : 0.f)) + x[jj].x, (sum.y + (rs.has_bias ? b[jj].y : 0.f)) + x[jj].y,
@@ -1181,6 +1182,285 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 #undef SF_TRACE
 }
 
+// ----------------------------------------------------------------------------------------------------------------- both MLP projections in one launch
+// ar_mlp_fused_kernel: ln2 (folded) + MLP up-projection + GELU, an exchange INSIDE one XCD, then the MLP down-projection - one launch instead of two per layer.
+//
+// Why an exchange is affordable here although round 3 measured 7.9 us for one (tools/gridbar/xchg_probe.hip): that one crossed XCDs - flag and data had to reach the memory
+// side.  Workgroup i of a launch runs on XCD i % 8 (tools/xcc_probe; checked at run time below), so with the hidden column tiles dealt out as tile = 32 (i % 8) + i / 8 the
+// 32 workgroups of an XCD produce one contiguous 512-column slice of the hidden row = exactly one K slice of the down-projection, and both sides of the exchange share that
+// XCD's L2: producers use plain stores (the vector L1 is write-through: an acknowledged store is in L2), consumers plain loads of lines their CU has not read in this launch,
+// and the rendezvous is one L2 counter per XCD.  Measured (tools/gridbar/xcd_xchg_probe.hip, profiles/r05_xcd_xchg_probe.txt): 1.1 us per such barrier, 2.3 us to read a
+// 64 KB slice back, no agent-scope fence anywhere.  What the fusion buys: the down-projection's launch ramp and its cold weight burst (requested here at kernel start, 32 KB per
+// workgroup, in registers long before the hidden slice exists) disappear behind the up-projection.
+//
+// Co-residency: every workgroup waits for its 31 XCD peers, so all of them must be resident - true whenever the launch has the GPU to itself (4 D / 16 = 256 workgroups of 8
+// waves, one per CU; the decode step is a single chain of kernels on one stream).  Two such launches interleaved on one device (two contexts decoding at once) could starve each
+// other: the spin is bounded (MLPF_TIMEOUT_TICKS of the 100 MHz clock) and a timeout raises the context's error word instead of hanging; the host serialises the decode
+// steps of different contexts of one process on a device (ar.cpp) so that this does not happen in the first place.
+//
+// The barrier is sense-reversing and cleans up after itself (count back to 0, generation + 1 by the last arriver): nothing has to be reset between launches, so the launch
+// replays inside a hipGraph.  Its words live at sync[64 x] (count) and sync[64 x + 32] (generation), one 256-byte slot per XCD; sync[512 + i] records the XCD workgroup i saw.
+constexpr long long MLPF_TIMEOUT_TICKS = 200LL * 1000 * 100;   // 200 ms
+size_t mlp_fused_sync_words() { return 512 + 1024; }
+
+template <int WT>   // weight storage of both packed images: 0 fp32, 1 fp16
+__global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArgs g) {
+    __shared__ float4 As[256 * 16];          // phase 1: the rows [k/4][16 rows] (K = D <= 1024); phase 2: the hidden slice (D / 2 columns)
+    __shared__ float4 gm_s[256];             // ln2 gamma
+    __shared__ float red[2][SF_WAVES][4][64];
+    __shared__ float stat[2][SF_WAVES][16];
+    __shared__ unsigned flag_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int D = g.D, K2 = 4 * D;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;     // workgroup jx of the per_xcd (= D / 32) on XCD xcd
+    const int tile = xcd * per_xcd + jx;                                                 // hidden column tile: the XCD's tiles are contiguous
+    const int n0 = tile * 16;
+    const int nch = D >> 2, kper = D / SF_WAVES;                                         // phase 1: float4 chunks per row, K slice of a wave (128 at D = 1024)
+    const int slice = K2 >> 3, kper2 = slice / SF_WAVES;                                 // phase 2: this XCD's K slice of the down-projection (512), per wave (64)
+#define MF_TRACE(i) do { if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    MF_TRACE(0);
+    unsigned* cnt = g.sync + 64 * xcd;
+    unsigned* gen = g.sync + 64 * xcd + 32;
+    unsigned gen0 = 0;
+    if (tid == 0) gen0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an L2-coherent read: the vector L1 never serves it)
+    // ---- requests, in the order the results are needed: rows, gamma, row constants, up weights, down weights
+    const int mr = min(r, g.M - 1);
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = min(q + 4 * wave + 32 * j, nch - 1);   // clamped, never predicated (see rowsrc_at)
+        v[j] = *reinterpret_cast<const float4*>(g.A + (long)mr * g.lda + 4 * c);
+    }
+    float4 gb_raw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 256) gb_raw = *reinterpret_cast<const float4*>(g.ln_w + 4 * min(tid, nch - 1));
+    float e_cs = 0.f, e_ds = 0.f;
+    if (tid < 256) { e_cs = g.ln_cs[n0 + (tid & 15)]; e_ds = g.ln_ds[n0 + (tid & 15)]; }
+    float4 wv[WT ? 1 : 8];
+    half8_t wh[WT ? 4 : 1];
+    float4 dv[WT ? 1 : 8];   // down weights: 2 column tiles x this wave's kper2 = 64 of the slice
+    half8_t dh[WT ? 4 : 1];
+    const int t2 = 2 * jx;   // this workgroup's two output column tiles of the down-projection
+    if (WT) {
+        const _Float16* wp = reinterpret_cast<const _Float16*>(g.Wup) + (((long)tile * (D >> 5) + ((wave * kper) >> 5)) * 64 + lane) * 8;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wh[u] = __builtin_nontemporal_load(reinterpret_cast<const half8_t*>(wp + (long)min(u, (kper >> 5) - 1) * 512));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const _Float16* dp = reinterpret_cast<const _Float16*>(g.Wdn) + (((long)(t2 + t) * (K2 >> 5) + ((xcd * slice + wave * kper2) >> 5) + u) * 64 + lane) * 8;
+                dh[2 * t + u] = __builtin_nontemporal_load(reinterpret_cast<const half8_t*>(dp));
+            }
+    } else {
+        const float* wp = g.Wup + (((long)tile * (D >> 4) + ((wave * kper) >> 4)) * 64 + lane) * 4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = ldg_nt4(wp + (long)min(u, (kper >> 4) - 1) * 256);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* dp = g.Wdn + (((long)(t2 + t) * (K2 >> 4) + ((xcd * slice + wave * kper2) >> 4) + u) * 64 + lane) * 4;
+                dv[4 * t + u] = ldg_nt4(dp);
+            }
+    }
+    // ---- phase 1: ln2 folded into the up-projection (the FD form of skinny_fused_kernel: raw rows to LDS, gamma at the operand read, statistics in the shadow of the weights)
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (q + 4 * wave + 32 * j < nch) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        s += xor16(s);
+        s += xor32(s);
+        if (q == 0) stat[0][wave][r] = s;
+        if (tid < 256) gm_s[tid] = gb_raw;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = q + 4 * wave + 32 * j;
+        if (c < nch) As[c * 16 + r] = v[j];
+    }
+    lds_barrier();
+    MF_TRACE(1);
+    float4 aop[8];
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SF_WAVES; ++w) t += stat[0][w][r];
+        const float mean = t / (float)D;
+        float qq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (q + 4 * wave + 32 * j < nch) {
+                const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+                qq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        qq += xor16(qq);
+        qq += xor32(qq);
+        if (q == 0) stat[1][wave][r] = qq;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c4 = min(WT ? ((wave * kper + 32 * (i >> 1)) >> 2) + 2 * q + (i & 1) : ((wave * kper + 16 * i) >> 2) + q, nch - 1);
+            aop[i] = mul4(As[c4 * 16 + r], gm_s[c4]);
+        }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (WT) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (32 * u < kper) {
+                const float4 a0 = aop[2 * u], a1 = aop[2 * u + 1];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, (float)wh[u][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, (float)wh[u][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, (float)wh[u][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, (float)wh[u][3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, (float)wh[u][4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, (float)wh[u][5], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, (float)wh[u][6], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, (float)wh[u][7], acc, 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (16 * u < kper) {
+                const float4 a4 = aop[u];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv[u].w, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[0][wave][j][lane] = acc[j];
+    lds_barrier();
+    MF_TRACE(2);
+    if (tid < 256) {   // one hidden element per thread: the 8 waves' partial sums in wave order, LayerNorm fix-up, GELU
+        const int j = tid >> 6, ln = tid & 63;
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < SF_WAVES; ++w) o += red[0][w][j][ln];
+        const int rw = 4 * (ln >> 4) + j;
+        float t1 = 0.f, t2s = 0.f;
+#pragma unroll
+        for (int w = 0; w < SF_WAVES; ++w) { t1 += stat[0][w][rw]; t2s += stat[1][w][rw]; }
+        const float mean = t1 / (float)D, rstd = rsqrtf(t2s / (float)D + g.eps);
+        o = gelu_erf(rstd * (o - mean * e_cs) + e_ds);
+        if (rw < g.M) g.hidden[(long)rw * K2 + n0 + (ln & 15)] = o;
+    }
+    // ---- the exchange: this XCD's per_xcd workgroups have all stored their 16 hidden columns
+    unsigned my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xf;
+    if (tid == 0) g.sync[512 + blockIdx.x] = my_xcc;
+    __builtin_amdgcn_s_waitcnt(0);   // (every wave: its stores are acknowledged, i.e. in L2)
+    __syncthreads();
+    if (tid == 0) {
+        unsigned ok = 1;
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == (unsigned)per_xcd) {   // last arriver: clean up, then release the others
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const long long t_in = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t_in > MLPF_TIMEOUT_TICKS) { ok = 0; break; }
+            }
+        }
+        flag_s = ok;
+    }
+    __syncthreads();
+    MF_TRACE(3);
+    if (tid < per_xcd && g.sync[512 + 8 * tid + xcd] != my_xcc) atomicOr(g.err, 2u);   // a peer that is NOT on this XCD: its stores are not in this L2 (placement assumption broken)
+    if (!flag_s) { if (tid == 0) atomicOr(g.err, 1u); }
+    // ---- phase 2: down-projection of this XCD's hidden slice, 2 x 16 output columns per workgroup, into partial plane `xcd`
+    const int nch2 = slice >> 2;   // 128 chunks of 4
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = q + 4 * wave + 32 * j;
+        const float4 hv = *reinterpret_cast<const float4*>(g.hidden + (long)mr * K2 + xcd * slice + 4 * min(c, nch2 - 1));
+        if (c < nch2) As[c * 16 + r] = hv;
+    }
+    __syncthreads();
+    f32x4 acc2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (WT) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c4 = ((wave * kper2 + 32 * u) >> 2) + 2 * q;
+            const float4 a0 = As[c4 * 16 + r], a1 = As[(c4 + 1) * 16 + r];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const half8_t w8 = dh[2 * t + u];
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, (float)w8[0], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, (float)w8[1], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, (float)w8[2], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, (float)w8[3], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, (float)w8[4], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, (float)w8[5], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, (float)w8[6], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, (float)w8[7], acc2[t], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 a4 = As[(((wave * kper2 + 16 * u) >> 2) + q) * 16 + r];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 w4 = dv[4 * t + u];
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w4.x, acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w4.y, acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w4.z, acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w4.w, acc2[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[t][wave][j][lane] = acc2[t][j];
+    __syncthreads();
+    MF_TRACE(4);
+    {   // thread (t, j, lane): one element of one of the two 16 x 16 output tiles
+        const int t = tid >> 8, j = (tid >> 6) & 3, ln = tid & 63;
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < SF_WAVES; ++w) o += red[t][w][j][ln];
+        const int mo = 4 * (ln >> 4) + j, col = (t2 + t) * 16 + (ln & 15);
+        if (mo < g.M) g.C[((long)xcd * g.M + mo) * D + col] = o;
+    }
+    MF_TRACE(5);
+#undef MF_TRACE
+}
+
+bool mlp_fused_supported(int M, int D, bool w_f16) {
+    static const int env = getenv("BEVGEN_MLP_FUSE") ? atoi(getenv("BEVGEN_MLP_FUSE")) : 1;
+    if (!env || M < 1 || M > 16 || D != 1024) return false;   // (the K slices per wave - 128 of D, 64 of the XCD's D / 2 - are written out for D = 1024)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    (void)w_f16;
+    return cus >= 4 * D / 16;   // one workgroup per CU: every workgroup of an XCD must be resident at once
+}
+
+void launch_ar_mlp_fused(const MlpFusedArgs& g, hipStream_t s) {
+    BG_REQUIRE(mlp_fused_supported(g.M, g.D, g.w_f16 != 0), "ar_mlp_fused: unsupported shape M=%d D=%d (or a device with fewer CUs than workgroups)", g.M, g.D);
+    BG_REQUIRE(g.A && g.ln_w && g.ln_cs && g.ln_ds && g.Wup && g.Wdn && g.hidden && g.C && g.sync && g.err && g.lda % 4 == 0, "ar_mlp_fused: missing operand");
+    const dim3 grid(4 * g.D / 16);
+    // work = algorithmic bytes: both weight matrices once + rows in, hidden out and back, partial planes out
+    ProfScope prof(PROF_GEMM_SKINNY, 8.0 * g.D * g.D * (g.w_f16 ? 2 : 4) + ((double)g.M * g.D + 2.0 * g.M * 4 * g.D + (double)MLP_FUSED_PLANES * g.M * g.D) * sizeof(float), s, true);
+    if (g.w_f16) {
+        if (prof.attached()) hipExtLaunchKernelGGL(ar_mlp_fused_kernel<1>, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, g);
+        else hipLaunchKernelGGL(ar_mlp_fused_kernel<1>, grid, dim3(SF_WAVES * 64), 0, s, g);
+    } else {
+        if (prof.attached()) hipExtLaunchKernelGGL(ar_mlp_fused_kernel<0>, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, g);
+        else hipLaunchKernelGGL(ar_mlp_fused_kernel<0>, grid, dim3(SF_WAVES * 64), 0, s, g);
+    }
+    LAUNCH_CHECK();
+}
+
 // W [N, K] row-major -> tile-major operand image: [N/16 column tiles][K/16 k-chunks][64 lanes][4]; lane l = r + 16 q holds W[16 tile + r][16 chunk + 4 q .. + 3],
 // i.e. exactly the float4 that lane feeds to the four MFMAs of the chunk.  Rows beyond N are zero.
 __global__ __launch_bounds__(256) void pack_skinny_weight_kernel(const float* __restrict__ W, float* __restrict__ Wp, int N, int K) {
@@ -1228,14 +1508,14 @@ void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStrea
 int skinny_fused_ksplit(int N, int K) {
     // the K slice of one workgroup is at most 1024 (A tile in LDS, W slice in registers); beyond that, split until the grid covers the chip
     int s = 1;
-    while (K / s > 1024 || (s < ROWSRC_MAX_SPLITS && cdiv(N, 16) * s < 192 && (K / (s * 2)) % (SF_WAVES * 16) == 0 && K / (s * 2) >= 256)) s *= 2;
+    while (K / s > 1024 || (s < ROWSRC_RS_SPLITS && cdiv(N, 16) * s < 192 && (K / (s * 2)) % (SF_WAVES * 16) == 0 && K / (s * 2) >= 256)) s *= 2;
     return s;
 }
 
 bool skinny_fused_supported(int M, int N, int K, bool ln) {
     if (M < 1 || M > 64 || K % 4 != 0) return false;
     const int s = ln ? 1 : skinny_fused_ksplit(N, K);
-    if (K % s != 0 || s > ROWSRC_MAX_SPLITS) return false;   // the consumer's row source adds at most ROWSRC_MAX_SPLITS partials
+    if (K % s != 0 || s > ROWSRC_RS_SPLITS) return false;   // the consumer's row source adds at most ROWSRC_RS_SPLITS partials
     const int kw = K / s;
     return kw <= 1024 && kw % (SF_WAVES * 16) == 0;
 }
@@ -1255,9 +1535,9 @@ void launch_skinny_fused(const SkinnyFusedArgs& g0, hipStream_t s) {
     BG_REQUIRE(skinny_fused_supported(g.M, g.N, g.K, ln) && g.K % g.ksplit == 0 && (g.K / g.ksplit) <= 1024 && (g.K / g.ksplit) % (SF_WAVES * 16) == 0,
                "skinny_fused: unsupported shape M=%d N=%d K=%d ksplit=%d", g.M, g.N, g.K, g.ksplit);
     BG_REQUIRE(!ln || g.ksplit == 1, "skinny_fused: LayerNorm needs the whole row in one workgroup");
-    BG_REQUIRE(g.ksplit <= ROWSRC_MAX_SPLITS, "skinny_fused: at most %d K splits", ROWSRC_MAX_SPLITS);
+    BG_REQUIRE(g.ksplit <= ROWSRC_RS_SPLITS, "skinny_fused: at most %d K splits", ROWSRC_RS_SPLITS);
     BG_REQUIRE(g.lda % 4 == 0 && g.Wp, "skinny_fused: A stride must be a multiple of 4, weights packed");
-    BG_REQUIRE(!g.a_src || (ln && g.a_src->ns <= ROWSRC_MAX_SPLITS), "skinny_fused: a row source needs the LayerNorm form and at most %d partial sums", ROWSRC_MAX_SPLITS);
+    BG_REQUIRE(!g.a_src || (ln && g.a_src->ns <= ROWSRC_RS_SPLITS), "skinny_fused: a row source needs the LayerNorm form and at most %d partial sums", ROWSRC_RS_SPLITS);
     BG_REQUIRE(!g.xn_out || (ln && g.a_src), "skinny_fused: xn_out is the LayerNorm output of the row-source form");
     if (g.a_src) { g.src = rowsrc_fix(*g.a_src); g.a_src = nullptr; }
     const bool rs = g.src.base != nullptr;

@@ -539,6 +539,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
             top.force_wm = 4;                            // the part that was sized to fill whole rounds of 256-row blocks keeps them
             top.M = g.m_base + (int)gy_top * 256;        // end row of the first part
             bot.m_base = top.M;
+            // (the rest on a side stream BESIDE a first part that leaves CUs idle - one scene: 215 blocks on 256 CUs - was measured and rejected: the fork / join events cost
+            // more than the overlap buys, one scene 162.9 -> 173.4 ms, sixteen scenes 10.34 -> 10.30 scenes/s; profiles/r05_ab_rowsplit_side_*.txt)
             launch_gemm_split_glds(top, stream);
             launch_gemm_split_glds(bot, stream);
             return;

@@ -276,6 +276,31 @@ struct SkinnyFusedArgs {
     int has_ln_b = 0;                  // filled in by the launcher
     RowSrc src;                        // filled in by the launcher from a_src
 };
+// Both MLP projections of a decode layer in ONE launch (decode_fused.hip: ar_mlp_fused_kernel).  One workgroup per 16 hidden columns (4 D / 16 of them: 256 at D = 1024,
+// one per CU); workgroup i runs on XCD i % 8 and the 4 D / 128 workgroups of an XCD produce a contiguous D / 2 slice of the hidden row, which is exactly one K slice of the
+// down-projection: after an XCD-LOCAL exchange (plain stores, one L2 counter, no agent-scope fence: producers and consumers share the XCD's L2) every workgroup multiplies
+// that slice by its 32 output columns of the down matrix, whose weights it requested at kernel start.  Output: 8 partial planes [8][M][D] (one per XCD), summed in order by
+// the consumer's row source.  M <= 16, D = 1024, a device with at least 4 D / 16 CUs; the launch must have the GPU to itself (every workgroup of an XCD waits for
+// its 31 peers: see the co-residency note in decode_fused.hip).
+struct MlpFusedArgs {
+    const float* A = nullptr; int lda = 0;            // [M, D] rows entering ln2
+    const float* ln_w = nullptr;                       // ln2 gamma [D]
+    const float *ln_cs = nullptr, *ln_ds = nullptr;    // [4 D] each: W_up gamma and W_up beta + bias (launch_ar_ln_fold)
+    float eps = 1e-5f;
+    const float* Wup = nullptr;                        // packed operand image of the up matrix [4 D, D]
+    const float* Wdn = nullptr;                        // packed operand image of the down matrix [D, 4 D]
+    int w_f16 = 0;
+    float* hidden = nullptr;                           // [M][4 D] scratch (the GELU output, exchanged through L2)
+    float* C = nullptr;                                // [8][M][D] partial sums of the down-projection
+    unsigned* sync = nullptr;                          // mlp_fused_sync_words() words of device memory, zeroed once (barrier state per XCD + placement check)
+    unsigned* err = nullptr;                           // host-visible error word (non-zero: a barrier timed out / a workgroup was not on the XCD its index implies)
+    int M = 0, D = 0;
+    long long* trace = nullptr;
+};
+constexpr int MLP_FUSED_PLANES = 8;
+size_t mlp_fused_sync_words();
+bool mlp_fused_supported(int M, int D, bool w_f16);    // shape + device (CU count) check
+void launch_ar_mlp_fused(const MlpFusedArgs& g, hipStream_t s);
 size_t skinny_packed_floats(int N, int K);
 void launch_pack_skinny_weight(const float* W, float* Wp, int N, int K, hipStream_t s);
 void launch_pack_skinny_weight_f16(const float* W, void* Wp /* N16 * K halves */, int N, int K, hipStream_t s);

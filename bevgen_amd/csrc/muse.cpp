@@ -209,8 +209,11 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
             // to_q and to_kv read the same LayerNorm planes (muse_net:126-132): ONE projection over the concatenated weight, query / key / value preparation in its
             // epilogue ($BEVGEN_QKV_MERGE=0: the two launches of rounds 2-4, for A/B runs)
+            // Measured (same box, profiles/r05_ab_qkv_merge*.txt): one scene 161.9 -> 160.4 ms (two small-problem launches become one), sixteen scenes 10.31 -> 10.21
+            // scenes/s (2304 tiles in one launch against 768 + 1536: the A panels are re-fetched per 8-column step either way, EXPERIMENTS.md "fabric-traffic floor"):
+            // merged only on the low-latency path.  $BEVGEN_QKV_MERGE = 0 never, 2 always
             static const int qkv_merge = getenv("BEVGEN_QKV_MERGE") ? atoi(getenv("BEVGEN_QKV_MERGE")) : 1;
-            const bool merged = qkv_merge && l.to_qkv_self;
+            const bool merged = l.to_qkv_self && (qkv_merge == 2 || (qkv_merge == 1 && rows <= 3072));
             if (!merged) gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw);
             {   // to_kv with the key / value preparation in its epilogue: k planes [B, H, NkS_pad, 64], v planes transposed [B, H, 64, NkS_pad]
                 const size_t kvS_ = (size_t)B * H * c.NkS_pad * 64;

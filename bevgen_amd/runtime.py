@@ -384,6 +384,13 @@ class Context:
                                                C.byref(ks), self._s()))
         return out[0] if ks.value == 1 else out[:ks.value].sum(0)
 
+    def op_mlp_fused(self, x, ln_w, ln_b, w1, b1, w2, b2, w_f16=False, eps=1e-5):
+        """Both MLP projections of a Route A decode layer in one launch: Linear2(GELU(Linear1(LayerNorm(x)))) for M <= 16 rows, without the residual."""
+        M, D = x.shape
+        out = torch.empty((M, D), dtype=torch.float32, device=self.device)
+        self._check(self.lib.bevgen_op_mlp_fused(self._h, _ptr(x), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), int(w_f16), _ptr(out), M, D, self._s()))
+        return out
+
     def op_layernorm(self, x, gamma, beta=None, eps=1e-5):
         y = torch.empty_like(x)
         self._check(self.lib.bevgen_op_layernorm(self._h, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), x.shape[0], x.shape[1], float(eps), self._s()))

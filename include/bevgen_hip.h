@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BEVGEN_ABI_VERSION 4   /* 4: BEVGEN_PROFILE_KINDS 5 -> 6 (bevgen_profile_end writes 18 doubles), bevgen_cfg.decode_chains, decode_path values 2 / 3 */
+#define BEVGEN_ABI_VERSION 5   /* 5: bevgen_op_mlp_fused; a context without max_batch <= 4 packs the split decode layer lazily (see Conventions).  4: 4: BEVGEN_PROFILE_KINDS 5 -> 6 (bevgen_profile_end writes 18 doubles), bevgen_cfg.decode_chains, decode_path values 2 / 3 */
 
 enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
 /* FP32  : every product and accumulation in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32) - bit-exact greedy tokens vs the CPU reference.
@@ -235,6 +235,11 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_w, const fl
  * ksplit -1 (LayerNorm with beta and bias): one K slice, the LayerNorm folded into the product the way the decode step launches ln2 + MLP-up. */
 int bevgen_op_ln_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w, const float* d_bias, float* d_c,
                       int M, int N, int K, int act_gelu, int ksplit, int* ksplit_out, void* stream);
+/* Both MLP projections of a Route-A decode layer in one launch (decode_fused.hip ar_mlp_fused_kernel; Block.forward's mlp(ln2(x)), transformer/mingpt_sparse.py:232-253):
+ * d_out [M, D] = Linear2(GELU(Linear1(LayerNorm(d_x)))) WITHOUT the residual, M <= 16, D = 1024; w_f16: the matrices are rounded to fp16 first (decode_weights = f16).
+ * Returns BEVGEN_ERR_INVALID where the launch is not supported (shape, or a device with fewer CUs than its 4 D / 16 workgroups). */
+int bevgen_op_mlp_fused(bevgen_ctx* ctx, const float* d_x, const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w1 /*[4D, D]*/, const float* d_b1,
+                        const float* d_w2 /*[D, 4D]*/, const float* d_b2, int w_f16, float* d_out, int M, int D, void* stream);
 /* d_out[i] = the uniform the MaskGit samplers draw for element i of noise stream `stream_id` (0 gumbel, 1 critic) at iteration `iter` under `seed`. */
 int bevgen_op_philox_uniform(bevgen_ctx* ctx, unsigned long long seed, unsigned iter, unsigned stream_id, int V /* vocabulary size: row layout of stream 0 */, long n,
                              float* d_out, void* stream);

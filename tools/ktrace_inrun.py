@@ -82,4 +82,7 @@ def measure_traffic(kernel_substr, batch, steps, kv, weights, timeout=300):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1].startswith("traffic"):
+        print(measure_traffic("ar_attn_fused_kernel", 16, int(sys.argv[1][7:] or 16), "f16", "f16"))
+        sys.exit(0)
     print(measure("ar_attn_fused_kernel", 16, int(sys.argv[1]) if len(sys.argv) > 1 else 2100, "f16", "f16"))
