@@ -465,21 +465,6 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
         a.B = B; a.G = G; a.H = H; a.D = D; a.Lmax = Lmax; a.n = n; a.prefix = prefix; a.scale = 0.125f;
         a.trace = ctx->trace;
         if (split == -1) { a.stage_cap = 0; split = 0; }                       // the fused kernel without K/V pieces staged in LDS
-        unsigned *coop_err_h = nullptr;
-        if (split == -2) {                                                      // the head-cooperative projection (B = 16, D = 1024): fails where it is not supported
-            split = 0;
-            BG_REQUIRE(ar_attn_coop_supported(B, G, D, H, Lmax, kv_dtype), "op_ar_attn_fused: the head-cooperative form does not support B=%d G=%d D=%d H=%d (or BEVGEN_QKV_COOP=0)", B, G, D, H);
-            float* rows = nullptr; float* qkvs = nullptr; unsigned* sync = nullptr;
-            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&rows), (size_t)H * 16 * D * 4));   // (test entry: plain allocations, freed below)
-            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&qkvs), (size_t)H * 16 * 192 * 4));
-            HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sync), ar_attn_coop_sync_words(H) * 4));
-            HIP_CHECK(hipMemsetAsync(sync, 0, ar_attn_coop_sync_words(H) * 4, s));
-            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&coop_err_h), 64, hipHostMallocMapped));
-            *coop_err_h = 0;
-            unsigned* err_d = nullptr;
-            HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&err_d), coop_err_h, 0));
-            a.coop_rows = rows; a.coop_qkv = qkvs; a.coop_sync = sync; a.coop_err = err_d;
-        }
         if (split) {
             BG_REQUIRE(skinny_fused_supported(B, 3 * D, D, true) && (!w_f16 || skinny_fused_f16_ok(3 * D, D, true)), "op_ar_attn_fused: the split form does not support B=%d D=%d", B, D);
             float* wp = ctx->arena.get<float>(skinny_packed_floats(3 * D, D));
@@ -502,12 +487,6 @@ int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* x, const float* partia
             }
         }
         launch_ar_attn_fused(a, s);
-        if (coop_err_h) {
-            HIP_CHECK(hipStreamSynchronize(s));
-            const unsigned e = *coop_err_h;
-            (void)hipHostFree(coop_err_h); (void)hipFree(a.coop_rows); (void)hipFree(a.coop_qkv); (void)hipFree(a.coop_sync);
-            BG_REQUIRE(e == 0, "op_ar_attn_fused: the cooperative launch reported error word %u (4 = barrier timeout, 8 = a workgroup off the XCD its index implies)", e);
-        }
     });
 }
 

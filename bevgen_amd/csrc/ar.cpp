@@ -401,9 +401,6 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
             a.ln_w = l.ln1_w; a.ln_b = l.ln1_b; a.eps = 1e-5f;
             a.wqkv = l.wqkv; a.bqkv = l.bqkv; a.wqkv_h = l.wqkv_h;
             a.ln_cs = l.ln1_cs; a.ln_ds = l.ln1_ds;
-            if (Bc == B && c.coop_sync) {   // one chain: the head-cooperative projection where the shape qualifies (launch_ar_attn_fused decides)
-                a.coop_rows = c.coop_rows; a.coop_qkv = c.coop_qkv; a.coop_sync = c.coop_sync; a.coop_err = c.mlpf_err_dev;
-            }
         }
         a.kcache = reinterpret_cast<char*>(st.kcache) + i * layer_bytes + chain_off;
         a.vcache = reinterpret_cast<char*>(st.vcache) + i * layer_bytes + chain_off;

@@ -79,9 +79,9 @@ void Ctx::check_mlpf_error() {
     if (!mlpf_err_host || !*mlpf_err_host) return;
     const unsigned e = *mlpf_err_host;
     *mlpf_err_host = 0;
-    fail(BEVGEN_ERR_INTERNAL, "a workgroup-cooperative launch of the decode step failed (error word %u:%s%s): the tokens of the affected call are invalid.  BEVGEN_MLP_FUSE=0 / "
-         "BEVGEN_QKV_COOP=0 select the forms without an in-kernel exchange", e, (e & 5u) ? " an XCD-local barrier timed out - the launch did not have the GPU to itself;" : "",
-         (e & 10u) ? " a workgroup was not placed on the XCD its index implies" : "");
+    fail(BEVGEN_ERR_INTERNAL, "the fused MLP launch of the decode step failed (error word %u:%s%s): the tokens of the affected call are invalid.  BEVGEN_MLP_FUSE=0 selects "
+         "the two-launch form without an in-kernel exchange", e, (e & 1u) ? " an XCD-local barrier timed out - the launch did not have the GPU to itself;" : "",
+         (e & 2u) ? " a workgroup was not placed on the XCD its index implies" : "");
 }
 const DevTensor* Ctx::find(const std::string& name) const {
     auto it = params.find(name);
@@ -315,10 +315,7 @@ static void finalize_ar(Ctx& c) {
     if (fused_like) {   // state of the fused MLP launch (both projections of a layer in one launch, XCD-local exchange)
         c.mlpf_sync = reinterpret_cast<unsigned*>(c.own(mlp_fused_sync_words() * sizeof(unsigned)));
         HIP_CHECK(hipMemset(c.mlpf_sync, 0, mlp_fused_sync_words() * sizeof(unsigned)));
-        c.coop_rows = reinterpret_cast<float*>(c.own((size_t)c.H * 16 * D * sizeof(float)));
-        c.coop_qkv = reinterpret_cast<float*>(c.own((size_t)c.H * 16 * 192 * sizeof(float)));
-        c.coop_sync = reinterpret_cast<unsigned*>(c.own(ar_attn_coop_sync_words(c.H) * sizeof(unsigned)));
-        HIP_CHECK(hipMemset(c.coop_sync, 0, ar_attn_coop_sync_words(c.H) * sizeof(unsigned)));
+
         if (!c.mlpf_err_host) {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.mlpf_err_host), 64, hipHostMallocMapped));
             *c.mlpf_err_host = 0;

@@ -118,7 +118,7 @@ __device__ __forceinline__ float wave_sum2(float v0, float v1) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-constexpr long long MLPF_TIMEOUT_TICKS = 200LL * 1000 * 100;   // bound of the XCD-local barrier spins (ar_mlp_fused_kernel, ar_attn_coop_kernel): 200 ms of the 100 MHz clock
+constexpr long long MLPF_TIMEOUT_TICKS = 200LL * 1000 * 100;   // bound of the XCD-local barrier spin (ar_mlp_fused_kernel): 200 ms of the 100 MHz clock
 constexpr float kLog2eF = 1.44269504088896340736f;
 constexpr int AF_WAVES = 16;
 
@@ -429,7 +429,7 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
     AF_TRACE(5);
 }
 
-// Tail shared by the fused and the head-cooperative kernel: block layout (kernel-uniform branches: keys of absent blocks are hidden, the walk follows the list of chunks that
+// Tail of the fused kernel: block layout (kernel-uniform branches: keys of absent blocks are hidden, the walk follows the list of chunks that
 // hold a present block; list positions [0, n_pos) are the chunks that start below n, ascending; without a list position = chunk), then append + walk + merge + store.
 template <int DT, int G, bool SP, bool STG>
 __device__ __forceinline__ void af_layout_attend(const ArAttnFusedArgs& a, const SparseVis& vis, const uint8_t* lay_row, const uint16_t* chunk_row, float* bias_s, const float* qkv_s,
@@ -727,260 +727,9 @@ __global__ __launch_bounds__(1024) void ar_attn_fused_kernel(ArAttnFusedArgs a) 
     af_layout_attend<DT, G, SP, STG>(a, vis, lay_row, chunk_row, bias_s, qkv_s, red, list_s, n, head, b0, xn_s + head * 64, D, st_w + lane * 16, js);
 }
 
-// ----------------------------------------------------------------------------------------------------------------- head-cooperative ln1 + qkv + attention
-// ar_attn_coop_kernel: the same layer half as ar_attn_fused_kernel for B = 16, G = 1, D = 1024, with the q/k/v projection shared by the 16 sequence-workgroups of a head.
-//
-// Round 4 left the projection as the largest piece of the decode step's context-independent time: each of a head's 16 workgroups pulls the head's 393 KB (fp16) of weight rows
-// through the XCD's L2 - 100 MB of L2 -> CU traffic per layer for 6.3 MB of weights, L2-bandwidth bound at 7.9 us.  Workgroup (head h, sequence b) has linear index h + 16 b,
-// i.e. runs on XCD h % 8 (tools/xcc_probe; checked below): a head's 16 workgroups share one L2, and an exchange through it costs 1.1 us per barrier (tools/gridbar/
-// xcd_xchg_probe.hip: plain stores - the vector L1 is write-through -, one L2 counter, plain loads of lines this CU has not read in this launch; no agent-scope fence).  So:
-//   1. every workgroup fetches ITS row (row source) and publishes it raw                                             -> barrier
-//   2. every workgroup reads all 16 rows (64 KB from L2) into LDS, k-chunk-major like skinny_fused_kernel, computes the 16 rows' LayerNorm statistics in the shadow, and
-//      projects 12 of the head's 192 q | k | v columns for all 16 sequences as ONE 16 x 16 x 1024 MFMA tile (fp32 16x16x4, K split over the 16 waves, its 24 KB of weight
-//      rows requested at kernel start), LayerNorm folded in as in the fused kernel; publishes the 16 x 12 slice          -> barrier
-//   3. reads its own sequence's 192 values back, and goes on exactly like the fused kernel (append, staged K/V walk, merge, + ln1(x)).
-// Weight traffic per layer through L2: 6.3 MB instead of 100 MB; rows: 16 x 64 KB per head instead.
-// Co-residency, timeout and error word: as for ar_mlp_fused_kernel (256 workgroups, one per CU; the spin is bounded; ar.cpp serialises concurrent contexts).
-// LDS: the 64 KB row tile, the 16 KB of wave partial sums and gamma live in the K/V staging region, which is only filled afterwards.
-template <int DT, int WT, bool SP>
-__global__ __launch_bounds__(1024) void ar_attn_coop_kernel(ArAttnFusedArgs a) {
-    constexpr int NW = AF_WAVES, G = 1, SL = 12;   // SL: q | k | v columns of the head per workgroup (192 / 16)
-    extern __shared__ float smem[];
-    const int D = a.D;
-    float* bias_s = smem;
-    float* xn_s = bias_s + a.Lpad;
-    float* qkv_s = xn_s + G * D;
-    float* red = qkv_s + G * 192;
-    float* stat = red + NW * (G + 1) * 66;
-    uint16_t* list_s = reinterpret_cast<uint16_t*>(stat + NW * G);
-    char* stage = reinterpret_cast<char*>(list_s + ((a.Lpad / 16 + 2 + 7) & ~7));
-    float4* As = reinterpret_cast<float4*>(stage);                        // [D / 4][16 rows]: 64 KB
-    float* redc = reinterpret_cast<float*>(stage + 64 * 1024);            // [16 waves][4][64]: 16 KB
-    float4* gm_s = reinterpret_cast<float4*>(stage + 80 * 1024);          // gamma: 4 KB
-    float* st0 = red;                 // statistics of the 16 rows [16 waves][16] x 2, own head's raw x / gamma / beta: inside `red` (free until the key walk)
-    float* st1 = red + NW * 16;
-    float* xh_s = red + 2 * NW * 16;
-    float* gh_s = xh_s + 64;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int head = blockIdx.x, b0 = blockIdx.y;
-    const int n = a.d_n ? *a.d_n + a.n : a.n;
-    const int row = n - 1;
-    const float sl2 = a.scale * kLog2eF;
-    unsigned* cnt = a.coop_sync + 64 * head;
-    unsigned* gen = cnt + 32;
-    unsigned gen0 = 0;
-    if (tid == 0) gen0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    // staged K/V pieces: as in ar_attn_fused_kernel
-    using TS = KvRow<DT>;
-    constexpr int KPI = 64 / TS::LPK, PIECE = NW * KPI, SU = WalkU<DT, G>::value, ROWB = 64 * (DT ? 2 : 4);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const char* st_w = stage + (wave_u * a.stage_cap) * 1024;
-    int js = 0, cid_lane = 0;
-    if (a.stage_cap > 0) {
-        if (SP) {
-            const SparseVis& v0 = a.vis;
-            const uint16_t* crow = v0.chunks + (long)head * v0.chunks_head_stride + (long)(row / v0.blk) * v0.chunks_ld;
-            const int total = crow[0], pos = wave_u + NW * lane;
-            cid_lane = crow[1 + min(pos, max(v0.chunks_ld - 2, 0))];
-            const bool ok = pos < total && 16 * cid_lane + 16 <= n - 1 && lane < a.stage_cap / (2 * SU);
-            js = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok));
-        } else {
-            js = min(((n - 1) / PIECE) / SU, a.stage_cap / (2 * SU));
-        }
-    }
-    auto stage_issue = [&]() {
-        const long wrow = (((long)b0 * a.H + head) * a.Lmax + (SP ? 0 : wave_u * KPI)) * ROWB + lane * 16;
-        for (int q_iss = 0; q_iss < js * 2 * SU; ++q_iss) {
-            const int j = q_iss / (2 * SU), rr = q_iss % (2 * SU);
-            const long koff = SP ? (long)(16 * __builtin_amdgcn_readlane(cid_lane, j) + (rr % SU) * KPI) * ROWB : (long)(j * SU + rr % SU) * (PIECE * ROWB);
-            const char* src = reinterpret_cast<const char*>(rr >= SU ? a.vcache : a.kcache) + wrow + koff;
-            glds16_hidden_nt(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(st_w + q_iss * 1024)));
-        }
-    };
-
-#define AC_TRACE(i) do { if (a.trace && tid == 0) a.trace[(long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-    AC_TRACE(0);
-    // ---- requests.  Only my row (and gamma / beta) goes out now: the first barrier has to see the row's store acknowledged, and the only way to wait for a store is
-    //      vmcnt(0) - anything requested before it (the weight rows come cold from HBM, 2-3 us) would be waited for as well.  Everything else is requested by the
-    //      waves while workgroup's arrival is on its way (wave 0, which runs the barrier protocol on returning atomics, after it)
-    const int tcol = min(tid, D - 1);
-    const float xv = rowsrc_at(a.x, b0, tcol);
-    const float lw = a.ln_w[tcol], lb = a.ln_b[tcol];
-    float4 gm4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 256) gm4 = *reinterpret_cast<const float4*>(a.ln_w + 4 * min(tid, (D >> 2) - 1));
-    float* rows_g = a.coop_rows + (long)head * 16 * D;
-    if (tid < D) rows_g[(long)b0 * D + tid] = xv;
-    unsigned my_xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
-    my_xcc &= 0xf;
-    unsigned* xcc_g = a.coop_sync + 64 * head + 40;   // [16]: the XCD each of the head's workgroups saw (same 256-byte slot as the barrier words)
-    if (tid == 0) xcc_g[b0] = my_xcc;
-    if ((tid >> 6) == head && tid < D) { xh_s[lane] = xv; gh_s[lane] = lw; gh_s[64 + lane] = lb; }
-    if (tid < 256) gm_s[tid] = gm4;
-    __builtin_amdgcn_s_waitcnt(0);   // this wave's part of the row is in L2
-    __syncthreads();
-    // Barrier protocol (thread 0): arrive, last arriver cleans up and releases; `seen` = the generation before the barrier.  Bounded spin.
-    auto head_sync = [&](unsigned seen) {
-        unsigned ok = 1;
-        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == 16u) {
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            const long long t_in = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seen) {
-                __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memrealtime() - t_in > MLPF_TIMEOUT_TICKS) { ok = 0; break; }
-            }
-        }
-        if (!ok) atomicOr(a.coop_err, 4u);
-    };
-    if (wave == 0) { if (tid == 0) head_sync(gen0); }   // (wave 0 first runs the protocol: its returning atomics would otherwise wait for its weight rows)
-    // B operand of the MFMA: lane (r, q) holds the 8 (fp16) / 4 (fp32) consecutive k of weight row jg(r) that quarter q owns in each k-chunk of this wave's K slice (64)
-    const int jg_r = SL * b0 + min(r, SL - 1);                                        // my columns within the head's 192 (lanes r >= 12: a repeat, not stored)
-    const long wrow_r = ((long)(jg_r >> 6) * D + head * 64 + (jg_r & 63)) * D;
-    float4 wv[WT ? 1 : 4];
-    half8_t wh[WT ? 2 : 1];
-    if (WT) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) wh[u] = *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(a.wqkv_h) + wrow_r + 64 * wave + 32 * u + 8 * q);
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wv[u] = *reinterpret_cast<const float4*>(a.wqkv + wrow_r + 64 * wave + 16 * u + 4 * q);
-    }
-    float c_mine = 0.f, d_mine = 0.f;
-    if (tid < 256) {   // epilogue thread (reg j = tid >> 6, lane ln = tid & 63) finishes column ln & 15
-        const int jg = SL * b0 + min(tid & 15, SL - 1);
-        c_mine = a.ln_cs[(long)(jg >> 6) * D + head * 64 + (jg & 63)];
-        d_mine = a.ln_ds[(long)(jg >> 6) * D + head * 64 + (jg & 63)];
-    }
-    constexpr int BR = 3;
-    const SparseVis& vis = a.vis;
-    const uint8_t* keep_row = vis.allowed + (long)head * vis.allowed_head_stride + (long)row * vis.ldallowed;
-    const uint8_t* lay_row = vis.lay + (long)head * vis.lay_head_stride + (long)(row / vis.blk) * vis.nb;
-    const float* bias_row = a.bias + (long)row * a.ldbias;
-    float braw[BR];
-    uint8_t kraw[BR];
-#pragma unroll
-    for (int j = 0; j < BR; ++j) {
-        const int k = min(tid + 1024 * j, n - 1);
-        braw[j] = bias_row[k];
-        kraw[j] = keep_row[k];
-    }
-    const uint16_t* chunk_row = vis.chunks + (long)head * vis.chunks_head_stride + (long)(row / vis.blk) * vis.chunks_ld;
-
-    lds_barrier();   // (LDS only: the weight rows and bias row stay in flight across it)
-    AC_TRACE(6);
-    const unsigned xcc_peer = xcc_g[min(tid, 15)];   // (compared behind the MFMAs: a use here would hold wave 0's row loads behind its weight rows)
-
-    // ---- 2. all 16 rows -> LDS (k-chunk-major), statistics, my 12 columns for all 16 sequences
-    float4 v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(rows_g + (long)r * D + 4 * (q + 4 * wave + 64 * j));
-    {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-        s += xor16(s);
-        s += xor32(s);
-        if (q == 0) st0[wave * 16 + r] = s;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) As[(q + 4 * wave + 64 * j) * 16 + r] = v[j];
-    lds_barrier();
-    float4 aop[4];
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += st0[w * 16 + r];
-        const float mean = t / (float)D;
-        float qq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
-            qq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-        }
-        qq += xor16(qq);
-        qq += xor32(qq);
-        if (q == 0) st1[wave * 16 + r] = qq;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {   // operand i of the MFMA loop: x o gamma of k-chunk c4 (4 consecutive k) of row r
-            const int c4 = WT ? ((64 * wave + 32 * (i >> 1)) >> 2) + 2 * q + (i & 1) : ((64 * wave + 16 * i) >> 2) + q;
-            aop[i] = mul4(As[c4 * 16 + r], gm_s[c4]);
-        }
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (WT) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float4 a0 = aop[2 * u], a1 = aop[2 * u + 1];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, (float)wh[u][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, (float)wh[u][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, (float)wh[u][2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, (float)wh[u][3], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, (float)wh[u][4], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, (float)wh[u][5], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, (float)wh[u][6], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, (float)wh[u][7], acc, 0, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 a4 = aop[u];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, wv[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, wv[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, wv[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, wv[u].w, acc, 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) redc[(wave * 4 + j) * 64 + lane] = acc[j];
-    if (tid < 16 && xcc_peer != my_xcc) atomicOr(a.coop_err, 8u);   // a peer that is NOT on this XCD: its stores are not in this L2 (placement assumption broken)
-    // bias row of this step with the visibility mask folded in (through registers since kernel start)
-#pragma unroll
-    for (int j = 0; j < BR; ++j)
-        if (tid + 1024 * j < n)
-            bias_s[tid + 1024 * j] = (kraw[j] || !vis.has_allowed) ? (a.has_bias ? braw[j] * sl2 : 0.f) : kNegBig;
-    for (int k = tid + 1024 * BR; k < n; k += 1024)
-        bias_s[k] = (keep_row[k] || !vis.has_allowed) ? (a.has_bias ? bias_row[k] * sl2 : 0.f) : kNegBig;
-    lds_barrier();
-    AC_TRACE(7);
-    float* qkv_g = a.coop_qkv + (long)head * 16 * 192;
-    if (tid < 256) {   // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg; thread t finishes (reg j = t >> 6, lane t & 63)
-        const int j = tid >> 6, ln = tid & 63;
-        float o = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) o += redc[(w * 4 + j) * 64 + ln];
-        const int seq = 4 * (ln >> 4) + j, col = ln & 15;
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { t1 += st0[w * 16 + seq]; t2 += st1[w * 16 + seq]; }
-        const float mean = t1 / (float)D, rstd = rsqrtf(t2 / (float)D + a.eps);
-        if (col < SL) qkv_g[(long)seq * 192 + SL * b0 + col] = rstd * (o - mean * c_mine) + d_mine;
-    } else if (tid < 320) {   // the residual ln1(x) of my row, this head's 64 columns (Block.forward adds the NORMALISED row)
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { t1 += st0[w * 16 + b0]; t2 += st1[w * 16 + b0]; }
-        const float mean = t1 / (float)D, rstd = rsqrtf(t2 / (float)D + a.eps);
-        xn_s[head * 64 + lane] = (xh_s[lane] - mean) * rstd * gh_s[lane] + gh_s[64 + lane];
-    }
-    __builtin_amdgcn_s_waitcnt(0);   // my slice is in L2
-    __syncthreads();
-    if (tid == 0) head_sync(gen0 + 1);
-    __syncthreads();
-    // ---- 3. my sequence's q | k | v
-    if (tid < 192) qkv_s[tid] = qkv_g[(long)b0 * 192 + tid];
-    // The K/V pieces go out behind the CONSUMED read-back: the compiler does not count hidden requests, so a value loaded before them and used after them is waited for with
-    // vmcnt(0) - i.e. behind all 128 KB of pieces.  The row tile / partial sums in the region are dead: every wave passed the barrier above after its last read of them.
-    stage_issue();
-    lds_barrier();   // (not __syncthreads(): its vmcnt(0) would wait for the 128 KB of pieces just requested)
-    AC_TRACE(2);
-    af_layout_attend<DT, G, SP, true>(a, vis, lay_row, chunk_row, bias_s, qkv_s, red, list_s, n, head, b0, xn_s + head * 64, D, st_w + lane * 16, js);
-#undef AC_TRACE
-}
+// (A head-cooperative form of this kernel - the 16 sequence-workgroups of a head exchanging rows and 12-column q | k | v slices through the XCD's L2, so that the head's
+// weight rows cross the L2 -> CU path once instead of 16 times - was built in round 5, parity-green, and measured slower: two serialized exchanges + the 64 KB row tile
+// cost 7.7 us against the ~4.4 us the projection proper takes here (the rest of "ln1 done -> qkv done" is the K/V piece issue).  git history + EXPERIMENTS.md round 5.)
 
 // ----------------------------------------------------------------------------------------------------------------- decode attention proper
 // decode_path = split: the row's q | k | v were projected for the whole batch by the LayerNorm + QKV kernel (skinny_fused_kernel<LN, RS>: the weight matrix is read from
@@ -1097,18 +846,6 @@ void launch_ar_ln_fold(const float* W, const float* b, const float* gamma, const
 
 bool ar_attn_fused_supported(int B, int G, int D, int H) { return D == H * 64 && D % 4 == 0 && D <= 1024 && (G == 1 || G == 2 || G == 4) && B % G == 0; }
 
-size_t ar_attn_coop_sync_words(int H) { return (size_t)64 * H; }
-bool ar_attn_coop_supported(int B, int G, int D, int H, int Lmax, int kv_dtype) {
-    static const int env = getenv("BEVGEN_QKV_COOP") ? atoi(getenv("BEVGEN_QKV_COOP")) : 1;
-    if (!env || B != 16 || G != 1 || D != 1024 || H * 64 != D || H % 8 != 0) return false;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < B * H) return false;
-    // the row tile (64 KB), the wave partial sums (16 KB) and gamma (4 KB) borrow the K/V staging region: it must exist
-    const size_t base = ar_attn_fused_lds_bytes(G, D, (int)round_up(Lmax, 4));
-    (void)kv_dtype;
-    return ar_attn_fused_max_lds() >= base + 1024 + 84 * 1024;
-}
-
 void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     ArAttnFusedArgs a = a0;
     BG_REQUIRE(ar_attn_fused_supported(a.B, a.G, a.D, a.H), "fused decode attention: unsupported shape B=%d G=%d D=%d H=%d", a.B, a.G, a.D, a.H);
@@ -1128,7 +865,6 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     BG_REQUIRE(lds <= 64 * 1024, "fused decode attention: %zu bytes of LDS needed (sequence length %d too long)", lds, a.Lmax);
     // K/V staging (fused kernel, G = 1, dense walk): what the CU's LDS has left beyond the kernel's own 24 KB, in whole pipeline steps per wave (gfx950: 160 KB per
     // workgroup -> 8 pieces per wave = 128 KB).  $BEVGEN_KV_STAGE overrides the launcher's choice (A/B switch; 0 = off)
-    const bool coop = !pre && a.coop_rows && a.coop_qkv && a.coop_sync && a.coop_err && a.ksplit == 1 && ar_attn_coop_supported(a.B, a.G, a.D, a.H, a.Lmax, a.kv_dtype);
     if (!pre && a.G == 1) {
         static const int env_cap = getenv("BEVGEN_KV_STAGE") ? atoi(getenv("BEVGEN_KV_STAGE")) : -1;
         const int step_pieces = 2 * (a.kv_dtype == 0 ? 4 : 2);   // K + V pieces of one pipeline step (WalkU)
@@ -1137,7 +873,6 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
         cap = std::max(0, std::min(cap, room)) / step_pieces * step_pieces;
         a.stage_cap = cap;
         lds += (size_t)cap * AF_WAVES * 1024;
-        if (coop) lds = std::max(lds, (pre ? 0 : ar_attn_fused_lds_bytes(a.G, a.D, a.Lpad)) + (size_t)84 * 1024);   // (staging switched off: the cooperative kernel still needs its row tile)
     } else {
         a.stage_cap = 0;
     }
@@ -1169,15 +904,6 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
 #undef AP_LAUNCH_G
 #undef AP_LAUNCH
 #undef AP_LAUNCH1
-    } else if (coop) {
-#define AC_LAUNCH1(K) do { static std::atomic<bool> bigc[MAX_DEVICES]; if (!bigc[dev_slot].load(std::memory_order_acquire)) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ar_attn_fused_max_lds() - 1024)); bigc[dev_slot].store(true, std::memory_order_release); } \
-                           if (prof.attached()) hipExtLaunchKernelGGL(K, grid, dim3(1024), lds, s, prof.ev_a(), prof.ev_b(), 0, a); \
-                           else hipLaunchKernelGGL(K, grid, dim3(1024), lds, s, a); } while (0)
-#define AC_LAUNCH(DT, WW) do { if (sp) AC_LAUNCH1((ar_attn_coop_kernel<DT, WW, true>)); else AC_LAUNCH1((ar_attn_coop_kernel<DT, WW, false>)); } while (0)
-        if (a.wqkv_h) { if (a.kv_dtype == 0) AC_LAUNCH(0, 1); else AC_LAUNCH(1, 1); }
-        else { if (a.kv_dtype == 0) AC_LAUNCH(0, 0); else AC_LAUNCH(1, 0); }
-#undef AC_LAUNCH
-#undef AC_LAUNCH1
     } else if (a.wqkv_h) {
         if (a.kv_dtype == 0) AF_LAUNCH_G(0, 1); else AF_LAUNCH_G(1, 1);
     } else {

@@ -255,17 +255,7 @@ struct ArAttnFusedArgs {
     // from HBM.  -1 = the launcher's choice ($BEVGEN_KV_STAGE overrides), 0 = off
     int stage_cap = -1;
     int has_bias = 0;                  // filled in by the launcher
-    // Head-cooperative q/k/v projection (ar_attn_coop_kernel; B = 16, G = 1, D = 1024, H % 8 == 0): the 16 sequence-workgroups of a head sit on one XCD and exchange
-    // through its L2 - every workgroup publishes its raw row, reads all 16, projects 12 of the head's 192 q|k|v columns for ALL 16 sequences as one MFMA tile, publishes that
-    // slice and reads its own sequence's 192 values back: the head's weight rows cross the L2 -> CU path once per head instead of once per sequence.
-    // All four non-null = use it (the launcher falls back when the shape does not qualify).
-    float* coop_rows = nullptr;        // [H][16][D] scratch
-    float* coop_qkv = nullptr;         // [H][16][192] scratch
-    unsigned* coop_sync = nullptr;     // [H][64] words, zeroed once (self-cleaning barrier: count at +0, generation at +32)
-    unsigned* coop_err = nullptr;      // host-visible error word (4 = barrier timeout, 8 = a workgroup off the XCD its index implies)
 };
-bool ar_attn_coop_supported(int B, int G, int D, int H, int Lmax, int kv_dtype);
-size_t ar_attn_coop_sync_words(int H);
 bool ar_attn_fused_supported(int B, int G, int D, int H);
 // per-row constants of LayerNorm folded into a projection: cs[j] = sum_k W[j][k] gamma[k], ds[j] = sum_k W[j][k] beta[k] + b[j]   (W [N, K] row-major; fp64 accumulation)
 void launch_ar_ln_fold(const float* W, const float* b, const float* gamma, const float* beta, float* cs, float* ds, int N, int K, hipStream_t s);

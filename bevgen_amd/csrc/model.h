@@ -172,7 +172,6 @@ struct Ctx {
     // under the tail of their K/V walk.  Measured slower on the same box (1.55 -> 1.65 / 1.61 ms/step, profiles/r03_ab_prefetch.txt): default off
     // fused MLP launch of the decode step (decode_fused.hip ar_mlp_fused_kernel): barrier words (device, zeroed at finalize) and the host-visible error word
     unsigned* mlpf_sync = nullptr;
-    float *coop_rows = nullptr, *coop_qkv = nullptr; unsigned* coop_sync = nullptr;   // head-cooperative q/k/v projection (ar_attn_coop_kernel): exchange scratch + barrier words
     unsigned *mlpf_err_host = nullptr, *mlpf_err_dev = nullptr;
     void check_mlpf_error();      // throws when a fused MLP launch reported a timeout / a broken placement assumption
     long long* trace = nullptr;   // diagnostics (bevgen_set_trace_buffer): phase timestamps of the fused decode kernels, [3 kinds][4096 workgroups][8]

@@ -416,54 +416,6 @@ def test_ar_attn_fused2_operator(gpu_ctx, B, H, n, Lmax, masked, wf16, kv, form)
     assert torch.equal(dkc[:, :, keep].float().cpu(), kc[:, :, keep]) and torch.equal(dvc[:, :, keep].float().cpu(), vc[:, :, keep])
 
 
-@pytest.mark.parametrize("kv", ["f32", "f16"])
-@pytest.mark.parametrize("n,Lmax,sparse,wf16,ns", [(1301, 2368, False, True, 8), (1301, 2368, True, False, 8), (1, 2368, False, False, 4), (2, 512, True, True, 0),
-                                                   (2368, 2368, False, True, 8), (300, 1024, False, False, 3)])
-def test_ar_attn_coop_operator(gpu_ctx, n, Lmax, sparse, wf16, ns, kv):
-    """ar_attn_coop_kernel (split = -2): the decode layer's attention half for B = 16, D = 1024 with the q/k/v projection shared by the 16 sequence-workgroups of a head
-    (rows and 12-column slices exchanged through the XCD's L2, two counter barriers) against fp64: the same contract as the fused kernel - output rows, appended k / v rows,
-    nothing else touched - over dense and block-sparse walks (staged K/V pieces), both cache and weight dtypes, 0 / 3 / 4 / 8 partial planes in the row source (8 = the
-    planes of the fused MLP launch), n = 1 and n = L.  The entry fails on a barrier timeout or a workgroup off its XCD; two calls give identical bits."""
-    B, H, blk = 16, 16, 16
-    D = H * 64
-    g = torch.Generator().manual_seed(n + ns)
-    x = torch.randn(B, D, generator=g)
-    partial = torch.randn(ns, B, D, generator=g) * 0.3 if ns else None
-    rbias = torch.randn(D, generator=g) * 0.1
-    ln_w, ln_b = torch.randn(D, generator=g) * 0.2 + 1, torch.randn(D, generator=g) * 0.1
-    wqkv = torch.randn(3 * D, D, generator=g) / math.sqrt(D)
-    bqkv = torch.randn(3 * D, generator=g) * 0.1
-    kc = torch.randn(B, H, Lmax, 64, generator=g)
-    vc = torch.randn(B, H, Lmax, 64, generator=g)
-    bias = torch.randn(Lmax, Lmax, generator=g)
-    mask = layout = None
-    if sparse:
-        mask = (torch.rand(Lmax, Lmax, generator=g) > 0.2).float()
-        layout = (torch.rand(H, Lmax // blk, Lmax // blk, generator=g) < 0.4).long()
-        mask[:, 0] = 1
-        layout[:, :, 0] = 1
-    if kv == "f16":
-        kc, vc = kc.half().float(), vc.half().float()
-    ref, k_new, v_new = _ar_attn_reference(x, partial, rbias, ln_w, ln_b, wqkv.half().float() if wf16 else wqkv, bqkv, kc, vc, n, bias, mask, layout, blk, 1, 0)
-    cdt = torch.float16 if kv == "f16" else torch.float32
-    outs = []
-    for _ in range(2):
-        dkc, dvc = dev(kc.to(cdt)), dev(vc.to(cdt))
-        out = gpu_ctx.op_ar_attn_fused(dev(x), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dkc, dvc, n, partial=None if partial is None else dev(partial), rbias=None if partial is None else dev(rbias),
-                                       bias=dev(bias), attn_mask=None if mask is None else dev(mask), layout=None if layout is None else dev(layout), block=blk,
-                                       kv_dtype=1 if kv == "f16" else 0, w_f16=wf16, split=-2)
-        outs.append(out.cpu())
-    assert torch.equal(outs[0], outs[1])
-    assert rel(outs[0].double(), ref) < (2e-3 if kv == "f16" else 2e-5)
-    assert rel(dkc[:, :, n - 1].float().cpu().double(), k_new) < (1e-3 if kv == "f16" else 1e-5)
-    assert rel(dvc[:, :, n - 1].float().cpu().double(), v_new) < (1e-3 if kv == "f16" else 1e-5)
-    keep = torch.ones(Lmax, dtype=torch.bool)
-    keep[n - 1] = False
-    assert torch.equal(dkc[:, :, keep].float().cpu(), kc[:, :, keep]) and torch.equal(dvc[:, :, keep].float().cpu(), vc[:, :, keep])
-    with pytest.raises(Exception, match="head-cooperative form does not support"):
-        gpu_ctx.op_ar_attn_fused(dev(x[:8]), dev(ln_w), dev(ln_b), dev(wqkv), dev(bqkv), dev(kc[:8].to(cdt)), dev(vc[:8].to(cdt)), n, split=-2, kv_dtype=1 if kv == "f16" else 0)
-
-
 @pytest.mark.parametrize("split", [False, True])
 def test_ar_attn_fused_operator_f16_weights(gpu_ctx, split):
     B, H, n, Lmax = 16, 16, 700, 1024
