@@ -372,21 +372,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
             if (do_swish) o = o / (1.f + expf(-o));
             out[k] = o;
         }
-        if (PLANES) {
-            // Neighbouring lanes (two consecutive float4 of one pixel: C / 4 is even, i and the grid stride keep the lane's parity) trade halves so that every lane stores 16
-            // contiguous bytes - the even lane the hi parts of the pair's 8 channels, the odd lane the lo parts: one store instruction of a wave covers whole 128-byte lines
-            // (as the LayerNorm plane writer does; store_planes4 writes 8 bytes of each plane per lane, two instructions that each touch half of every line)
-            const bool odd = threadIdx.x & 1;
-            half4_t h, l;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { h[k] = split_hi(out[k]); l[k] = split_lo(out[k], h[k]); }
-            const uint2 hw2 = __builtin_bit_cast(uint2, h), lw2 = __builtin_bit_cast(uint2, l);
-            const uint2 send = odd ? hw2 : lw2;
-            const uint2 recv = make_uint2((unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xf, 0xf, true));
-            const uint4 o16 = odd ? make_uint4(recv.x, recv.y, lw2.x, lw2.y) : make_uint4(hw2.x, hw2.y, recv.x, recv.y);
-            const int c8 = 8 * (cq >> 1);
-            *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(y) + pix * 2 * C + (c8 >> 5) * 64 + (c8 & 31) + (odd ? 32 : 0)) = o16;
-        } else reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
+        if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + pix * 2 * C, cq * 4, make_float4(out[0], out[1], out[2], out[3]));
+        else reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -398,7 +385,7 @@ void launch_groupnorm_apply(const float* x, const float* stats, const float* gam
 }
 
 void launch_groupnorm_apply_planes(const float* x, const float* stats, const float* gamma, const float* beta, void* planes, int n, int hw, int C, int do_swish, hipStream_t s) {
-    BG_REQUIRE(C % 32 == 0, "groupnorm_apply_planes: C=%d must be a multiple of 32", C);   // (also: the lane-pair store needs C % 8 == 0)
+    BG_REQUIRE(C % 32 == 0, "groupnorm_apply_planes: C=%d must be a multiple of 32", C);
     const long total4 = (long)n * hw * C / 4;
     const int blocks = (int)std::min<long>((total4 + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(groupnorm_apply_kernel<true>, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, reinterpret_cast<float*>(planes), total4, hw, C, do_swish);

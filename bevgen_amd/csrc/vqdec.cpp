@@ -214,8 +214,10 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
         }
     }
     const long attn_hwp = round_up(attn_hw, 32);
-    static const int chunk_env = getenv("BEVGEN_VQ_CHUNK") ? atoi(getenv("BEVGEN_VQ_CHUNK")) : 0;   // A/B switch
-    const int chunk_max = chunk_env > 0 ? chunk_env : 48;   // images per pass: the 16 x 16 stages only fill the chip (256 x 128 tiles on 256 CUs) from ~48 images; 148 -> 128 ms per 96 images vs 16, arena ~10 GB
+    // images per pass: the 16 x 16 stages only fill the chip (256 x 128 tiles on 256 CUs) from ~48 images; 148 -> 128 ms per 96 images vs 16, arena ~10 GB.  (Round 5: smaller
+    // passes whose full-resolution tensors would fit the 256 MB memory-side cache between conv -> statistics -> apply -> conv are slower throughout: 6 / 12 / 24 images per
+    // pass 11.96 / 9.14 / 7.96 ms per scene against 7.47, profiles/r05_ab_vq.txt)
+    const int chunk_max = 48;
     const int attn_c = max_c;
     const int chunk = std::min(n_total, chunk_max);
     const size_t act_b = (size_t)per_img * chunk * sizeof(float);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """VQGAN decode alone at the bench shape: n images (default 96 = 16 six-view scenes) of 16 x 16 latents -> 256 x 256 uint8; ms per scene over a few repetitions.
-usage: vq_probe.py [n=96] [precision=f16x3] [reps=5]     ($BEVGEN_VQ_CHUNK etc. are read by the library)"""
+usage: vq_probe.py [n=96] [precision=f16x3] [reps=5]     """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,5 +24,5 @@ for _ in range(reps):
     out = ctx.vq_decode(ids, uint8=True)
     torch.cuda.synchronize()
     ts.append(time.time() - t0)
-print(f"n={n} precision={precision} chunk={os.environ.get('BEVGEN_VQ_CHUNK', 'default')}: {min(ts) * 1e3 / (n / 6):.3f} ms per six-view scene (best of {reps}; mean {sum(ts) / len(ts) * 1e3 / (n / 6):.3f}), checksum {int(out.long().sum())}")
+print(f"n={n} precision={precision}: {min(ts) * 1e3 / (n / 6):.3f} ms per six-view scene (best of {reps}; mean {sum(ts) / len(ts) * 1e3 / (n / 6):.3f}), checksum {int(out.long().sum())}")
 ctx.close()
