@@ -1210,8 +1210,8 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 // other: the spin is bounded (MLPF_TIMEOUT_TICKS of the 100 MHz clock) and a timeout raises the context's error word instead of hanging; the host serialises the decode
 // steps of different contexts of one process on a device (ar.cpp) so that this does not happen in the first place.
 //
-// The barrier is sense-reversing and cleans up after itself (count back to 0, generation + 1 by the last arriver): nothing has to be reset between launches, so the launch
-// replays inside a hipGraph.  Its words live at sync[64 x] (count) and sync[64 x + 32] (generation), one 256-byte slot per XCD; sync[512 + i] records the XCD workgroup i saw.
+// The barrier word is a monotonic arrival counter (one per XCD at sync[64 x], a 256-byte slot each): nothing has to be reset between launches, so the launch replays inside
+// a hipGraph; sync[512 + i] records the XCD workgroup i saw.
 size_t mlp_fused_sync_words() { return 512 + 1024; }
 
 template <int WT>   // weight storage of both packed images: 0 fp32, 1 fp16
@@ -1231,10 +1231,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     const int slice = K2 >> 3, kper2 = slice / SF_WAVES;                                 // phase 2: this XCD's K slice of the down-projection (512), per wave (64)
 #define MF_TRACE(i) do { if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     MF_TRACE(0);
-    unsigned* cnt = g.sync + 64 * xcd;
-    unsigned* gen = g.sync + 64 * xcd + 32;
-    unsigned gen0 = 0;
-    if (tid == 0) gen0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an L2-coherent read: the vector L1 never serves it)
+    unsigned* cnt = g.sync + 64 * xcd;   // monotonic arrival counter of this XCD's workgroups (never reset: per_xcd arrivals per launch, compared modulo 2^32)
     // ---- requests, in the order the results are needed: rows, gamma, row constants, up weights, down weights
     const int mr = min(r, g.M - 1);
     float4 v[8];
@@ -1370,13 +1367,14 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     __syncthreads();
     if (tid == 0) {
         unsigned ok = 1;
+        // One atomic per arrival and nothing to clean up: the counter only grows, launch k of this buffer's life takes it from k per_xcd to (k + 1) per_xcd (launches on
+        // one buffer are serialised), so the value my own arrival returns tells me which multiple of per_xcd completes MY launch.  The last arrival IS the release - no
+        // second word, no second round trip on the critical path - and the comparison is modulo 2^32 (134 million launches per wrap, and a wrap is harmless).
         const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1 == (unsigned)per_xcd) {   // last arriver: clean up, then release the others
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+        const unsigned target = (old / (unsigned)per_xcd + 1u) * (unsigned)per_xcd;
+        if (old + 1u != target) {
             const long long t_in = __builtin_amdgcn_s_memrealtime();
-            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+            while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // (an L2-coherent read: the vector L1 never serves it)
                 __builtin_amdgcn_s_sleep(1);
                 if (__builtin_amdgcn_s_memrealtime() - t_in > MLPF_TIMEOUT_TICKS) { ok = 0; break; }
             }

@@ -34,7 +34,7 @@ def test_bench_world_2_control_flow_under_gloo():
     assert abs(d["value"] - 2 * 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6     # whole-job scenes / max-over-ranks time
     assert d["rccl_world_size"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.0001   # per-rank K-step times <= the job's
     legs = d["legs"]
-    assert list(d)[-1] == "legs", "the flat per-leg scalars come LAST in the line (they must survive a tail cut)"
+    assert list(d)[-2:] == ["legs", "roofline_decode_attention"] or list(d)[-1] == "legs", "the flat per-leg scalars (and the decode-attention roofline) come LAST in the line: they must survive a tail cut"
     s = legs["strong_scaling"]
     assert s["global_batch"] == 16 and s["scenes_per_s"] > 0 and len(s["per_rank_ms_per_step"]) == 2
     c5 = legs["config5"]       # BASELINE configs[4] across the ranks: 64 sequences per GPU, token ids gathered to rank 0
