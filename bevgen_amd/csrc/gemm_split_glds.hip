@@ -29,6 +29,14 @@
 namespace bevgen {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+// sum over an aligned row of 16 lanes with DPP row operations (every lane of the row ends with the row's sum)
+__device__ __forceinline__ float row16_sum(float d) {
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0x140, 0xf, 0xf, true));   // row_mirror
+    return d;
+}
 
 constexpr int GBN = 128, GBK = 32;
 constexpr float kGLoInv = 1.f / 2048.f;
@@ -474,6 +482,16 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                     }
                     f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
                     *reinterpret_cast<f32x4*>(cp) = o;
+                    if (MODE == MODE_CONV3 && g.gn_part) {
+                        // GroupNorm statistics of the output tensor: this lane's 4 consecutive channels of its row, summed over the 32 rows (lanes) of the half -
+                        // one (sum, sum of squares) pair per (32 rows, 4 channels).  The launcher guarantees whole tiles (every lane here, no tail), so the DPP row sums
+                        // and the cross-row exchange run with all lanes active
+                        float s4 = (v[0] + v[1]) + (v[2] + v[3]);
+                        float q4 = fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+                        s4 = row16_sum(s4); q4 = row16_sum(q4);
+                        s4 += xor16(s4); q4 += xor16(q4);
+                        if (r == 0) *reinterpret_cast<float2*>(g.gn_part + ((long)(m >> 5) * (g.N >> 2) + (n >> 2)) * 2) = make_float2(s4, q4);
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -497,6 +515,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         g.a_bytes = (int)(unsigned)a_bytes;
     }
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
+    if (g.gn_part)
+        BG_REQUIRE(g.mode == MODE_CONV3 && g.epi == 0 && g.ksplit <= 1 && g.M % 256 == 0 && g.m_base == 0 && g.N % GBN == 0 && g.ldc == g.N && (g.ldc & 3) == 0 &&
+                       (!g.R || (g.ldr & 3) == 0) && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.R || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0) && !g.bias_m,
+                   "gemm_split_glds: GroupNorm partials need whole 256 x 128 tiles of a convolution with the plain epilogue (M=%d N=%d)", g.M, g.N);
     BG_REQUIRE(g.K % GBK == 0 && g.lda % GBK == 0 && g.ldb % GBK == 0, "gemm_split_glds: K, lda, ldb must be multiples of 32 (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
     BG_REQUIRE(g.batch == 1, "gemm_split_glds: batched form not provided");
     if (g.epi == EPI_MUSE_KV)

@@ -56,6 +56,10 @@ struct GemmArgs {
     const void* epi_aux = nullptr;
     int epi_ld = 0;
     float epi_post = 1.f;             // EPI_MUSE_Q: extra factor on the prepared query (the attention kernel's score scale, folded in here)
+    // MODE_CONV3 on the LDS-DMA kernel, plain epilogue: the GroupNorm(32) statistics of the OUTPUT tensor leave the epilogue as partial sums - per 32 output rows (pixels)
+    // and 4 output channels one (sum, sum of squares) pair, gn_part [M / 32][N / 4][2] fp32 - so that the consumer's GroupNorm needs no statistics pass over the tensor
+    // (launch_groupnorm_stats_from_partials).  Needs M % 256 == 0 (a row tile never straddles two images: hw % 256 == 0), N % 128 == 0, ldc == N
+    float* gn_part = nullptr;
     // EPI_MUSE_QKV (Route M self-attention): to_q and to_kv as ONE projection [rows, 3 H 64] = q | k | v over the concatenated weight - the LayerNorm planes are read once
     // instead of twice and a launch disappears.  Column tiles below H 64 take the EPI_MUSE_Q epilogue with (epi_qh, epi_ql, epi_qscale), the rest the EPI_MUSE_KV one
     // with the fields above (columns counted from H 64)
@@ -102,8 +106,13 @@ bool vq_out_conv_supported(int C, int cout);
 void launch_vq_out_conv(const float* x, const float* stats, const float* gamma, const float* beta, const float* wgt, const float* bias, const float* mean, const float* stdv, int clamp01,
                         float* y, uint8_t* y8, int n, int H, int W, int C, int cout, hipStream_t s);
 void launch_groupnorm_stats(const float* x, float* stats, void* ws /*groupnorm_ws_bytes*/, int n, int hw, int C, float eps, hipStream_t s);
+// the same statistics from the producing convolution's epilogue partials (GemmArgs::gn_part): no pass over the tensor; fp64 reduction in a fixed order
+bool groupnorm_partials_supported(int hw, int C);   // hw % 256 == 0 and whole 4-channel quads per group (C % 128 == 0)
+size_t groupnorm_part_floats(int n, int hw, int C);
+void launch_groupnorm_stats_from_partials(const float* part, float* stats, int n, int hw, int C, float eps, hipStream_t s);
 // y = (x-mean)*rstd*gamma+beta, optionally followed by swish (x*sigmoid(x)); NHWC
 void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s);
+void launch_to_planes(const float* x, void* planes, int n, int hw, int C, hipStream_t s);   // fp32 NHWC -> (hi, lo) plane image, values unchanged (C / 4 a power of two)
 void launch_groupnorm_apply_planes(const float* x, const float* stats, const float* gamma, const float* beta, void* planes, int n, int hw, int C, int do_swish, hipStream_t s);
 
 // ---------------------------------------------------------------- attention.hip

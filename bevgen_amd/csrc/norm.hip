@@ -296,7 +296,22 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __r
     const int p_end = min(hw, p_begin + GN_PIX_PER_BLOCK);
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     const float* base = x + ((long)n * hw) * C + cq * 4;
-    for (int p = p_begin + psub; p < p_end; p += pstep) {
+    // four independent loads in flight per thread (one load per iteration left the pass latency bound: 0.59 ms per scene for ONE read of every activation, where the apply
+    // pass reads and writes them in 0.7); the sums stay in the order p_begin + psub, + pstep, ... : bit-identical statistics
+    int p = p_begin + psub;
+    for (; p + 3 * pstep < p_end; p += 4 * pstep) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(p + u * pstep) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[0] += v[u].x; ss[0] += (double)v[u].x * v[u].x;
+            s[1] += v[u].y; ss[1] += (double)v[u].y * v[u].y;
+            s[2] += v[u].z; ss[2] += (double)v[u].z * v[u].z;
+            s[3] += v[u].w; ss[3] += (double)v[u].w * v[u].w;
+        }
+    }
+    for (; p < p_end; p += pstep) {
         const float4 v = *reinterpret_cast<const float4*>(base + (long)p * C);
         s[0] += v.x; ss[0] += (double)v.x * v.x;
         s[1] += v.y; ss[1] += (double)v.y * v.y;
@@ -352,43 +367,104 @@ void launch_groupnorm_stats(const float* x, float* stats, void* ws, int n, int h
     LAUNCH_CHECK();
 }
 
+// Apply pass.  grid (blocks per image, n), 256 threads.  The channel count is a multiple of 128 in every VQGAN level (128 / 256 / 512): C / 4 float4 per pixel is a power of
+// two and divides the block's 256 threads' stride, so a thread keeps ONE channel quad for its whole loop - its four (scale, shift) pairs a = rstd gamma, b = beta - mean a are
+// formed once, and no index of the loop needs a division (round 4's flat grid-stride loop spent 64-bit divisions and four statistics / gamma / beta loads on every element:
+// 4 TB/s where the LayerNorm writers reach 6).
+// Statistics from the producing convolution's epilogue (GemmArgs::gn_part [n hw / 32][C / 4][2]: sum and sum of squares of 32 pixels x 4 channels, fp32): one workgroup per
+// (group, image) adds its hw / 32 x cpg / 4 pairs in fp64, thread-strided then a fixed-order tree - run-to-run deterministic, no pass over the activation.
+__global__ __launch_bounds__(256) void groupnorm_finalize_partials_kernel(const float* __restrict__ part, float* __restrict__ stats, int hw, int C, float eps) {
+    __shared__ double sh[256][2];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / GN_GROUPS, qpg = cpg >> 2, quads = C >> 2, rows = hw >> 5;
+    const float2* p = reinterpret_cast<const float2*>(part) + ((long)n * rows) * quads + (long)g * qpg;
+    double a = 0, b = 0;
+    for (int e = tid; e < rows * qpg; e += 256) {
+        const float2 v = p[(long)(e / qpg) * quads + (e % qpg)];
+        a += v.x; b += v.y;
+    }
+    sh[tid][0] = a; sh[tid][1] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { sh[tid][0] += sh[tid + o][0]; sh[tid][1] += sh[tid + o][1]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double count = (double)hw * cpg, mean = sh[0][0] / count;
+        double var = sh[0][1] / count - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * ((long)n * GN_GROUPS + g)] = (float)mean;
+        stats[2 * ((long)n * GN_GROUPS + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+bool groupnorm_partials_supported(int hw, int C) { return hw % 256 == 0 && C % 128 == 0; }
+size_t groupnorm_part_floats(int n, int hw, int C) { return (size_t)n * (hw / 32) * (C / 4) * 2; }
+void launch_groupnorm_stats_from_partials(const float* part, float* stats, int n, int hw, int C, float eps, hipStream_t s) {
+    BG_REQUIRE(groupnorm_partials_supported(hw, C), "groupnorm from partials: unsupported shape hw=%d C=%d", hw, C);
+    hipLaunchKernelGGL(groupnorm_finalize_partials_kernel, dim3(GN_GROUPS, n), dim3(256), 0, s, part, stats, hw, C, eps);
+    LAUNCH_CHECK();
+}
+
 template <bool PLANES>   // PLANES: y is the interleaved (hi, lo) f16 plane image [pixel][C/32][2][32] read by the LDS-DMA split-precision convolution
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ y, long total4, int hw, int C, int do_swish) {
-    const int cpg = C / GN_GROUPS;
-    const int q4 = C >> 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-        const int cq = (int)(i % q4);
-        const long pix = i / q4;
-        const int n = (int)(pix / hw);
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        const float in[4] = {v.x, v.y, v.z, v.w};
-        float out[4];
+                                                              const float* __restrict__ beta, float* __restrict__ y, int hw, int C, int do_swish) {
+    const int n = blockIdx.y;
+    const int cpg = C / GN_GROUPS, q4 = C >> 2;
+    const long per_img4 = (long)hw * q4;                           // float4 per image
+    const int stride = (int)(gridDim.x * blockDim.x);             // a multiple of q4 (launcher)
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cq = i0 & (q4 - 1);                                  // this thread's channel quad, for every iteration
+    float sc[4], sh[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = cq * 4 + k;
+    for (int k = 0; k < 4; ++k) {
+        const int c = cq * 4 + k;
+        if (stats) {
             const float* st = stats + ((long)n * GN_GROUPS + c / cpg) * 2;
-            float o = (in[k] - st[0]) * st[1] * gamma[c] + beta[c];
-            if (do_swish) o = o / (1.f + expf(-o));
-            out[k] = o;
+            sc[k] = st[1] * gamma[c];
+            sh[k] = beta[c] - st[0] * sc[k];
+        } else {   // no normalisation: the pass only re-lays the tensor out (launch_to_planes)
+            sc[k] = 1.f; sh[k] = 0.f;
         }
-        if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + pix * 2 * C, cq * 4, make_float4(out[0], out[1], out[2], out[3]));
-        else reinterpret_cast<float4*>(y)[i] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+    const float4* xin = reinterpret_cast<const float4*>(x) + (long)n * per_img4;
+    const int lg = 31 - __builtin_clz(q4);
+    for (long i = i0; i < per_img4; i += stride) {
+        const float4 v = xin[i];
+        float out[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
+        if (do_swish) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = out[k] / (1.f + expf(-out[k]));
+        }
+        if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + ((long)n * hw + (i >> lg)) * 2 * C, cq * 4, make_float4(out[0], out[1], out[2], out[3]));
+        else reinterpret_cast<float4*>(y)[(long)n * per_img4 + i] = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
+static dim3 groupnorm_apply_grid(int n, int hw, int C) {
+    const int q4 = C >> 2;
+    BG_REQUIRE(C % 4 == 0 && (q4 & (q4 - 1)) == 0 && (q4 <= 256 ? 256 % q4 == 0 : q4 % 256 == 0), "groupnorm apply: C / 4 = %d must be a power of two", q4);
+    const long per_img4 = (long)hw * q4;
+    long bx = std::max<long>(1, std::min<long>((per_img4 + 255) / 256, std::max<long>(1, 4096 / std::max(n, 1))));
+    if (q4 > 256) bx = std::max<long>(q4 / 256, bx / (q4 / 256) * (q4 / 256));   // stride = 256 bx must stay a multiple of q4
+    return dim3((unsigned)bx, (unsigned)n);
+}
+
 void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s) {
-    const long total4 = (long)n * hw * C / 4;
-    const int blocks = (int)std::min<long>((total4 + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(groupnorm_apply_kernel<false>, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, total4, hw, C, do_swish);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<false>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, stats, gamma, beta, y, hw, C, do_swish);
+    LAUNCH_CHECK();
+}
+
+// fp32 NHWC activation -> the (hi, lo) plane image the LDS-DMA convolution reads, values unchanged (x 1 + 0 is exact)
+void launch_to_planes(const float* x, void* planes, int n, int hw, int C, hipStream_t s) {
+    BG_REQUIRE(C % 32 == 0, "to_planes: C=%d must be a multiple of 32", C);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<true>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       reinterpret_cast<float*>(planes), hw, C, 0);
     LAUNCH_CHECK();
 }
 
 void launch_groupnorm_apply_planes(const float* x, const float* stats, const float* gamma, const float* beta, void* planes, int n, int hw, int C, int do_swish, hipStream_t s) {
     BG_REQUIRE(C % 32 == 0, "groupnorm_apply_planes: C=%d must be a multiple of 32", C);
-    const long total4 = (long)n * hw * C / 4;
-    const int blocks = (int)std::min<long>((total4 + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(groupnorm_apply_kernel<true>, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, reinterpret_cast<float*>(planes), total4, hw, C, do_swish);
+    hipLaunchKernelGGL(groupnorm_apply_kernel<true>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, stats, gamma, beta, reinterpret_cast<float*>(planes), hw, C, do_swish);
     LAUNCH_CHECK();
 }
 

@@ -54,9 +54,15 @@ AttnBlockW load_attn(Ctx& c, const std::string& p) {
 
 struct Act { float* p; int n, h, w, c; long elems() const { return (long)n * h * w * c; } };
 
+// GroupNorm statistics of a tensor as partial sums out of the epilogue of the convolution that produced it (GemmArgs::gn_part): `of` names the tensor they describe.
+// Every writer of an activation buffer goes through note_write() so that a stale association can never be used.
+struct GnPart { float* buf = nullptr; const float* of = nullptr; };
+static void note_write(GnPart* gp, const float* y) { if (gp && gp->of == y) gp->of = nullptr; }
+
 // planes: x.p holds the interleaved (hi, lo) f16 plane image of the activation (written by gn(..., planes = true)) instead of fp32
-void conv3(const Act& x, const ConvW& w, float* y, const float* residual, int up, hipStream_t s, bool planes = false) {
+void conv3(const Act& x, const ConvW& w, float* y, const float* residual, int up, hipStream_t s, bool planes = false, GnPart* gp = nullptr) {
     GemmArgs g;
+    note_write(gp, y);
     const int oh = up ? x.h * 2 : x.h, ow = up ? x.w * 2 : x.w;
     g.mode = MODE_CONV3;
     if (planes) { g.A_hi = reinterpret_cast<const uint16_t*>(x.p); g.A_lo = g.A_hi + 32; }
@@ -65,10 +71,14 @@ void conv3(const Act& x, const ConvW& w, float* y, const float* residual, int up
     g.M = x.n * oh * ow; g.N = w.cout; g.K = 9 * w.cin;
     g.lda = w.cin; g.ldb = 9 * w.cin; g.ldc = w.cout; g.ldr = w.cout;
     g.conv_h = oh; g.conv_w = ow; g.conv_cin = w.cin; g.conv_up = up;
+    // the LDS-DMA kernel (plane input) also leaves the GroupNorm partial sums of its output where the shape allows: the consumer's statistics pass disappears
+    static const int gn_epi = getenv("BEVGEN_GN_EPILOGUE") ? atoi(getenv("BEVGEN_GN_EPILOGUE")) : 1;   // (0: always the statistics pass, for A/B runs)
+    if (gn_epi && gp && gp->buf && planes && groupnorm_partials_supported(oh * ow, w.cout)) { g.gn_part = gp->buf; gp->of = y; }
     launch_gemm(g, s);
 }
 
-void conv1(const float* x, long rows, const ConvW& w, float* y, const float* residual, hipStream_t s) {
+void conv1(const float* x, long rows, const ConvW& w, float* y, const float* residual, hipStream_t s, GnPart* gp = nullptr) {
+    note_write(gp, y);
     GemmArgs g;
     g.A = x; g.B = w.w; g.C = y; g.R = residual; g.bias_n = w.b;
     g.M = (int)rows; g.N = w.cout; g.K = w.cin;
@@ -81,10 +91,18 @@ struct DecWs {
     float* stats;       // [n*32*2]
     void* gn_ws;
     float *q, *k, *vT, *S;
+    GnPart part;        // epilogue partials of the most recent convolution output (buf: groupnorm_part_floats of the widest level, or null)
 };
 
+// statistics of x: from the producing convolution's epilogue partials when they describe exactly this tensor, else the pass over the tensor
+void gn_stats(const Act& x, DecWs& ws, hipStream_t s) {
+    if (ws.part.of == x.p && ws.part.buf) launch_groupnorm_stats_from_partials(ws.part.buf, ws.stats, x.n, x.h * x.w, x.c, 1e-6f, s);
+    else launch_groupnorm_stats(x.p, ws.stats, ws.gn_ws, x.n, x.h * x.w, x.c, 1e-6f, s);
+}
+
 void gn(const Act& x, const float* w, const float* b, float* y, int swish, DecWs& ws, hipStream_t s, bool planes = false) {
-    launch_groupnorm_stats(x.p, ws.stats, ws.gn_ws, x.n, x.h * x.w, x.c, 1e-6f, s);
+    gn_stats(x, ws, s);
+    note_write(&ws.part, y);
     if (planes) launch_groupnorm_apply_planes(x.p, ws.stats, w, b, y, x.n, x.h * x.w, x.c, swish, s);
     else launch_groupnorm_apply(x.p, ws.stats, w, b, y, x.n, x.h * x.w, x.c, swish, s);
 }
@@ -94,16 +112,16 @@ void resblock(const ResBlockW& r, Act& x, float* y, float* scratch, DecWs& ws, h
     // h = conv1(swish(norm1(x)));  split-precision mode: the normalised activation is written directly as the (hi, lo) planes the convolution reads
     gn(x, r.n1w, r.n1b, ws.t, 1, ws, s, planes);
     Act t{ws.t, x.n, x.h, x.w, r.cin};
-    conv3(t, r.c1, scratch, nullptr, 0, s, planes);
+    conv3(t, r.c1, scratch, nullptr, 0, s, planes, &ws.part);
     Act h1{scratch, x.n, x.h, x.w, r.cout};
     gn(h1, r.n2w, r.n2b, ws.t, 1, ws, s, planes);
     Act t2{ws.t, x.n, x.h, x.w, r.cout};
     const float* shortcut = x.p;
     if (r.has_nin) {  // x = nin_shortcut(x)  (1x1), written over h1 (no longer needed after norm2)
-        conv1(x.p, (long)x.n * x.h * x.w, r.nin, scratch, nullptr, s);
+        conv1(x.p, (long)x.n * x.h * x.w, r.nin, scratch, nullptr, s, &ws.part);
         shortcut = scratch;
     }
-    conv3(t2, r.c2, y, shortcut, 0, s, planes);  // y = x + conv2(...)
+    conv3(t2, r.c2, y, shortcut, 0, s, planes, &ws.part);  // y = x + conv2(...); its epilogue also leaves the statistics the next block's norm1 needs
     x = Act{y, x.n, x.h, x.w, r.cout};
 }
 
@@ -137,7 +155,7 @@ void attnblock(const AttnBlockW& a, Act& x, float* y, DecWs& ws, hipStream_t s) 
         g.batch = n; g.strideA = (long)hw * hwp; g.strideB = (long)C * hwp; g.strideC = (long)hw * C;
         launch_gemm(g, s);
     }
-    conv1(ws.q, rows, a.proj, y, x.p, s);  // x + proj_out(h)
+    conv1(ws.q, rows, a.proj, y, x.p, s, &ws.part);  // x + proj_out(h)
     x = Act{y, n, x.h, x.w, C};
 }
 
@@ -221,14 +239,15 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
     const int attn_c = max_c;
     const int chunk = std::min(n_total, chunk_max);
     const size_t act_b = (size_t)per_img * chunk * sizeof(float);
-    const size_t need = 4 * act_b + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, RH * RW) +
+    const size_t need = 4 * act_b + act_b / 64 + (size_t)chunk * 64 * sizeof(float) + groupnorm_ws_bytes(chunk, RH * RW) +
                         (size_t)chunk * attn_hwp * (3 * attn_c + attn_hwp) * sizeof(float) + (size_t)chunk * lat_hw * g.vq_embed_dim * sizeof(float) +
-                        (size_t)chunk * RH * RW * 4 * sizeof(float) + 32 * 256;
+                        (size_t)chunk * RH * RW * 4 * sizeof(float) + 34 * 256;
     c.arena.reserve(need);
     for (int i0 = 0; i0 < n_total; i0 += chunk) {
         const int n = std::min(chunk, n_total - i0);
         c.arena.reset();
         DecWs ws;
+        if (planes) ws.part.buf = c.arena.get<float>((size_t)per_img * n / 64 + 64);   // GroupNorm partials of one tensor: (pixels / 32) x (channels / 4) x 2
         ws.a = c.arena.get<float>((size_t)per_img * n);
         ws.b = c.arena.get<float>((size_t)per_img * n);
         ws.t = c.arena.get<float>((size_t)per_img * n);
@@ -246,7 +265,7 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
         else launch_nchw_to_nhwc(latents_nchw + (long)i0 * g.vq_embed_dim * lat_hw, zq, n, (int)lat_hw, g.vq_embed_dim, s);
         conv1(zq, lrows, c.post_quant, ws.t, nullptr, s);                       // post_quant_conv
         Act x{ws.t, n, lat_h, lat_w, g.vq_z_channels};
-        conv3(x, c.conv_in, ws.a, nullptr, 0, s);                               // conv_in
+        conv3(x, c.conv_in, ws.a, nullptr, 0, s, false, &ws.part);               // conv_in
         x = Act{ws.a, n, lat_h, lat_w, c.conv_in.cout};
         // three rotating activation buffers (input / scratch / output of a block) + ws.t for the normalised tensor
         float* o = c.arena.get<float>((size_t)per_img * n);
@@ -276,14 +295,26 @@ void vq_decode(Ctx& c, const int64_t* ids, const float* latents_nchw, int n_tota
                 float* bufs[3] = {ws.a, ws.b, o};
                 float* y = nullptr;
                 for (float* b : bufs) if (b != x.p) { y = b; break; }
-                conv3(x, u.up, y, nullptr, 1, s);
+                // The upsample convolution reads the block output directly (no GroupNorm in front of it, s1model:49-53): in split-precision mode the tensor is first
+                // re-laid out as (hi, lo) planes (one elementwise pass over the SMALL pre-upsample tensor) so that the 4x larger convolution runs on the LDS-DMA kernel
+                // instead of the register-staged one ($BEVGEN_VQ_UP_PLANES=0: as in rounds 2-4)
+                static const int up_planes = getenv("BEVGEN_VQ_UP_PLANES") ? atoi(getenv("BEVGEN_VQ_UP_PLANES")) : 1;
+                const int q4 = x.c >> 2;
+                if (planes && up_planes && (q4 & (q4 - 1)) == 0 && x.c % 32 == 0) {
+                    note_write(&ws.part, ws.t);
+                    launch_to_planes(x.p, ws.t, x.n, x.h * x.w, x.c, s);
+                    Act xp{ws.t, x.n, x.h, x.w, x.c};
+                    conv3(xp, u.up, y, nullptr, 1, s, true, &ws.part);
+                } else {
+                    conv3(x, u.up, y, nullptr, 1, s, false, &ws.part);
+                }
                 x = Act{y, x.n, x.h * 2, x.w * 2, u.up.cout};
             }
         }
         const long o_off = (long)i0 * g.vq_out_ch * RH * RW;
         static const bool tail_off = getenv("BEVGEN_VQ_TAIL") && atoi(getenv("BEVGEN_VQ_TAIL")) == 0;   // (A/B switch: 0 = the three-kernel tail)
         if (!tail_off && vq_out_conv_supported(x.c, g.vq_out_ch)) {   // norm_out + swish + conv_out + denormalise + layout in one kernel
-            launch_groupnorm_stats(x.p, ws.stats, ws.gn_ws, x.n, x.h * x.w, x.c, 1e-6f, s);
+            gn_stats(x, ws, s);
             launch_vq_out_conv(x.p, ws.stats, c.norm_out_w, c.norm_out_b, c.conv_out.w, c.conv_out.b, denorm ? c.denorm_mean : nullptr, denorm ? c.denorm_std : nullptr, denorm ? 1 : 0,
                                out_mode == 2 ? nullptr : reinterpret_cast<float*>(out) + o_off, out_mode == 2 ? reinterpret_cast<uint8_t*>(out) + o_off : nullptr, x.n, x.h, x.w, x.c,
                                g.vq_out_ch, s);
