@@ -68,8 +68,12 @@ bool split_supported(const Ctx& c, int B) {
 // split / fused: B = 1 0.99 / 1.28, B = 2 1.04 / 1.24, B = 3 1.14 / 1.22, B = 4 1.17 / 1.21, B = 6 1.27 / 1.21, B = 8 1.34 / 1.24, B = 16 1.47 / 1.42.  With 16-64
 // workgroups per layer the fused kernel's per-head GEMV cannot pull the 12.6 MB of q/k/v weights fast enough and a workgroup's 1.2 MB K/V range streams at one CU's
 // rate; the projection kernel spreads the weights over 192 workgroups and the attention-only kernel cuts each key walk into up to four ranges.
+// Round 5, with both MLP projections in one launch (ar_mlp_fused_kernel, fused path only), same box, full decodes, ms per step fused / split (profiles/r05_auto_threshold.txt):
+// fp16 cache + fp16 weights B = 1 0.710 / 0.829, 2 0.715 / 0.855, 4 0.727 / 0.940, 8 0.737 / 1.014 - the fused layer wins at EVERY batch size; fp32 storage
+// B = 1 1.116 / 0.919, 2 1.091 / 0.945, 3 1.094 / 1.044, 4 1.094 / 1.072, 6 1.095 / 1.186: the split layer up to four sequences, as before.
 int effective_decode_path(const Ctx& c, int B, int G) {
     if (c.cfg.decode_path != BEVGEN_DECODE_AUTO) return c.cfg.decode_path;
+    if (c.cfg.decode_weight_dtype == BEVGEN_W_F16 && G <= 1 && c.mlpf_sync && mlp_fused_supported(B, c.D, true)) return BEVGEN_DECODE_FUSED;
     return (B / std::max(G, 1) <= 4 && split_supported(c, B)) ? BEVGEN_DECODE_SPLIT : BEVGEN_DECODE_FUSED;
 }
 

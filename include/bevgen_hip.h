@@ -78,7 +78,8 @@ typedef struct bevgen_cfg {
                                                           reads the weight once, then the decode-attention kernel proper = the K/V stream and nothing else) or
                                                           BEVGEN_DECODE_AUTO (what the Python host asks for: SPLIT, with the key walk of every (sequence, head) cut into up to
                                                           four ranges, for up to four sequences / layout groups per call - the interactive single-scene caller, where 16-64
-                                                          workgroups per layer cannot pull weights and K/V fast enough: 0.99 vs 1.28 ms/step at B = 1 - else FUSED) */
+                                                          workgroups per layer cannot pull weights and K/V fast enough: 0.92 vs 1.12 ms/step at B = 1 - else FUSED; with
+                                                          decode_weight_dtype = BEVGEN_W_F16 FUSED at every batch size: its single MLP launch makes it the faster form, 0.71 vs 0.83) */
     int32_t decode_weight_dtype;                       /* Route A projection weights (q/k/v, MLP, head): BEVGEN_W_F32 (default) or BEVGEN_W_F16: bevgen_finalize rounds them to
                                                           fp16-representable values (prefill and decode then use the same model: the reference's Route A runs fp16,
                                                           sparse_self_attention.py:127) and the decode step streams the 2-byte copies: half the weight traffic */
