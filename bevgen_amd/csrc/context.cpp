@@ -315,6 +315,7 @@ static void finalize_ar(Ctx& c) {
     if (fused_like) {   // state of the fused MLP launch (both projections of a layer in one launch, XCD-local exchange)
         c.mlpf_sync = reinterpret_cast<unsigned*>(c.own(mlp_fused_sync_words() * sizeof(unsigned)));
         HIP_CHECK(hipMemset(c.mlpf_sync, 0, mlp_fused_sync_words() * sizeof(unsigned)));
+        (void)mlp_fused_supported(1, D, wf16);   // (runs the device's one-time placement probe here, never inside a stream capture)
 
         if (!c.mlpf_err_host) {
             HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.mlpf_err_host), 64, hipHostMallocMapped));

@@ -1233,13 +1233,17 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     MF_TRACE(0);
     unsigned* cnt = g.sync + 64 * xcd;   // monotonic arrival counter of this XCD's workgroups (never reset: per_xcd arrivals per launch, compared modulo 2^32)
     // ---- requests, in the order the results are needed: rows, gamma, row constants, up weights, down weights
-    const int mr = min(r, g.M - 1);
+    const int n_mc = (g.M + 15) >> 4;   // row chunks of 16 (M <= 64): the weight slices stay in registers across them
     float4 v[8];
+    auto load_rows = [&](int mc) {
+        const int mr = min(16 * mc + r, g.M - 1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = min(q + 4 * wave + 32 * j, nch - 1);   // clamped, never predicated (see rowsrc_at)
-        v[j] = *reinterpret_cast<const float4*>(g.A + (long)mr * g.lda + 4 * c);
-    }
+        for (int j = 0; j < 8; ++j) {
+            const int c = min(q + 4 * wave + 32 * j, nch - 1);   // clamped, never predicated (see rowsrc_at)
+            v[j] = *reinterpret_cast<const float4*>(g.A + (long)mr * g.lda + 4 * c);
+        }
+    };
+    load_rows(0);
     float4 gb_raw = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 256) gb_raw = *reinterpret_cast<const float4*>(g.ln_w + 4 * min(tid, nch - 1));
     float e_cs = 0.f, e_ds = 0.f;
@@ -1273,6 +1277,8 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
             }
     }
     // ---- phase 1: ln2 folded into the up-projection (the FD form of skinny_fused_kernel: raw rows to LDS, gamma at the operand read, statistics in the shadow of the weights)
+    for (int mc = 0; mc < n_mc; ++mc) {
+    if (mc > 0) load_rows(mc);
     {
         float s = 0.f;
 #pragma unroll
@@ -1281,7 +1287,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
         s += xor16(s);
         s += xor32(s);
         if (q == 0) stat[0][wave][r] = s;
-        if (tid < 256) gm_s[tid] = gb_raw;
+        if (tid < 256 && mc == 0) gm_s[tid] = gb_raw;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1356,7 +1362,9 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
         for (int w = 0; w < SF_WAVES; ++w) { t1 += stat[0][w][rw]; t2s += stat[1][w][rw]; }
         const float mean = t1 / (float)D, rstd = rsqrtf(t2s / (float)D + g.eps);
         o = gelu_erf(rstd * (o - mean * e_cs) + e_ds);
-        if (rw < g.M) g.hidden[(long)rw * K2 + n0 + (ln & 15)] = o;
+        if (16 * mc + rw < g.M) g.hidden[(long)(16 * mc + rw) * K2 + n0 + (ln & 15)] = o;
+    }
+    if (mc + 1 < n_mc) __syncthreads();   // As / red / stat are rewritten by the next row chunk
     }
     // ---- the exchange: this XCD's per_xcd workgroups have all stored their 16 hidden columns
     unsigned my_xcc;
@@ -1387,11 +1395,15 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     if (!flag_s) { if (tid == 0) atomicOr(g.err, 1u); }
     // ---- phase 2: down-projection of this XCD's hidden slice, 2 x 16 output columns per workgroup, into partial plane `xcd`
     const int nch2 = slice >> 2;   // 128 chunks of 4
+    for (int mc = 0; mc < n_mc; ++mc) {
+    {
+        const int mr = min(16 * mc + r, g.M - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = q + 4 * wave + 32 * j;
-        const float4 hv = *reinterpret_cast<const float4*>(g.hidden + (long)mr * K2 + xcd * slice + 4 * min(c, nch2 - 1));
-        if (c < nch2) As[c * 16 + r] = hv;
+        for (int j = 0; j < 4; ++j) {
+            const int c = q + 4 * wave + 32 * j;
+            const float4 hv = *reinterpret_cast<const float4*>(g.hidden + (long)mr * K2 + xcd * slice + 4 * min(c, nch2 - 1));
+            if (c < nch2) As[c * 16 + r] = hv;
+        }
     }
     __syncthreads();
     f32x4 acc2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -1438,20 +1450,50 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
         float o = 0.f;
 #pragma unroll
         for (int w = 0; w < SF_WAVES; ++w) o += red[t][w][j][ln];
-        const int mo = 4 * (ln >> 4) + j, col = (t2 + t) * 16 + (ln & 15);
+        const int mo = 16 * mc + 4 * (ln >> 4) + j, col = (t2 + t) * 16 + (ln & 15);
         if (mo < g.M) g.C[((long)xcd * g.M + mo) * D + col] = o;
+    }
+    if (mc + 1 < n_mc) __syncthreads();   // As / red are rewritten by the next row chunk
     }
     MF_TRACE(5);
 #undef MF_TRACE
 }
 
+// Placement check, once per device (bevgen_finalize): the exchange inside ar_mlp_fused_kernel is only coherent if the workgroups i, i + 8, i + 16, ... of a launch share an
+// XCD (one L2).  A 256-workgroup launch records HW_REG_XCC_ID per workgroup; any residue class that is split over two XCDs switches the fused launch off for this
+// device (the kernel repeats the check on every launch and raises the context's error word, but a wrong placement should never get that far).
+__global__ void xcc_probe_kernel(unsigned* out) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = x & 0xf;
+}
+static bool xcd_placement_ok() {
+    static std::atomic<int> state[MAX_DEVICES];   // 0 unknown, 1 ok, 2 not ok
+    const int dev = current_device_slot();
+    int st = state[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        unsigned* d = nullptr;
+        unsigned h[256];
+        bool ok = hipMalloc(reinterpret_cast<void**>(&d), sizeof h) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(xcc_probe_kernel, dim3(256), dim3(512), 0, 0, d);
+            ok = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+            (void)hipFree(d);
+        }
+        for (int i = 8; ok && i < 256; ++i) ok = h[i] == h[i & 7];
+        st = ok ? 1 : 2;
+        state[dev].store(st, std::memory_order_release);
+    }
+    return st == 1;
+}
+
 bool mlp_fused_supported(int M, int D, bool w_f16) {
     static const int env = getenv("BEVGEN_MLP_FUSE") ? atoi(getenv("BEVGEN_MLP_FUSE")) : 1;
-    if (!env || M < 1 || M > 16 || D != 1024) return false;   // (the K slices per wave - 128 of D, 64 of the XCD's D / 2 - are written out for D = 1024)
+    if (!env || M < 1 || M > 64 || D != 1024) return false;   // (the K slices per wave - 128 of D, 64 of the XCD's D / 2 - are written out for D = 1024)
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
     (void)w_f16;
-    return cus >= 4 * D / 16;   // one workgroup per CU: every workgroup of an XCD must be resident at once
+    return cus >= 4 * D / 16 && xcd_placement_ok();   // one workgroup per CU: every workgroup of an XCD must be resident at once; workgroup i on XCD i % 8
 }
 
 void launch_ar_mlp_fused(const MlpFusedArgs& g, hipStream_t s) {

@@ -289,7 +289,7 @@ struct SkinnyFusedArgs {
 // one per CU); workgroup i runs on XCD i % 8 and the 4 D / 128 workgroups of an XCD produce a contiguous D / 2 slice of the hidden row, which is exactly one K slice of the
 // down-projection: after an XCD-LOCAL exchange (plain stores, one L2 counter, no agent-scope fence: producers and consumers share the XCD's L2) every workgroup multiplies
 // that slice by its 32 output columns of the down matrix, whose weights it requested at kernel start.  Output: 8 partial planes [8][M][D] (one per XCD), summed in order by
-// the consumer's row source.  M <= 16, D = 1024, a device with at least 4 D / 16 CUs; the launch must have the GPU to itself (every workgroup of an XCD waits for
+// the consumer's row source.  M <= 64 (row chunks of 16), D = 1024, a device with at least 4 D / 16 CUs; the launch must have the GPU to itself (every workgroup of an XCD waits for
 // its 31 peers: see the co-residency note in decode_fused.hip).
 struct MlpFusedArgs {
     const float* A = nullptr; int lda = 0;            // [M, D] rows entering ln2

@@ -237,7 +237,7 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_w, const fl
 int bevgen_op_ln_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w, const float* d_bias, float* d_c,
                       int M, int N, int K, int act_gelu, int ksplit, int* ksplit_out, void* stream);
 /* Both MLP projections of a Route-A decode layer in one launch (decode_fused.hip ar_mlp_fused_kernel; Block.forward's mlp(ln2(x)), transformer/mingpt_sparse.py:232-253):
- * d_out [M, D] = Linear2(GELU(Linear1(LayerNorm(d_x)))) WITHOUT the residual, M <= 16, D = 1024; w_f16: the matrices are rounded to fp16 first (decode_weights = f16).
+ * d_out [M, D] = Linear2(GELU(Linear1(LayerNorm(d_x)))) WITHOUT the residual, M <= 64, D = 1024; w_f16: the matrices are rounded to fp16 first (decode_weights = f16).
  * Returns BEVGEN_ERR_INVALID where the launch is not supported (shape, or a device with fewer CUs than its 4 D / 16 workgroups). */
 int bevgen_op_mlp_fused(bevgen_ctx* ctx, const float* d_x, const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w1 /*[4D, D]*/, const float* d_b1,
                         const float* d_w2 /*[D, 4D]*/, const float* d_b2, int w_f16, float* d_out, int M, int D, void* stream);

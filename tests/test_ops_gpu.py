@@ -485,10 +485,11 @@ def test_ln_gemm_operator(gpu_ctx, M, N, K, ln, gelu):
         assert rel(out.cpu().double(), ref) < 6e-6
 
 
-@pytest.mark.parametrize("M,D,w_f16", [(16, 1024, False), (16, 1024, True), (5, 1024, True), (1, 1024, False), (9, 1024, False)])
+@pytest.mark.parametrize("M,D,w_f16", [(16, 1024, False), (16, 1024, True), (5, 1024, True), (1, 1024, False), (9, 1024, False), (64, 1024, True), (33, 1024, False)])
 def test_mlp_fused_operator(gpu_ctx, M, D, w_f16):
     """ar_mlp_fused_kernel through bevgen_op_mlp_fused: Linear2(GELU(Linear1(LayerNorm(x)))) of Block.forward (transformer/mingpt_sparse.py:232-253) in ONE launch - the
-    up-projection's 16-column tiles exchanged inside each XCD, the down-projection as 8 partial planes summed by the consumer's row source - against fp64; the entry
+    up-projection's 16-column tiles exchanged inside each XCD, the down-projection as 8 partial planes summed by the consumer's row source, rows in chunks of 16 (M <= 64:
+    BASELINE config 5's 64 sequences) - against fp64; the entry
     launches it twice on one barrier state (self-cleaning, as the hipGraph replay needs it) and fails on a barrier timeout or a workgroup off its XCD."""
     g = torch.Generator().manual_seed(7 * M + D + int(w_f16))
     x = torch.randn(M, D, generator=g) * 1.3 + 0.2
@@ -505,7 +506,7 @@ def test_mlp_fused_operator(gpu_ctx, M, D, w_f16):
     out2 = gpu_ctx.op_mlp_fused(dev(x), dev(lw), dev(lb), dev(w1), dev(b1), dev(w2), dev(b2), w_f16=w_f16)
     assert torch.equal(out, out2), "two launches of the same operator differ: the partial planes must be summed in a fixed order"
     with pytest.raises(Exception, match="unsupported shape"):
-        gpu_ctx.op_mlp_fused(dev(torch.randn(17, D)), dev(lw), dev(lb), dev(w1), dev(b1), dev(w2), dev(b2))
+        gpu_ctx.op_mlp_fused(dev(torch.randn(65, D)), dev(lw), dev(lb), dev(w1), dev(b1), dev(w2), dev(b2))
     with pytest.raises(Exception, match="unsupported shape"):   # other widths run the two skinny launches in the model path
         gpu_ctx.op_mlp_fused(dev(torch.randn(4, 512)), dev(lw[:512]), dev(lb[:512]), dev(w1[:2048, :512]), dev(b1[:2048]), dev(w2[:512, :2048]), dev(b2[:512]))
 
