@@ -15,6 +15,8 @@ SHAPES = {
     "gemm_split_glds_kernel": ("M=24576 N=1024 K=1024, A and B as interleaved hi/lo f16 planes (4 B/element), fp32 C", (24576 * 1024 + 1024 * 1024 + 24576 * 1024) * 4),
     "ar_attn_fused_kernel": (f"Route A config 4, B=16 H=16 fp32 KV, mean over {STEPS} decode steps x 24 layers (mean context {MEAN_N:.0f}, visible fraction {VISIBLE:.3f}): K/V rows of present blocks once + the layer's q/k/v weight (12.6 MB, read through L2 by the 16 workgroups of a head)",
                              2 * 16 * 16 * MEAN_N * VISIBLE * 64 * 4 + 3 * 1024 * 1024 * 4),
+    "ar_mlp_fused_kernel<0>": ("ln2 (folded) + MLP up + GELU + MLP down in one launch (round 5), M=16 D=1024, fp32 weights: both matrices once + rows in, hidden out and back (XCD-local exchange), 8 partial planes out",
+                               (2 * 4096 * 1024 + 16 * 1024 + 2 * 16 * 4096 + 8 * 16 * 1024) * 4),
     "skinny_fused_kernel<true, 0, false, true>": ("ln2 (folded) + MLP up-projection M=16 N=4096 K=1024, fp32 weights", (4096 * 1024 + 16 * 1024 + 16 * 4096) * 4),
     "skinny_fused_kernel<true, 0, false, false>": ("ln_f + head M=16 N=1024 K=1024, fp32 weights", (1024 * 1024 + 16 * 1024 + 16 * 1024) * 4),
     "skinny_fused_kernel<false": ("MLP down-projection M=16 N=1024 K=4096, split over K (4 partial sums written)", (1024 * 4096 + 16 * 4096 + 4 * 16 * 1024) * 4),
