@@ -1,5 +1,6 @@
 // Shared declarations for libbevgen_hip (gfx950 / CDNA4 only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -8,6 +9,15 @@
 #include <cstdarg>
 
 namespace bevgen {
+
+// hipFuncSetAttribute (the > 64 KB dynamic-LDS opt-in) is PER DEVICE state and the launchers may be entered from several host threads with contexts on several GPUs:
+// their one-time flags are indexed by the current device and atomic (setting an attribute twice is harmless)
+constexpr int kMaxDevices = 64;
+inline int device_slot() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
 
 // -------- error handling: C++ exceptions inside, translated to int codes at the C-ABI --------
 struct Error : std::runtime_error {

@@ -216,11 +216,12 @@ void launch_gemm(const GemmArgs& g_in, hipStream_t stream) {
     if (g.mode == MODE_CONV3) BG_REQUIRE(g.conv_cin % BK == 0 && g.K == 9 * g.conv_cin, "conv3x3: Cin=%d must be a multiple of 32", g.conv_cin);
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch);
     const size_t lds = (size_t)2 * (BM + BN) * LDSS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[kMaxDevices];
+    const int dslot = device_slot();
+    if (!attr_set[dslot].load(std::memory_order_acquire)) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<MODE_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<MODE_CONV3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dslot].store(true, std::memory_order_release);
     }
     ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : PROF_GEMM, 2.0 * g.M * (double)g.N * g.K * g.batch, stream);
     if (g.mode == MODE_CONV3)

@@ -590,8 +590,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
     dim3 grid(cdiv(g.N, GBN), cdiv(rows, tbm), g.ksplit);
     const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[kMaxDevices];
+    const int dslot = device_slot();
+    if (!attr_set[dslot].load(std::memory_order_acquire)) {
 #define BG_SET(K, BYTES) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), 2 * 256 * 2 * GBK * 2);
@@ -614,7 +615,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
 #undef BG_SET
-        attr_set = true;
+        attr_set[dslot].store(true, std::memory_order_release);
     }
     ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : (wm == 4 ? PROF_GEMM : PROF_GEMM_SMALL), 2.0 * rows * (double)g.N * g.K, stream);
     const bool conv = g.mode == MODE_CONV3;
