@@ -19,6 +19,7 @@ LIMITS = {
     "decode_fused.hip": {"ar_attn_fused_kernelILi0ELi1ELi0ELb0E": 0, "ar_attn_fused_kernelILi1ELi1ELi0ELb0E": 0, "ar_attn_fused_kernelILi1ELi1ELi1ELb0E": 0,
                          "ar_attn_fused_kernelILi0ELi1ELi0ELb1E": 0, "ar_attn_fused_kernelILi1ELi1ELi0ELb1E": 0, "ar_attn_fused_kernelILi0ELi4ELi0ELb0E": 0,
                          "ar_attn_kernelILi1ELi1ELb0E": 0, "ar_attn_kernelILi0ELi1ELb0E": 0, "ar_attn_kernelILi1ELi1ELb1E": 0,
+                         "ar_mlp_fused_kernelILi0E": 0, "ar_mlp_fused_kernelILi1E": 0,
                          "skinny_fused_kernelILb1ELi0ELb0E": 0,
                          "skinny_fused_kernelILb1ELi0ELb1E": 0, "skinny_fused_kernelILb0ELi0ELb0E": 0},
     "attention_split.hip": {"attention_split_kernelILb0E": 0},
