@@ -494,11 +494,25 @@ int bevgen_op_conv3x3(bevgen_ctx* ctx, const float* x, const float* w, const flo
                       int up, void* stream) {
     return guarded(ctx, [&] {
         GemmArgs g;
+        const int flags = up;   // bit 0: nearest-2x upsample fused into the gather; bit 1: the LDS-DMA kernel on operand planes split here (tests / probes: the model hands it
+        up &= 1;                // planes its GroupNorm wrote); bit 2 (with bit 1): the general convolution variant also where the stride-1 one (MODE_CONV3S) applies
         const int oh = up ? 2 * H : H, ow = up ? 2 * W : W;
         g.mode = MODE_CONV3;
         g.A = x; g.B = w; g.C = y; g.R = residual; g.bias_n = bias;
         g.M = n * oh * ow; g.N = Cout; g.K = 9 * Cin; g.lda = Cin; g.ldb = 9 * Cin; g.ldc = Cout; g.ldr = Cout;
         g.conv_h = oh; g.conv_w = ow; g.conv_cin = Cin; g.conv_up = up;
+        if (flags & 2) {
+            BG_REQUIRE(Cin % 32 == 0, "op_conv3x3: the LDS-DMA kernel needs Cin %% 32 == 0 (Cin=%d)", Cin);
+            const size_t xb = (size_t)n * H * W * Cin * 4, wb = (size_t)Cout * 9 * Cin * 4;
+            ctx->arena.reserve(xb + wb + 4096);
+            ctx->arena.reset();
+            uint16_t* ap = reinterpret_cast<uint16_t*>(ctx->arena.alloc(xb));
+            uint16_t* bp = reinterpret_cast<uint16_t*>(ctx->arena.alloc(wb));
+            launch_split_weight(x, ap, (long)n * H * W * Cin, (hipStream_t)stream);
+            launch_split_weight(w, bp, (long)Cout * 9 * Cin, (hipStream_t)stream);
+            g.A = nullptr; g.A_hi = ap; g.A_lo = ap + 32; g.B_hi = bp; g.B_lo = bp + 32;
+            g.conv_general = (flags & 4) != 0;
+        }
         launch_gemm(g, (hipStream_t)stream);
     });
 }

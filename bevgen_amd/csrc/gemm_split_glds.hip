@@ -19,6 +19,10 @@
 //        bottom          :  ds_read F0 of tile t+1; DMA of tile t+3 -> stage of t | MFMAs on F1, DMA pieces interleaved between MFMA groups
 //   so every ds_read is issued a full 12-MFMA phase before its use and every DMA two k-tiles before its use.
 // * MODE_CONV3: implicit-GEMM 3x3 convolution over NHWC planes; taps that fall into the zero padding are fetched from a zero page.
+// * MODE_CONV3S: the same for the common case (stride 1, padding 1, no fused upsample: every 3x3 convolution of the VQGAN decoder but the four behind an upsample).  The address
+//   of a tap is then the output pixel's own address plus a WAVE-UNIFORM displacement, and whether the tap lies inside the image is one bit of a 9-bit mask the lane forms once:
+//   4 VALU per DMA piece instead of ~20 (coordinates, four bound compares, the address polynomial), no per-piece coordinate registers - the general variant sits at the
+//   register limit and spills 13 VGPRs, and the VALU in front of every DMA request delays the MFMAs queued behind it.
 #include "common.h"
 #include "kernels.h"
 #include "profiler.h"
@@ -102,8 +106,10 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     // no per-iteration address VALU and 6 VGPRs of DMA state.  Rows outside the problem are CLAMPED to the last row: they only feed
     // accumulator rows / columns that the epilogue never stores.
     // MODE_CONV3: the A address depends on the tap (and taps inside the zero padding read a zero page), so it is rebuilt per piece.
+    constexpr bool CONVG = MODE == MODE_CONV3, CONVS = MODE == MODE_CONV3S, CONV = CONVG || CONVS;
     unsigned a_off[NAJ], b_off[NBJ];
-    int a_img[NAJ], a_yx[NAJ];   // MODE_CONV3: image index and (y << 16 | x) of the output pixel; rows past M have a_img >= number of images
+    int a_img[CONVG ? NAJ : 1], a_yx[CONVG ? NAJ : 1];   // MODE_CONV3: image index and (y << 16 | x) of the output pixel; rows past M have a_img >= number of images
+    unsigned a_msk[CONVS ? NAJ : 1];                      // MODE_CONV3S: bit (3 kh + kw) = tap (kh, kw) of this lane's output pixel lies inside the image (0 for rows past M)
 #pragma unroll
     for (int j = 0; j < NBJ; ++j) {
         const int R = wave * (8 * NBJ) + j * 8 + (lane >> 3);   // B row inside the tile
@@ -116,9 +122,21 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
         const int R = wave * (8 * NAJ) + j * 8 + (lane >> 3);   // A row inside the tile
         const int c = (lane & 7) ^ ((R >> 1) & 7);
         const int m = m0l + R;
-        if (MODE == MODE_PLAIN) {
+        if constexpr (MODE == MODE_PLAIN) {
             a_off[j] = (unsigned)(((long)min(m, g.M - 1) * 2 * g.lda + c * 8) * 2);
-            a_img[j] = a_yx[j] = 0;
+        } else if constexpr (CONVS) {
+            const int hw = g.conv_h * g.conv_w;
+            const int mc = min(m, g.M - 1);
+            const int img = mc / hw, rem = mc - img * hw;
+            const int y = rem / g.conv_w, x = rem - y * g.conv_w;
+            a_off[j] = (unsigned)mc * (unsigned)(g.conv_cin * 4) + (unsigned)(c * 16);   // the pixel's own (centre tap) line, this lane's 16-byte chunk
+            unsigned rowm = (y > 0 ? 1u : 0u) | 2u | (y + 1 < g.conv_h ? 4u : 0u);       // kh = 0, 1, 2 inside
+            unsigned colm = (x > 0 ? 1u : 0u) | 2u | (x + 1 < g.conv_w ? 4u : 0u);       // kw = 0, 1, 2 inside
+            unsigned msk = 0;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                if (rowm & (1u << kh)) msk |= colm << (3 * kh);
+            a_msk[j] = m < g.M ? msk : 0u;
         } else {
             a_off[j] = (unsigned)(c * 16);   // byte position of the lane's chunk inside the 128-byte (pixel, k-block) line
             const int hw = g.conv_h * g.conv_w;
@@ -132,12 +150,21 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     const int kt_first = kz * (nk_all / ksl) + min(kz, nk_all % ksl);
     // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order)
     int k_issue = kt_first * GBK;
-    const int n_img = MODE == MODE_CONV3 ? g.M / (g.conv_h * g.conv_w) : 0;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ap), 0, MODE == MODE_CONV3 ? g.a_bytes : -1, 0x00020000);
+    const int n_img = CONVG ? g.M / (g.conv_h * g.conv_w) : 0;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Ap), 0, CONV ? g.a_bytes : -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Bp), 0, -1, 0x00020000);
+    // MODE_CONV3S: wave-uniform state of the k-tile being issued - its tap as a mask bit, and the byte displacement of (tap, channel block) from the centre line
+    int s_c0 = 0, s_tap = 0;
+    if (CONVS && kt_first > 0) { s_tap = k_issue / g.conv_cin; s_c0 = k_issue - s_tap * g.conv_cin; }
+    auto tap_delta = [&]() { const int kh = s_tap / 3, kw = s_tap - 3 * kh; return ((kh - 1) * g.conv_w + (kw - 1)) * (g.conv_cin * 4) + s_c0 * 4; };
+    int s_delta = CONVS ? tap_delta() : 0;
+    unsigned s_bit = 1u << s_tap;
     auto issue_a = [&](int stage, int j) {
         _Float16* sa = smem_g + stage * STAGE_H + (wave * (8 * NAJ) + j * 8) * 2 * GBK;
-        if (MODE == MODE_CONV3) {
+        if constexpr (CONVS) {
+            // (an offset beyond the resource's num_records returns zeros, as in the general variant)
+            glds16_buf(a_rsrc, (a_msk[j] & s_bit) ? a_off[j] + (unsigned)s_delta : 0xFFFFFF00u, 0, sa);
+        } else if constexpr (CONVG) {
             // scalar part (tap of this k-tile) + a dozen 32-bit VALU per piece; taps inside the zero padding (and rows past M) use an offset
             // beyond the resource's num_records: the buffer load returns zeros and the DMA writes them (checked on gfx950)
             const int tap = k_issue / g.conv_cin;
@@ -158,6 +185,11 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
 #pragma unroll
         for (int j = 0; j < NBJ; ++j) glds16_buf(b_rsrc, b_off[j], k_issue * 4, sb + j * 8 * 2 * GBK);
         k_issue += GBK;
+        if (CONVS) {
+            s_c0 += GBK;
+            s_delta += GBK * 4;
+            if (s_c0 == g.conv_cin) { s_c0 = 0; ++s_tap; s_bit <<= 1; s_delta = tap_delta(); }
+        }
     };
     auto issue_a_half = [&](int stage, int half) {   // the A pieces in two groups (interleaved with the MFMA groups of a phase)
 #pragma unroll
@@ -482,7 +514,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                     }
                     f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
                     *reinterpret_cast<f32x4*>(cp) = o;
-                    if (MODE == MODE_CONV3 && g.gn_part) {
+                    if (CONV && g.gn_part) {
                         // GroupNorm statistics of the output tensor: this lane's 4 consecutive channels of its row, summed over the 32 rows (lanes) of the half -
                         // one (sum, sum of squares) pair per (32 rows, 4 channels).  The launcher guarantees whole tiles (every lane here, no tail), so the DPP row sums
                         // and the cross-row exchange run with all lanes active
@@ -596,12 +628,16 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
 #define BG_SET(K, BYTES) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
@@ -609,7 +645,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
@@ -619,6 +657,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     }
     ProfScope prof(g.mode == MODE_CONV3 ? PROF_CONV3 : (wm == 4 ? PROF_GEMM : PROF_GEMM_SMALL), 2.0 * rows * (double)g.N * g.K, stream);
     const bool conv = g.mode == MODE_CONV3;
+    // stride 1, padding 1, no fused upsample: the variant with wave-uniform tap displacements (MODE_CONV3S; $BEVGEN_CONV_FAST=0 keeps the general one, for A/B runs)
+    static const int conv_fast_env = getenv("BEVGEN_CONV_FAST") ? atoi(getenv("BEVGEN_CONV_FAST")) : 1;
+    const bool convs = conv && conv_fast_env && !g.conv_general && !g.conv_up && g.conv_stride == 1 && g.conv_pad == 1 && g.conv_hin == g.conv_h && g.conv_win == g.conv_w;
 #define BG_LAUNCH(MODE_, WM_, S_, THREADS)                                                                                           \
     do {                                                                                                                             \
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_, WM_, S_, true>), grid, dim3(THREADS), lds, stream, g);    \
@@ -630,6 +671,9 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     } else if (half) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), grid, dim3(256), lds, stream, g);
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), grid, dim3(256), lds, stream, g);
+    } else if (thin && convs) {
+        if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, true, false, 1>), grid, dim3(512), lds, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, false, false, 1>), grid, dim3(512), lds, stream, g);
     } else if (thin && conv) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2, 4, true, false, 1>), grid, dim3(512), lds, stream, g);
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_CONV3, 2, 4, false, false, 1>), grid, dim3(512), lds, stream, g);
@@ -645,10 +689,12 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), grid, dim3(256), lds, stream, g);
         else hipLaunchKernelGGL((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), grid, dim3(256), lds, stream, g);
     } else if (wm == 2) {
-        if (conv) BG_LAUNCH(MODE_CONV3, 2, 2, 256);
+        if (convs) BG_LAUNCH(MODE_CONV3S, 2, 2, 256);
+        else if (conv) BG_LAUNCH(MODE_CONV3, 2, 2, 256);
         else BG_LAUNCH(MODE_PLAIN, 2, 2, 256);
     } else {
-        if (conv) BG_LAUNCH(MODE_CONV3, 4, 3, 512);
+        if (convs) BG_LAUNCH(MODE_CONV3S, 4, 3, 512);
+        else if (conv) BG_LAUNCH(MODE_CONV3, 4, 3, 512);
         else BG_LAUNCH(MODE_PLAIN, 4, 3, 512);
     }
 #undef BG_LAUNCH

@@ -6,7 +6,7 @@
 namespace bevgen {
 
 // ---------------------------------------------------------------- gemm.hip
-enum { MODE_PLAIN = 0, MODE_CONV3 = 1 };
+enum { MODE_PLAIN = 0, MODE_CONV3 = 1, MODE_CONV3S = 2 };   // (MODE_CONV3S: kernel-template value only - launch_gemm_split_glds picks it for stride-1 / pad-1 / no-upsample convolutions; callers pass MODE_CONV3)
 enum { ACT_NONE = 0, ACT_GELU = 1 };
 enum { EPI_PLAIN = 0, EPI_MUSE_Q = 1, EPI_GEGLU = 2, EPI_MUSE_KV = 3, EPI_MUSE_QKV = 4 };
 
@@ -71,6 +71,7 @@ struct GemmArgs {
     int ksplit = 1;
     float* kpart = nullptr;
     int a_bytes = 0;                  // MODE_CONV3: size of the activation plane image (buffer-resource bound), filled in by the launcher
+    bool conv_general = false;        // MODE_CONV3 on the LDS-DMA kernel: keep the general variant where the stride-1 one would be picked (operator tests)
     int tile_band = 0;                // tile-order band height (0 = row-major); filled in by the launcher
     int m_base = 0;                   // first row of this launch (the launcher cuts a problem whose last round of tiles would be nearly empty into two row ranges; M stays the END row)
     bool no_row_split = false;        // launcher-internal

@@ -438,12 +438,15 @@ class Context:
                                                      _ptr(layout), int(block), B, int(G), H, int(n), Lmax, int(prefix), int(split), _ptr(out), self._s()))
         return out
 
-    def op_conv3x3(self, x_nhwc, w_ohwi, bias, residual=None, upsample=False):
+    def op_conv3x3(self, x_nhwc, w_ohwi, bias, residual=None, upsample=False, kernel="auto"):
+        """kernel: 'auto' (fp32 input: the register-staged kernel), 'dma' (the LDS-DMA kernel on planes split inside the call), 'dma_general' (its general variant
+        also where the stride-1 variant applies)."""
         n, H, W, Cin = x_nhwc.shape
         Cout = w_ohwi.shape[0]
         oh, ow = (2 * H, 2 * W) if upsample else (H, W)
         y = torch.empty((n, oh, ow, Cout), dtype=torch.float32, device=self.device)
-        self._check(self.lib.bevgen_op_conv3x3(self._h, _ptr(x_nhwc), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(y), n, H, W, Cin, Cout, int(upsample), self._s()))
+        flags = int(upsample) | {"auto": 0, "dma": 2, "dma_general": 6}[kernel]
+        self._check(self.lib.bevgen_op_conv3x3(self._h, _ptr(x_nhwc), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(y), n, H, W, Cin, Cout, flags, self._s()))
         return y
 
     def op_groupnorm(self, x_nhwc, gamma, beta, swish=True):

@@ -268,6 +268,8 @@ int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* d_q, const void* d_
 int bevgen_op_ar_attn_fused(bevgen_ctx* ctx, const float* d_x, const float* d_partial, int ns, const float* d_rbias, const float* d_ln_w, const float* d_ln_b,
                             const float* d_wqkv, const float* d_bqkv, int w_f16, void* d_kcache, void* d_vcache, int kv_dtype, const float* d_bias, int ldbias,
                             const float* d_attn_mask, const int64_t* d_layout, int block, int B, int G, int H, int n, int Lmax, int prefix, int split, float* d_out, void* stream);
+/* upsample2x: bit 0 = nearest-2x upsample of the input fused into the gather; bit 1 = run the LDS-DMA kernel on (hi, lo) operand planes split inside the call (Cin % 32 == 0;
+ * the decoder reaches that kernel with planes its GroupNorm wrote); bit 2 (with bit 1) = its general variant also where the stride-1 variant applies. */
 int bevgen_op_conv3x3(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_w_ohwi, const float* d_bias, const float* d_residual,
                       float* d_y_nhwc, int n, int H, int W, int Cin, int Cout, int upsample2x, void* stream);
 int bevgen_op_groupnorm(bevgen_ctx* ctx, const float* d_x_nhwc, const float* d_gamma, const float* d_beta, float* d_y, int n, int hw, int C,

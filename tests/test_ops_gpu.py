@@ -230,6 +230,28 @@ def test_conv3x3(gpu_ctx, n, H, W, Cin, Cout, up):
     assert rel(out.cpu().permute(0, 3, 1, 2).double(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("n,H,W,Cin,Cout", [(3, 5, 7, 32, 3),          # fewer rows than one tile, ragged everything, three output channels
+                                            (2, 16, 16, 64, 128),      # whole 128-row tiles, alone on their CUs (the eight-wave block)
+                                            (1, 14, 25, 128, 96),      # the non-square latent grid of the 224 x 400 cameras
+                                            (1, 200, 200, 32, 64),     # 313 blocks of 128 rows (two per CU)
+                                            (2, 128, 128, 32, 256)])   # 256 blocks of 256 rows: the throughput shape
+def test_conv3x3_lds_dma_kernel(gpu_ctx, n, H, W, Cin, Cout):
+    """The LDS-DMA convolution at operator level (the decoder reaches it with planes its GroupNorm wrote): against fp64, and the stride-1 variant (wave-uniform tap
+    displacements + a per-lane tap mask, MODE_CONV3S) bit-identical to the general one on every block shape the launcher picks."""
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = torch.randn(n, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    res = torch.randn_like(ref, dtype=torch.float32)
+    ref = ref + res.double()
+    args = (dev(x.permute(0, 2, 3, 1)), dev(w.permute(0, 2, 3, 1)), dev(b))
+    fast = gpu_ctx.op_conv3x3(*args, residual=dev(res.permute(0, 2, 3, 1)), kernel="dma")
+    general = gpu_ctx.op_conv3x3(*args, residual=dev(res.permute(0, 2, 3, 1)), kernel="dma_general")
+    assert rel(fast.cpu().permute(0, 3, 1, 2).double(), ref) < 2e-6
+    assert torch.equal(fast, general)
+
+
 @pytest.mark.parametrize("n,hw,C,swish", [(2, 64, 32, True), (1, 4096, 128, True), (3, 256, 512, False), (2, 100, 64, True)])
 def test_groupnorm(gpu_ctx, n, hw, C, swish):
     g = torch.Generator().manual_seed(C)

@@ -24,5 +24,8 @@ for _ in range(reps):
     out = ctx.vq_decode(ids, uint8=True)
     torch.cuda.synchronize()
     ts.append(time.time() - t0)
-print(f"n={n} precision={precision}: {min(ts) * 1e3 / (n / 6):.3f} ms per six-view scene (best of {reps}; mean {sum(ts) / len(ts) * 1e3 / (n / 6):.3f}), checksum {int(out.long().sum())}")
+import hashlib
+pix = ctx.vq_decode(ids[:12], uint8=False)   # fp32 pixels of two scenes: a bit-level fingerprint for A/B runs over kernel variants that must not change results
+sha = hashlib.sha256(pix.cpu().numpy().tobytes()).hexdigest()[:16]
+print(f"n={n} precision={precision}: {min(ts) * 1e3 / (n / 6):.3f} ms per six-view scene (best of {reps}; mean {sum(ts) / len(ts) * 1e3 / (n / 6):.3f}), checksum {int(out.long().sum())}, fp32 pixels sha256 {sha}")
 ctx.close()
