@@ -426,19 +426,6 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
             mf.sync = c.mlpf_sync; mf.err = c.mlpf_err_dev;
             mf.M = Bc; mf.D = D;
             mf.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
-            // K/V prefetch for the next attention launch (the next layer's; behind the last layer, layer 0 of the next step): the leading rows of every (sequence, head)
-            // into the L2 of the XCD its attention workgroup runs on.  One sequence per attention workgroup, heads a multiple of 8 (workgroup -> XCD = head % 8), at most
-            // one pair per MLP workgroup.  $BEVGEN_KV_PREFETCH_KB = KiB per pair (K and V together; 0 = off)
-            static const int pf_kb = getenv("BEVGEN_KV_PREFETCH_KB") ? atoi(getenv("BEVGEN_KV_PREFETCH_KB")) : 64;
-            if (pf_kb > 0 && st.G == 1 && H % 8 == 0 && (H / 8) * Bc <= D / 32) {
-                const int nl = (i + 1) % g.num_layers;
-                mf.pf_k = reinterpret_cast<const char*>(st.kcache) + nl * layer_bytes + chain_off;
-                mf.pf_v = reinterpret_cast<const char*>(st.vcache) + nl * layer_bytes + chain_off;
-                mf.pf_H = H;
-                mf.pf_pair_stride = (long)L * 64 * eb;
-                // (64 KiB of fp16 rows = the K = 256 condition rows, which every step's walk covers; rows beyond the context are allocated memory, read in vain)
-                mf.pf_bytes = (int)std::min<long>((long)pf_kb * 512, (long)L * 64 * eb) / 1024 * 1024;
-            }
             launch_ar_mlp_fused(mf, s);
             src = RowSrc{};
             src.base = x2; src.ld = D; src.partial = part; src.ns = MLP_FUSED_PLANES; src.pstride = (long)Bc * D; src.pld = D; src.bias = l.mlp2_b;

@@ -1221,7 +1221,6 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     __shared__ float red[2][SF_WAVES][4][64];
     __shared__ float stat[2][SF_WAVES][16];
     __shared__ unsigned flag_s;
-    __shared__ __attribute__((aligned(1024))) float4 pf_sink[SF_WAVES * 64];   // landing zone of the K/V prefetch requests (never read)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int D = g.D, K2 = 4 * D;
@@ -1406,25 +1405,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
             if (c < nch2) As[c * 16 + r] = hv;
         }
     }
-    // ---- K/V prefetch for the next attention launch.  From here on this launch needs nothing from the fabric (the hidden slice is in this XCD's L2, the down weights in
-    // registers): ~3 us of idle HBM.  L2 contents survive the kernel boundary (tools/l2bw/l2_persist_probe: a region read by the previous kernel on the same XCD comes back
-    // at 23 TB/s chip-wide, against 7.3 from the memory-side cache and 6.3 from HBM) and the attention workgroup of (sequence, head) runs on XCD head % 8, so workgroup jx of
-    // this XCD requests the leading rows of ONE such pair: they are the rows the attention launch stages first.  The requests are asm (the compiler must not count them: nothing
-    // ever waits for them), their results are never read, they follow this launch's last load in issue order (a CU returns loads in order), and the barriers below order
-    // LDS traffic only.  They are LDS-DMA requests into a sink nobody reads (no destination registers whose reuse a late return could clobber).
-    if (g.pf_k && mc == n_mc - 1) {
-        const int hx = g.pf_H >> 3;
-        if (jx < hx * g.M) {   // (workgroup-uniform)
-            const int head = xcd + 8 * (jx % hx), seq = jx / hx;
-            const long pair = ((long)seq * g.pf_H + head) * g.pf_pair_stride;
-            const int per = g.pf_bytes >> 10;   // 1 KiB pieces per image
-            for (int pc = wave; pc < 2 * per; pc += SF_WAVES) {
-                const char* src = (pc < per ? reinterpret_cast<const char*>(g.pf_k) + pair + (long)pc * 1024 : reinterpret_cast<const char*>(g.pf_v) + pair + (long)(pc - per) * 1024) + lane * 16;
-                glds16_hidden(src, (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(pf_sink + wave * 64)));
-            }
-        }
-    }
-    lds_barrier();
+    __syncthreads();
     f32x4 acc2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (WT) {
 #pragma unroll
@@ -1462,7 +1443,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[t][wave][j][lane] = acc2[t][j];
-    lds_barrier();
+    __syncthreads();
     MF_TRACE(4);
     {   // thread (t, j, lane): one element of one of the two 16 x 16 output tiles
         const int t = tid >> 8, j = (tid >> 6) & 3, ln = tid & 63;

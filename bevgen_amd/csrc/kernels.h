@@ -306,11 +306,6 @@ struct MlpFusedArgs {
     unsigned* err = nullptr;                           // host-visible error word (non-zero: a barrier timed out / a workgroup was not on the XCD its index implies)
     int M = 0, D = 0;
     long long* trace = nullptr;
-    // K/V prefetch for the NEXT decode-attention launch (decode_fused.hip, phase 2): the workgroups of XCD x pull the leading pf_bytes of the K rows and of the V rows of
-    // the (sequence, head) pairs whose attention workgroups will run on XCD x (head % 8 == x) into that XCD's L2.  Null pf_k: off
-    const void *pf_k = nullptr, *pf_v = nullptr;      // next layer's cache images [M][pf_H][Lmax][64]
-    int pf_H = 0, pf_bytes = 0;                        // heads (a multiple of 8); bytes per pair and image (a multiple of 1024)
-    long pf_pair_stride = 0;                           // bytes between consecutive (sequence, head) pairs = Lmax * 64 * element size
 };
 constexpr int MLP_FUSED_PLANES = 8;
 size_t mlp_fused_sync_words();
