@@ -7,9 +7,18 @@ there is no data-path collective here either; the only exchange is one gather of
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
+
+
+def _passthrough(dist) -> bool:
+    """No collective needed: no process group, or a group of one - unless $BEVGEN_FORCE_COLLECTIVE=1 asks for the collective anyway (the GPU suite's single-GPU RCCL
+    test: one rank is all a 1-GPU box can host, and the call path through RCCL should still have run on hardware once)."""
+    if dist is None or not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("BEVGEN_FORCE_COLLECTIVE") != "1"
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -29,7 +38,7 @@ def gather_scenes(px: torch.Tensor, dist=None, dst: int = 0) -> Optional[torch.T
     `dst`; returns the concatenation there, None elsewhere.  All ranks must pass blocks of the same shape (pad the last shard if the scene count
     does not divide)."""
     u8 = px if px.dtype == torch.uint8 else to_uint8(px)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _passthrough(dist):
         return u8
     world, rank = dist.get_world_size(), dist.get_rank()
     bufs: Optional[List[torch.Tensor]] = [torch.empty_like(u8) for _ in range(world)] if rank == dst else None
@@ -40,7 +49,7 @@ def gather_scenes(px: torch.Tensor, dist=None, dst: int = 0) -> Optional[torch.T
 def gather_token_ids(ids: torch.Tensor, dist=None, dst: int = 0) -> Optional[torch.Tensor]:
     """Same for token ids (int32 on the wire, 6 KB per six-view scene: int16 is not a collective dtype on every backend)."""
     small = ids.to(torch.int32)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _passthrough(dist):
         return small.to(torch.int64)
     world, rank = dist.get_world_size(), dist.get_rank()
     bufs = [torch.empty_like(small) for _ in range(world)] if rank == dst else None
