@@ -718,6 +718,12 @@ def main():
                                                            "ms_per_decode_step_p99": c5["ms_per_decode_step_p99"], "sequences_per_s": c5["decode_sequences_per_s"], "prefill_ms": c5["decode_prefill_ms"],
                                                            "roofline_decode_attention": c5["roofline_decode_attention"], "decode_step_roofline": c5["decode_step_roofline"],
                                                            "config": "BASELINE configs[4] on one GPU: Route A config-4 model, top-k 32, explicit uniforms (Philox seed 2025), 16 BEV layouts x 4 samples, condition prefix prefilled and read once per layout"}
+            # the same with the fp16 K/V cache + fp16 projection weights (BASELINE configs[3] names fp16; token ids then follow the near-tie criterion, not equality)
+            c5h = decode_leg(local_rank, 64, args.decode_steps, kv_cache="f16", weights="f16", S=4, top_k=32, stochastic=True)
+            line["config5_topk32_4_samples_per_layout_f16"] = {"sequences": 64, "layouts": 16, "ms_per_decode_step": c5h["ms_per_decode_step"], "ms_per_decode_step_median": c5h["ms_per_decode_step_median"],
+                                                               "ms_per_decode_step_p99": c5h["ms_per_decode_step_p99"], "sequences_per_s": c5h["decode_sequences_per_s"],
+                                                               "roofline_decode_attention": c5h["roofline_decode_attention"], "decode_step_roofline": c5h["decode_step_roofline"],
+                                                               "config": "as config5_topk32_4_samples_per_layout, fp16 K/V cache + fp16 projection weights"}
     if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "none":
         line["cpu_baseline"] = cpu_baseline(args.cams, args.timesteps, args.cpu_baseline)
 
@@ -802,6 +808,10 @@ def main():
             c = detail["config5_topk32_4_samples_per_layout"]
             legs["config5_64seq_1gpu"] = {"ms_step": rnd(c["ms_per_decode_step"]), "median": rnd(c["ms_per_decode_step_median"]), "p99": rnd(c["ms_per_decode_step_p99"]),
                                           "sequences_per_s": rnd(c["sequences_per_s"], 2), "attn_frac_storage_bytes": rnd(c["roofline_decode_attention"]["frac"]), "step_frac": rnd(c["decode_step_roofline"]["frac"])}
+        if "config5_topk32_4_samples_per_layout_f16" in detail:
+            c = detail["config5_topk32_4_samples_per_layout_f16"]
+            legs["config5_64seq_1gpu_f16"] = {"ms_step": rnd(c["ms_per_decode_step"]), "sequences_per_s": rnd(c["sequences_per_s"], 2), "attn_frac_storage_bytes": rnd(c["roofline_decode_attention"]["frac"]),
+                                              "step_frac": rnd(c["decode_step_roofline"]["frac"])}
         dl = {"prefill_ms": rnd(detail["decode_prefill_ms"], 2)}
         for name, key in (("split_path_f16_kv_f16_w", "decode_split_path_f16_kv_cache_f16_weights"), ("density035_f16_kv", "decode_density_035_f16_kv_cache"),
                           ("density035_f16_kv_f16_w", "decode_density_035_f16_kv_cache_f16_weights"), ("f16_kv", "decode_f16_kv_cache"), ("f32_kv", None),
