@@ -364,11 +364,8 @@ int bevgen_op_attention_ex(bevgen_ctx* ctx, const float* q, const float* k, cons
             hipStream_t s = (hipStream_t)stream;
             const size_t nq = (size_t)B * H * Nq * 64, nk = (size_t)B * H * Nk_pad * 64;
             const size_t bpk = bias ? (size_t)attn_bias_packed_floats(Nq, Nk_pad) : 0, braw = bias ? (size_t)Nq * ldbias : 0;
-            const int flat = key_splits < 0 ? -key_splits : 0;   // key_splits = -W: the flat tile queue on W workgroups
-            if (flat) key_splits = 1;
             BG_REQUIRE(key_splits >= 1 && key_splits <= 8 && Nk_pad / 32 >= key_splits, "op_attention: key_splits=%d out of range for Nk_pad=%d", key_splits, Nk_pad);
-            BG_REQUIRE(!flat || attn_flat_ok(B, H, Nq, Nk_pad, flat), "op_attention: a flat queue of %d workgroups does not fit B=%d H=%d Nq=%d Nk_pad=%d", flat, B, H, Nq, Nk_pad);
-            const size_t kws = flat ? (size_t)attn_flat_ws_floats(flat) : key_splits > 1 ? (size_t)attn_split_ws_floats(B, H, Nq, key_splits) : 0;
+            const size_t kws = key_splits > 1 ? (size_t)attn_split_ws_floats(B, H, Nq, key_splits) : 0;
             ctx->arena.reserve((nq + 2 * nk) * 4 + (bpk + braw + kws) * 4 + 8192);
             ctx->arena.reset();
             _Float16* Qp = reinterpret_cast<_Float16*>(ctx->arena.alloc(nq * 4));
@@ -387,7 +384,6 @@ int bevgen_op_attention_ex(bevgen_ctx* ctx, const float* q, const float* k, cons
             }
             sa.bias_head_stride = 0;
             if (key_splits > 1) { sa.ksplit = key_splits; sa.kws = reinterpret_cast<float*>(ctx->arena.alloc(kws * 4)); }
-            if (flat) { sa.flat_wgs = flat; sa.kws = reinterpret_cast<float*>(ctx->arena.alloc(kws * 4)); }
             sa.O = out; sa.Op = nullptr; sa.B = B; sa.H = H; sa.Nq = Nq; sa.Nk_pad = Nk_pad; sa.scale = scale * kLog2e;
             sa.o_bstride = (long)Nq * H * 64; sa.o_qstride = (long)H * 64; sa.o_hstride = 64;
             launch_attention_split(sa, s);

@@ -56,12 +56,8 @@ __device__ unsigned long long g_attn_trace[8 * 16 * 8];   // [wave][tile][stamp]
 #define PP_STAMP(k) do { } while (0)
 #endif
 
-// KS: 1 = key-split form (AttnSplitArgs::ksplit > 1; a template value so that the throughput instantiation carries none of its index arithmetic).
-//     2 = FLAT TILE QUEUE (AttnSplitArgs::flat_wgs > 0): the (batch, head, query block) pairs x their key tiles are one list of P T units, cut into gridDim.x equal
-//     contiguous shares - a workgroup walks up to ATTN_FLAT_MAXSEG segments (the tail of one pair's key range, whole pairs, the head of the next one's) and leaves
-//     one partial row set per segment.  Whatever the batch size, every CU gets the same number of key tiles: one scene is 96 pairs x 49 tiles = 18.4 tiles per
-//     workgroup instead of 24.5 with two uniform ranges (192 workgroups), two scenes 36.75 instead of 49 (192 workgroups, 64 CUs idle), three 55 instead of 98 (two rounds).
-template <bool TRACE, int KS = 0>
+// KS: key-split form (AttnSplitArgs::ksplit > 1; a template flag so that the throughput instantiation carries none of its index arithmetic)
+template <bool TRACE, bool KS = false>
 __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2][4][PP_PLANE];   // [stage][Kh, Kl, Vh, Vl]
 #ifdef BEVGEN_ATTN_LAB
@@ -72,44 +68,35 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     const int qi = lane & 31, h = lane >> 5;
     // XCD-aware order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  The q blocks of one (batch, head) read the same K / V planes, so they
     // are given to ONE XCD: virtual id v = (L % 8) * (total / 8) + L / 8, q block = v % nqb - K / V enter one L2 instead of (up to) all eight
-    // (flat queue: gridDim = (W, 1, 1); consecutive virtual ids own consecutive shares of the unit list, i.e. consecutive query blocks of one (batch, head))
-    const int nqb = KS == 2 ? (a.Nq + 255) / 256 : (int)gridDim.x, n_heads = KS == 2 ? a.H : (int)gridDim.y;
-    const int total = KS == 2 ? (int)gridDim.x : nqb * gridDim.y * gridDim.z;
-    const int lin = KS == 2 ? (int)blockIdx.x : blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int nqb = gridDim.x, total = nqb * gridDim.y * gridDim.z;
+    const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
     const int vid = (total % 8 == 0) ? (lin % 8) * (total / 8) + lin / 8 : lin;
-    const int ntiles_all = a.Nk_pad / SKT;
-    const int bstep = a.bias_pk_tile_step;   // (no bias: the launcher points bias_pk at a zero block with both steps 0 - unconditional loads, no select in the loop)
-    // flat queue: this workgroup's units [u_cur, u_end) of the P * ntiles_all (pair-major)
-    long u_cur = 0, u_end = 0;
-    if (KS == 2) {
-        const long U = (long)nqb * n_heads * a.B * ntiles_all;
-        u_cur = (long)vid * U / total; u_end = (long)(vid + 1) * U / total;
-    }
-  for (int seg = 0;; ++seg) {
-    if (KS == 2 && u_cur >= u_end) break;
-    const int pair = KS == 2 ? (int)(u_cur / ntiles_all) : vid;
-    // pair order.  Default: the q blocks of one (batch, head) are neighbours (their K / V planes enter one XCD's L2).  qb_major: all pairs of one q block are neighbours -
-    // an XCD then walks at most two q blocks' rows of the bias image (1.6 MB each: they stay in its 4 MB L2 and every head / scene re-reads them there), and K / V come
-    // from the memory side instead.  The bias segment is requested ONE tile ahead and is the MFMA's C operand, K / V two tiles ahead: the bias is the latency-critical stream
-    const int n_bz = total / (nqb * n_heads);
-    const int qblk = a.qb_major ? pair / (n_heads * n_bz) : pair % nqb;
-    const int head = a.qb_major ? pair % n_heads : (pair / nqb) % n_heads;
-    const int bz = a.qb_major ? (pair / n_heads) % n_bz : pair / (nqb * n_heads);
-    const int nks = KS == 1 ? a.ksplit : 1;
-    const int b = KS == 1 ? bz / nks : bz, ks = KS == 1 ? bz - b * nks : 0;   // KS == 1: gridDim.z = B * ksplit
+    const int qblk = vid % nqb, head = (vid / nqb) % gridDim.y, bz = vid / (nqb * gridDim.y);
+    const int nks = KS ? a.ksplit : 1;
+    const int b = KS ? bz / nks : bz, ks = KS ? bz - b * nks : 0;   // gridDim.z = B * ksplit
     const int qrow = qblk * 256 + wave * 32 + qi;
     const bool qvalid = qrow < a.Nq;
     const int qc = qvalid ? qrow : a.Nq - 1;
 
     const long qoff = ((long)b * a.H + head) * a.Nq * 64 + (long)qc * 64 + 8 * h;
     const long koff = ((long)(b / a.kv_group) * a.H + head) * (long)a.Nk_pad * 64;
-    // this segment's key tiles [t_first, t_first + ntiles)
-    const int t_first = KS == 2 ? (int)(u_cur - (long)pair * ntiles_all) : (KS == 1 ? ks * ntiles_all / nks : 0);
-    const int ntiles = KS == 2 ? (int)min((long)(ntiles_all - t_first), u_end - u_cur) : (KS == 1 ? (ks + 1) * ntiles_all / nks - t_first : ntiles_all);
-    if (KS == 2) u_cur += ntiles;
+    // (no bias: the launcher points bias_pk at a zero block with both steps 0 - unconditional loads, no select in the loop)
+    const int bstep = a.bias_pk_tile_step;
+    // this workgroup's key tiles [t_first, t_first + ntiles)
+    const int ntiles_all = a.Nk_pad / SKT;
+    const int t_first = KS ? ks * ntiles_all / nks : 0;
+    const int ntiles = KS ? (ks + 1) * ntiles_all / nks - t_first : ntiles_all;
     const float* Bp = a.bias_pk + (long)head * a.bias_head_stride + (long)(qblk * 8 + wave) * a.bias_pk_qb_stride + lane * 4 + (long)t_first * bstep;
 
-    half8 qh[4], qs[4], qls[4];   // q_hi, q_hi 2^-11, q_lo 2^-11 (loaded below, behind the first tile's requests)
+    // q_hi, q_hi 2^-11, q_lo 2^-11
+    half8 qh[4], qs[4], qls[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qh[s] = *reinterpret_cast<const half8*>(a.Qh + qoff + 16 * s);
+        const half8 ql = *reinterpret_cast<const half8*>(a.Ql + qoff + 16 * s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qs[s][e] = qh[s][e] * (_Float16)kLoI; qls[s][e] = ql[e] * (_Float16)kLoI; }
+    }
     f32x16 oM[2], oC[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -153,17 +140,8 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
         }
     };
 
-    // the first tile's K / V^T chunks and bias segment are requested BEFORE the query rows: nothing below depends on another load, so the workgroup's cold start is one
-    // memory round trip (q, tile 0 and its bias together) instead of two (the q operands were formed - a wait - before tile 0 was even requested)
     gload_bias(0);
     gload(0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qh[s] = *reinterpret_cast<const half8*>(a.Qh + qoff + 16 * s);
-        const half8 ql = *reinterpret_cast<const half8*>(a.Ql + qoff + 16 * s);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { qs[s][e] = qh[s][e] * (_Float16)kLoI; qls[s][e] = ql[e] * (_Float16)kLoI; }
-    }
     lstore(0);
     gload(min(1, ntiles - 1));
     __syncthreads();
@@ -289,9 +267,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     const float l_tot = l_run + xor32(l_run);
     if (KS) {   // partial result of this key range: unnormalised output row (relative to m_run), m_run, row sum
         if (qvalid) {
-            // KS == 1: [range][B][H][Nq] rows; KS == 2: [workgroup share][segment][256 rows of the query block]
-            float* wrow = KS == 2 ? a.kws + (((long)vid * ATTN_FLAT_MAXSEG + seg) * 256 + (wave * 32 + qi)) * 66
-                                  : a.kws + ((((long)ks * a.B + b) * a.H + head) * a.Nq + qrow) * 66;
+            float* wrow = a.kws + ((((long)ks * a.B + b) * a.H + head) * a.Nq + qrow) * 66;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -302,7 +278,6 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
                 }
             if (h == 0) *reinterpret_cast<float2*>(wrow + 64) = make_float2(m_run, l_tot);
         }
-        if (KS == 2) continue;   // next segment (the barrier that closed this one's last phase has every wave past its last LDS read)
         return;
     }
     const float inv = 1.f / l_tot;
@@ -320,8 +295,6 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
                 else *reinterpret_cast<float4*>(a.O + orow + d) = make_float4(o[0], o[1], o[2], o[3]);
             }
     }
-    return;
-  }   // segments
 }
 
 // bias [Nq, ld] -> packed image [ceil(Nq/256) * 8 q blocks][Nk_pad/32][4][64][4]: element (qb, tile, g, lane = qi + 32 h, e) = bias[32 qb + qi][32 tile + 8 g + 4 h + e]
@@ -386,59 +359,9 @@ __global__ __launch_bounds__(256) void attention_split_combine_kernel(AttnSplitA
     else *reinterpret_cast<float4*>(a.O + (long)b * a.o_bstride + (long)q * a.o_qstride + (long)head * a.o_hstride + d) = o;
 }
 
-// merge of the segments of a flat-queue launch: one thread per (pair, row of its query block, 4 output columns); the shares that touch the pair in ascending order
-__global__ __launch_bounds__(256) void attention_flat_combine_kernel(AttnSplitArgs a) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const int nqb = (a.Nq + 255) / 256;
-    const long P = (long)a.B * a.H * nqb;
-    if (i >= P * 256 * 16) return;
-    const int d = (int)(i & 15) * 4, r = (int)((i >> 4) & 255);
-    const long p = i >> 12;
-    const int qblk = (int)(p % nqb), head = (int)((p / nqb) % a.H), b = (int)(p / ((long)nqb * a.H));
-    const int q = qblk * 256 + r;
-    if (q >= a.Nq) return;
-    const long T = a.Nk_pad / SKT, U = P * T, W = a.flat_wgs;
-    const long w_lo = ((p * T + 1) * W + U - 1) / U - 1, w_hi = (((p + 1) * T) * W + U - 1) / U - 1;   // share of unit u: ceil((u + 1) W / U) - 1
-    float m = kNegBig;
-    for (long w = w_lo; w <= w_hi; ++w) {
-        const long seg = p - (w * U / W) / T;
-        m = fmaxf(m, a.kws[((w * ATTN_FLAT_MAXSEG + seg) * 256 + r) * 66 + 64]);
-    }
-    float l = 0.f;
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long w = w_lo; w <= w_hi; ++w) {
-        const long seg = p - (w * U / W) / T;
-        const float* wr = a.kws + ((w * ATTN_FLAT_MAXSEG + seg) * 256 + r) * 66;
-        const float sc = __builtin_amdgcn_exp2f(wr[64] - m);
-        l = fmaf(wr[65], sc, l);
-        const float2 v0 = *reinterpret_cast<const float2*>(wr + d), v1 = *reinterpret_cast<const float2*>(wr + d + 2);
-        o.x = fmaf(v0.x, sc, o.x); o.y = fmaf(v0.y, sc, o.y); o.z = fmaf(v1.x, sc, o.z); o.w = fmaf(v1.y, sc, o.w);
-    }
-    const float inv = 1.f / l;
-    o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-    if (a.Op) store_planes4(a.Op + ((long)b * a.Nq + q) * 2 * (a.H * 64), head * 64 + d, o);
-    else *reinterpret_cast<float4*>(a.O + (long)b * a.o_bstride + (long)q * a.o_qstride + (long)head * a.o_hstride + d) = o;
-}
-
 void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
     AttnSplitArgs a = a0;
     if (a.ksplit < 1) a.ksplit = 1;
-    static const int qbm_env = getenv("BEVGEN_ATTN_QB_MAJOR") ? atoi(getenv("BEVGEN_ATTN_QB_MAJOR")) : 0;
-    a.qb_major = qbm_env && a.flat_wgs == 0 && ((long)cdiv(a.Nq, 256) * a.H * a.B * a.ksplit) % 8 == 0;
-    if (a.flat_wgs > 0) {
-        BG_REQUIRE(a.kws && a.ksplit == 1 && a.Nk_pad % SKT == 0 && attn_flat_ok(a.B, a.H, a.Nq, a.Nk_pad, a.flat_wgs),
-                   "attention_split: flat queue of %d workgroups does not fit B=%d H=%d Nq=%d Nk_pad=%d (or no workspace)", a.flat_wgs, a.B, a.H, a.Nq, a.Nk_pad);
-        a.bias_pk_tile_step = 1024;
-        a.bias_pk_qb_stride = (long)(a.Nk_pad / SKT) * 1024;
-        if (a.bias_pk == nullptr) { a.bias_pk = zero_block(); a.bias_head_stride = 0; a.bias_pk_tile_step = 0; a.bias_pk_qb_stride = 0; }
-        ProfScope prof(PROF_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk_pad * 64, s);
-        hipLaunchKernelGGL((attention_split_kernel<false, 2>), dim3(a.flat_wgs), dim3(512), 0, s, a);
-        LAUNCH_CHECK();
-        const long total = (long)a.B * a.H * ((a.Nq + 255) / 256) * 256 * 16;
-        hipLaunchKernelGGL(attention_flat_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
-        LAUNCH_CHECK();
-        return;
-    }
     BG_REQUIRE(a.ksplit == 1 || (a.kws && a.Nk_pad / SKT >= a.ksplit), "attention_split: key split %d needs a workspace and at least one key tile per range", a.ksplit);
     BG_REQUIRE(a.Nk_pad % SKT == 0 && a.Nk_pad > 0, "attention_split: Nk_pad=%d must be a positive multiple of %d", a.Nk_pad, SKT);
     a.bias_pk_tile_step = 1024;
@@ -455,8 +378,8 @@ void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
     else
 #endif
     {
-        if (a.ksplit > 1) hipLaunchKernelGGL((attention_split_kernel<false, 1>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((attention_split_kernel<false, 0>), grid, dim3(512), 0, s, a);
+        if (a.ksplit > 1) hipLaunchKernelGGL((attention_split_kernel<false, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((attention_split_kernel<false, false>), grid, dim3(512), 0, s, a);
     }
     LAUNCH_CHECK();
     if (a.ksplit > 1) {

@@ -162,21 +162,9 @@ struct AttnSplitArgs {
     // key split (low-latency path: one scene gives cdiv(Nq, 256) * H = 96 workgroups for 256 CUs): the key tiles are cut into `ksplit` ranges, one workgroup per
     // (query block, head, batch, range); each writes its unnormalised output row, running maximum and row sum to `kws` and a combine kernel merges the ranges
     int ksplit = 1;
-    float* kws = nullptr;             // attn_split_ws_floats(B, H, Nq, ksplit) floats (flat queue: attn_flat_ws_floats(flat_wgs))
-    // flat tile queue (attention_split.hip, KS = 2): > 0 = number of workgroups the (pair, key tile) list is cut into; the launcher checks attn_flat_ok()
-    int flat_wgs = 0;
-    int qb_major = 0;                 // set by the launcher: pair order of the workgroups (attention_split.hip)
+    float* kws = nullptr;             // attn_split_ws_floats(B, H, Nq, ksplit) floats
 };
 inline long attn_split_ws_floats(int B, int H, int Nq, int ksplit) { return (long)ksplit * B * H * Nq * 66; }
-constexpr int ATTN_FLAT_MAXSEG = 4;   // segments (pairs touched) per workgroup share
-inline long attn_flat_ws_floats(int wgs) { return (long)wgs * ATTN_FLAT_MAXSEG * 256 * 66; }
-// shares of ceil(U / W) units touch at most ATTN_FLAT_MAXSEG pairs, every pair has at least one tile per touching share by construction
-inline bool attn_flat_ok(int B, int H, int Nq, int Nk_pad, int wgs) {
-    const long T = Nk_pad / 32, P = (long)B * H * ((Nq + 255) / 256), U = P * T;
-    if (wgs <= 0 || T <= 0 || U < wgs) return false;
-    const long share = (U + wgs - 1) / wgs;
-    return (share - 1 + T - 1) / T + 1 <= ATTN_FLAT_MAXSEG;
-}
 long attn_bias_packed_floats(int Nq, int Nk_pad);
 void launch_pack_attn_bias(const float* bias, int ld, int Nq, int Nk_pad, float* out, hipStream_t s);
 void launch_attn_split_operands(const float* q, const float* k, const float* v, void* Qh, void* Ql, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nq, int Nk_pad,

@@ -24,7 +24,6 @@ struct MuseWs {
     std::vector<float*> crossK, crossV;
     float *x = nullptr, *xn = nullptr, *qraw = nullptr, *kvraw = nullptr, *Q = nullptr, *Ks = nullptr, *Vs = nullptr, *att = nullptr, *h = nullptr, *g = nullptr;
     float* attn_ws = nullptr; int attn_ks = 1;   // key-split self-attention of the low-latency path (pick_attn_ksplit): partial rows of the key ranges
-    int attn_flat = 0;                            // > 0: the flat tile queue on that many workgroups instead (pick_attn_flat); attn_ws holds its segment partials
     float* kpart = nullptr;   // split-K partial tiles of the narrow (N = D) projections when the batch is too small to fill the chip (low-latency path)
 };
 
@@ -60,21 +59,6 @@ int pick_attn_ksplit(long blocks, int ntiles) {
     return std::max(ks, 1);
 }
 
-// Flat tile queue of the self-attention (attention_split.hip, KS = 2): P = cdiv(N, 256) H B workgroups of T key tiles each cost ceil(P / 256) T tile times on 256 CUs;
-// the flat queue costs P T / 256 (+ a segment switch and the merge).  Taken when the grid wastes at least an eighth of its tile times and the key range is long;
-// returns the number of workgroups (0: the plain / key-split launch).  $BEVGEN_ATTN_FLAT = 0 | W pins it
-int pick_attn_flat(int B, int H, int Nq, int Nk_pad) {
-    static const int env = getenv("BEVGEN_ATTN_FLAT") ? atoi(getenv("BEVGEN_ATTN_FLAT")) : -1;
-    const long P = (long)cdiv(Nq, 256) * H * B, T = Nk_pad / 32;
-    int W = 0;
-    if (env >= 0) W = env;
-    else if (T >= 16 && P % 256 != 0) {
-        const double paid = (double)cdiv(P, 256L) * T, need = (double)P * T / 256.0;
-        if (paid >= 1.125 * need + 2.0) W = 256;
-    }
-    return W > 0 && attn_flat_ok(B, H, Nq, Nk_pad, W) ? W : 0;
-}
-
 size_t muse_ws_bytes(const Ctx& c, int B) {
     const size_t rows = (size_t)B * c.N;
     const size_t crows = (size_t)B * c.K;
@@ -91,9 +75,7 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
     if (std::max(pick_ksplit((long)rows, c.D, c.D), pick_ksplit((long)rows, c.D, c.Fpad)) > 1) f += (size_t)KSPLIT_MAX * rows * c.D;
     {
         const int ks = pick_attn_ksplit((long)cdiv(c.N, 256) * c.H * B, c.NkS_pad / 32);
-        const int fw = pick_attn_flat(B, c.H, c.N, c.NkS_pad);
-        if (fw > 0) f += (size_t)attn_flat_ws_floats(fw);
-        else if (ks > 1) f += (size_t)attn_split_ws_floats(B, c.H, c.N, ks);
+        if (ks > 1) f += (size_t)attn_split_ws_floats(B, c.H, c.N, ks);
     }   // split-K partial tiles (small batches only)
     return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256;
 }
@@ -166,9 +148,7 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.g = a.get<float>((size_t)w.rows * c.Fpad);
     w.kpart = std::max(pick_ksplit(w.rows, D, D), pick_ksplit(w.rows, D, c.Fpad)) > 1 ? a.get<float>((size_t)KSPLIT_MAX * w.rows * D) : nullptr;
     w.attn_ks = pick_attn_ksplit((long)cdiv(c.N, 256) * H * B, c.NkS_pad / 32);
-    w.attn_flat = pick_attn_flat(B, H, c.N, c.NkS_pad);
-    if (w.attn_flat > 0) { w.attn_ks = 1; w.attn_ws = a.get<float>((size_t)attn_flat_ws_floats(w.attn_flat)); }
-    else w.attn_ws = w.attn_ks > 1 ? a.get<float>((size_t)attn_split_ws_floats(B, H, c.N, w.attn_ks)) : nullptr;
+    w.attn_ws = w.attn_ks > 1 ? a.get<float>((size_t)attn_split_ws_floats(B, H, c.N, w.attn_ks)) : nullptr;
     HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
     HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
 
@@ -265,9 +245,9 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             sa.ldbias = c.ldS; sa.bias_head_stride = 0; sa.scale = 8.0f * kLog2e;
             sa.o_bstride = (long)N * D; sa.o_qstride = D; sa.o_hstride = 64;
             sa.Op = reinterpret_cast<_Float16*>(w.att);
-            sa.ksplit = w.attn_ks; sa.kws = w.attn_ws; sa.flat_wgs = w.attn_flat;
+            sa.ksplit = w.attn_ks; sa.kws = w.attn_ws;
             launch_attention_split(sa, s);
-            sa.ksplit = 1; sa.kws = nullptr; sa.flat_wgs = 0;   // (the cross-attention's 9 key tiles stay one range)
+            sa.ksplit = 1; sa.kws = nullptr;   // (the cross-attention's 9 key tiles stay one range)
         } else {
             launch_muse_q_prep(w.qraw, l.q_scale[0], w.Q, B, H, N, s);
             launch_muse_kv_prep(w.kvraw, l.null_kv[0], l.k_scale[0], w.Ks, w.Vs, B, H, N, c.NkS_pad, s);

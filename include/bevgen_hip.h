@@ -249,9 +249,7 @@ int bevgen_op_geglu_layernorm(bevgen_ctx* ctx, const float* d_h, const float* d_
 int bevgen_op_attention(bevgen_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, const float* d_bias, int ldbias,
                         int B, int H, int Nq, int Nk_pad, float scale, float* d_out, void* stream);   /* q [B,H,Nq,64], k/v [B,H,Nk_pad,64] */
 /* The same with the key tiles of the split-precision kernel cut into `key_splits` ranges (1..8; needs Nk_pad / 32 >= key_splits) merged by a combine kernel - the form
- * the Route M model path picks for its self-attention at one scene per call (muse.cpp pick_attn_ksplit); fp32-precision contexts ignore key_splits.
- * key_splits = -W (W > 0): the flat tile queue - the (batch, head, query block) x key tile list cut into W equal shares, one workgroup each (what the model path uses when
- * the grid would leave CUs idle or pay a short last round; every share may touch at most 4 pairs: W >= about a third of the pairs). */
+ * the Route M model path picks for its self-attention at one scene per call (muse.cpp pick_attn_ksplit); fp32-precision contexts ignore key_splits. */
 int bevgen_op_attention_ex(bevgen_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, const float* d_bias, int ldbias,
                            int B, int H, int Nq, int Nk_pad, float scale, int key_splits, float* d_out, void* stream);
 int bevgen_op_decode_attention(bevgen_ctx* ctx, const float* d_q, const void* d_kcache, const void* d_vcache, int kv_dtype,
