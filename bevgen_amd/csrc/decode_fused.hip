@@ -1214,6 +1214,26 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 // a hipGraph; sync[512 + i] records the XCD workgroup i saw.
 size_t mlp_fused_sync_words() { return 512 + 1024; }
 
+// fp16 weight storage: the product of 8 consecutive k of a row with the weight fragment on the f16 matrix pipe instead of eight v_mfma_f32_16x16x4_f32 (32 cycles of
+// the SIMD's matrix pipe each, 40 as a dependent chain: the 32 + 32 of a workgroup's two projections were ~2 us of the launch's 10.7).  The fp32 activation is split
+// a = hi + lo 2^-11 (two f16 numbers, as everywhere in Route M; the fp16 weight is exact), so a w = hi w + 2^-11 lo w with both products exact in the fp32 accumulators:
+// two v_mfma_f32_16x16x32_f16 (~17 cycles each) on separate accumulators, merged by mlpf_merge.  Lane (r, q) holds row r, k = 8 q .. 8 q + 7 of both operands - the
+// same (lane, element) -> k map on either side, which is all a matrix instruction needs.
+__device__ __forceinline__ void mlpf_mma_f16(const float4& a0, const float4& a1, const half8_t& w, f32x4& acc_hi, f32x4& acc_lo) {
+    half8_t ah, al;
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ah[e] = split_hi(av[e]); al[e] = split_lo(av[e], ah[e]); }
+    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, w, acc_hi, 0, 0, 0);
+    acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, w, acc_lo, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mlpf_merge(const f32x4& hi, const f32x4& lo) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = hi[j] + lo[j] * (1.f / 2048.f);
+    return o;
+}
+
 template <int WT>   // weight storage of both packed images: 0 fp32, 1 fp16
 __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArgs g) {
     __shared__ float4 As[256 * 16];          // phase 1: the rows [k/4][16 rows] (K = D <= 1024); phase 2: the hidden slice (D / 2 columns)
@@ -1321,20 +1341,11 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (WT) {
+        f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (32 * u < kper) {
-                const float4 a0 = aop[2 * u], a1 = aop[2 * u + 1];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, (float)wh[u][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, (float)wh[u][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, (float)wh[u][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, (float)wh[u][3], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, (float)wh[u][4], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, (float)wh[u][5], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, (float)wh[u][6], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, (float)wh[u][7], acc, 0, 0, 0);
-            }
-        }
+        for (int u = 0; u < 4; ++u)
+            if (32 * u < kper) mlpf_mma_f16(aop[2 * u], aop[2 * u + 1], wh[u], acc, acc_lo);
+        acc = mlpf_merge(acc, acc_lo);
     } else {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -1408,23 +1419,23 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     __syncthreads();
     f32x4 acc2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (WT) {
+        f32x4 acc2_lo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int c4 = ((wave * kper2 + 32 * u) >> 2) + 2 * q;
             const float4 a0 = As[c4 * 16 + r], a1 = As[(c4 + 1) * 16 + r];
+            half8_t ah, al;   // (the split of the hidden values is shared by the two column tiles)
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ah[e] = split_hi(av[e]); al[e] = split_lo(av[e], ah[e]); }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const half8_t w8 = dh[2 * t + u];
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, (float)w8[0], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, (float)w8[1], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, (float)w8[2], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, (float)w8[3], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, (float)w8[4], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, (float)w8[5], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, (float)w8[6], acc2[t], 0, 0, 0);
-                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, (float)w8[7], acc2[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, dh[2 * t + u], acc2[t], 0, 0, 0);
+                acc2_lo[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, dh[2 * t + u], acc2_lo[t], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc2[t] = mlpf_merge(acc2[t], acc2_lo[t]);
     } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -24,7 +24,10 @@ ctx.trace_begin()
 ctx.ar_sample(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], steps=steps, samples_per_layout=S)
 tr = ctx.trace_end().double() / 100.0   # us (100 MHz)
 names = [("ln1+qkv+attention", ["start", "ln1 done", "qkv done", "append done", "attention done", "end"]),
-         ("ln2+MLP-up", ["start", "A tile staged", "MFMA+reduce", "end"]),
+         # (the fused MLP launch - ar_mlp_fused_kernel, the default at D = 1024 - stamps six points into this slot; the two-launch form the first four)
+         ("ln2+MLP-up" if os.environ.get("BEVGEN_LN2_FOLD") == "0" else "fused MLP launch (ln2 + up + GELU | exchange | down)",
+          ["start", "A tile staged", "MFMA+reduce", "end"] if os.environ.get("BEVGEN_LN2_FOLD") == "0" else
+          ["start", "rows staged", "up-projection + GELU stored", "exchange passed", "down-projection partial sums in LDS", "end"]),
          ("MLP-down", ["start", "A tile staged", "MFMA+reduce", "end"])]
 print(f"B={B} S={S} kv={kv} weights={WT}: last step context n={cfg.num_cond_tokens + steps - 1}")
 for k, (name, pts) in enumerate(names):
