@@ -1218,7 +1218,8 @@ size_t mlp_fused_sync_words() { return 512 + 1024; }
 // the SIMD's matrix pipe each, 40 as a dependent chain: the 32 + 32 of a workgroup's two projections were ~2 us of the launch's 10.7).  The fp32 activation is split
 // a = hi + lo 2^-11 (two f16 numbers, as everywhere in Route M; the fp16 weight is exact), so a w = hi w + 2^-11 lo w with both products exact in the fp32 accumulators:
 // two v_mfma_f32_16x16x32_f16 (~17 cycles each) on separate accumulators, merged by mlpf_merge.  Lane (r, q) holds row r, k = 8 q .. 8 q + 7 of both operands - the
-// same (lane, element) -> k map on either side, which is all a matrix instruction needs.
+// same (lane, element) -> k map on either side, which is all a matrix instruction needs.  Range: hi overflows for |a| >= 65520 -> inf / NaN (loud); the operands here
+// are ln2's output scaled by gamma and the GELU output.
 __device__ __forceinline__ void mlpf_mma_f16(const float4& a0, const float4& a1, const half8_t& w, f32x4& acc_hi, f32x4& acc_lo) {
     half8_t ah, al;
     const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
