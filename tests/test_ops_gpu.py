@@ -533,6 +533,25 @@ def test_mlp_fused_operator(gpu_ctx, M, D, w_f16):
         gpu_ctx.op_mlp_fused(dev(torch.randn(4, 512)), dev(lw[:512]), dev(lb[:512]), dev(w1[:2048, :512]), dev(b1[:2048]), dev(w2[:512, :2048]), dev(b2[:512]))
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 40.0])
+def test_mlp_fused_operator_f16_matrix_pipe_over_input_magnitudes(gpu_ctx, scale):
+    """fp16 weight storage: the launch multiplies on the f16 matrix pipe with the activation split hi + lo 2^-11 (two v_mfma_f32_16x16x32_f16 per 32 k).  The split keeps
+    22 mantissa bits whatever the magnitude (lo is scaled out of the subnormal range), so rows whose LayerNorm gain / bias put them three decades apart - and hidden values
+    from ~0 to a few hundred behind the GELU - must meet the same fp64 bound as the unit-scale case."""
+    M, D = 16, 1024
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(M, D, generator=g)
+    lw, lb = (torch.randn(D, generator=g) * 0.2 + 1) * scale, torch.randn(D, generator=g) * 0.1 * scale   # ln2's output carries the scale
+    w1 = (torch.randn(4 * D, D, generator=g) / math.sqrt(D)).half().float()
+    b1 = torch.randn(4 * D, generator=g) * 0.2 * scale
+    w2 = (torch.randn(D, 4 * D, generator=g) / math.sqrt(4 * D)).half().float()
+    b2 = torch.randn(D, generator=g) * 0.2
+    h = F.layer_norm(x.double(), (D,), lw.double(), lb.double(), 1e-5)
+    ref = F.gelu(h @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+    out = gpu_ctx.op_mlp_fused(dev(x), dev(lw), dev(lb), dev(w1), dev(b1), dev(w2), dev(b2), w_f16=True)
+    assert rel(out.cpu().double(), ref) < 8e-6
+
+
 def test_profiler_state_is_per_context(gpu_ctx):
     """bevgen_profile_begin / _end time the launches of THEIR context only: another context's calls in between are not recorded (and do not disturb the records)."""
     from bevgen_amd.runtime import Context
