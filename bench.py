@@ -508,10 +508,12 @@ def main():
         def one_step(e=None):
             if e: e[0].record()
             # stochastic sampling like the reference's default generate (gumbel + critic noise, top-k 0.9): uniforms drawn inside the sampler kernels
-            ids = ctx.maskgit_generate(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], timesteps=args.timesteps, noise_seed=2025 + 7919 * rank + len(seeds))
+            ids = ctx.maskgit_generate(bt["cond_ids"], bt["intrinsics_inv"], bt["extrinsics_inv"], timesteps=args.timesteps, noise_seed=2025 + 7919 * rank + len(seeds), check=False)
             seeds.append(0)
             if e: e[1].record()
-            px = ctx.vq_decode(ids.reshape(batch * cams, -1), latent_hw=(cfg.cam_latent_h, cfg.cam_latent_w), uint8=True)      # [B*C,3,256,256] uint8
+            px = ctx.vq_decode(ids.reshape(batch * cams, -1), latent_hw=(cfg.cam_latent_h, cfg.cam_latent_w), uint8=True, check=False)      # [B*C,3,256,256] uint8
+            # (check=False: the step stays asynchronous; the device status word - non-finite logits / pixels, f16 range - is read without a sync at the entry of the next
+            # library call and, after the timed region's closing synchronisation, by ctx.synchronize() below: a flagged step fails the bench instead of being timed)
             if e: e[2].record()
             out = gather_scenes(px.reshape(batch, cams, 3, px.shape[-2], px.shape[-1]), dist)
             if e: e[3].record()
@@ -528,6 +530,8 @@ def main():
             one_step(ev[i])
         sync()
         mine = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier)
+        if hasattr(ctx, "synchronize"):
+            ctx.synchronize()                    # raises if any kernel of the K steps flagged its results
         if dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0

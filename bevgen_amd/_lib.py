@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVGEN_LIB_PATH") or os.path.join(_HERE, "csrc", "libbevgen_hip.so")   # override: A/B runs of two builds on one GPU box
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bevgen_hip.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ROUTE_MASKGIT, ROUTE_AR = 0, 1
 PRECISION_FP32, PRECISION_BF16, PRECISION_F16X3 = 0, 1, 2
 KV_F32, KV_F16 = 0, 1
@@ -21,6 +21,8 @@ DECODE_FUSED, DECODE_PER_OP, DECODE_SPLIT, DECODE_AUTO = 0, 1, 2, 3
 VQ_OUT_RAW, VQ_OUT_DENORM, VQ_OUT_U8 = 0, 1, 2
 W_F32, W_F16 = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_U8, DTYPE_F64 = 0, 1, 2, 3
+ERR_NUMERIC = -5
+STATUS_MLP_BARRIER, STATUS_MLP_PLACEMENT, STATUS_NONFINITE_LOGITS, STATUS_F16_RANGE, STATUS_NONFINITE_PIXELS = 1, 2, 4, 8, 16
 
 
 class BevgenError(RuntimeError):
@@ -54,6 +56,8 @@ SIGNATURES = {
     "bevgen_destroy": (None, [_p]),
     "bevgen_last_error": (C.c_char_p, [_p]),
     "bevgen_abi_version": (_i, []),
+    "bevgen_synchronize": (_i, [_p, _p]),
+    "bevgen_status": (_i, [_p, C.POINTER(C.c_uint)]),
     "bevgen_load_tensor": (_i, [_p, C.c_char_p, _p, _i, _i, C.POINTER(C.c_int64)]),
     "bevgen_set_tables": (_i, [_p, _p, _p, _p, _p, _p]),
     "bevgen_finalize": (_i, [_p]),

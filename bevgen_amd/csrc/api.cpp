@@ -1,5 +1,7 @@
 // extern "C" surface of libbevgen_hip (declared in include/bevgen_hip.h): argument validation, exception -> error-code
 // translation.  No torch types cross this boundary: raw pointers, sizes and a hipStream_t.
+#include <memory>
+
 #include "model.h"
 #include "profiler.h"
 
@@ -10,16 +12,19 @@ struct bevgen_ctx : public Ctx {};
 static thread_local std::string g_create_error;
 
 template <class F>
-static int guarded(bevgen_ctx* ctx, F&& f) {
+static int guarded(bevgen_ctx* ctx, F&& f, bool check_first = true) {
     try {
         if (!ctx) return BEVGEN_ERR_INVALID;
         HIP_CHECK(hipSetDevice(ctx->device));
         split_registry_set(ctx->cfg.precision == BEVGEN_PRECISION_F16X3 ? &ctx->split : nullptr);
-        struct CurrentProf {   // this context's profiler receives the launch records of this call (restored on every exit path)
+        struct CurrentProf {   // this context's profiler and status word receive the launch records / flags of this call (restored on every exit path)
             Profiler* old;
-            explicit CurrentProf(Profiler* p) : old(prof_set_current(p)) {}
-            ~CurrentProf() { prof_set_current(old); }
-        } cur(&ctx->prof);
+            unsigned* old_st;
+            CurrentProf(Profiler* p, unsigned* st) : old(prof_set_current(p)), old_st(status_set_current(st)) {}
+            ~CurrentProf() { prof_set_current(old); status_set_current(old_st); }
+        } cur(&ctx->prof, ctx->status_dev);
+        // a flag raised by a kernel of an EARLIER (asynchronous) call: the host-visible word is read without synchronising, the error belongs to that call
+        if (check_first) ctx->check_status("raised by an earlier call on this context");
         f();
         return BEVGEN_OK;
     } catch (const Error& e) {
@@ -56,10 +61,14 @@ int bevgen_create(const bevgen_cfg* cfg, int device, bevgen_ctx** out) {
         BG_REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, "bevgen_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
                    prop.gcnArchName);
         HIP_CHECK(hipSetDevice(device));
-        auto* c = new bevgen_ctx();
+        std::unique_ptr<bevgen_ctx> c(new bevgen_ctx());
         c->cfg = *cfg;
         c->device = device;
-        *out = c;
+        // the device status word: mapped host memory, so that the host reads it without a copy or a synchronisation (common.h BG_ST_*)
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c->status_host), 64, hipHostMallocMapped));
+        *c->status_host = 0;
+        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->status_dev), c->status_host, 0));
+        *out = c.release();
         return BEVGEN_OK;
     } catch (const Error& e) {
         g_create_error = e.what();
@@ -74,10 +83,27 @@ void bevgen_destroy(bevgen_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    if (ctx->status_host && *ctx->status_host)   // nobody asked (no bevgen_synchronize, no later call): the last resort is to say it here
+        fprintf(stderr, "libbevgen_hip: context destroyed with device status word %u pending (BEVGEN_STATUS_* in bevgen_hip.h): results of its last calls were invalid\n",
+                *ctx->status_host);
     delete ctx;
 }
 
 const char* bevgen_last_error(const bevgen_ctx* ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int bevgen_synchronize(bevgen_ctx* ctx, void* stream) {
+    return guarded(ctx, [&] {
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        if (ctx->graph_stream) HIP_CHECK(hipStreamSynchronize(ctx->graph_stream));   // (joined into `stream` by an event at the end of bevgen_ar_sample; belt and braces)
+        ctx->check_status("bevgen_synchronize");
+    }, false);
+}
+
+int bevgen_status(bevgen_ctx* ctx, unsigned* word) {
+    if (!ctx || !word) return BEVGEN_ERR_INVALID;
+    *word = ctx->status_host ? __atomic_load_n(ctx->status_host, __ATOMIC_ACQUIRE) : 0u;
+    return BEVGEN_OK;
+}
 
 int bevgen_load_tensor(bevgen_ctx* ctx, const char* name, const void* h, int dtype, int ndim, const int64_t* shape) {
     return guarded(ctx, [&] { ctx_load_tensor(*ctx, name, h, dtype, ndim, shape); });
@@ -320,14 +346,10 @@ int bevgen_op_mlp_fused(bevgen_ctx* ctx, const float* x, const float* ln_w, cons
         launch_ar_ln_fold(w1u, b1, ln_w, ln_b, cs, ds, 4 * D, D, s);
         HIP_CHECK(hipMemsetAsync(zero, 0, (size_t)M * D * sizeof(float), s));
         HIP_CHECK(hipMemsetAsync(sync, 0, mlp_fused_sync_words() * sizeof(unsigned), s));
-        unsigned *err_h = nullptr, *err_d = nullptr;
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&err_h), 64, hipHostMallocMapped));
-        *err_h = 0;
-        HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&err_d), err_h, 0));
         MlpFusedArgs g;
         g.A = x; g.lda = D; g.ln_w = ln_w; g.ln_cs = cs; g.ln_ds = ds; g.eps = eps;
         g.Wup = reinterpret_cast<const float*>(w1p); g.Wdn = reinterpret_cast<const float*>(w2p); g.w_f16 = w_f16;
-        g.hidden = hidden; g.C = part; g.sync = sync; g.err = err_d; g.M = M; g.D = D;
+        g.hidden = hidden; g.C = part; g.sync = sync; g.err = ctx->status_dev; g.M = M; g.D = D;
         g.trace = ctx->trace ? ctx->trace + 4096 * 8 : nullptr;
         // (twice: the second launch runs on the barrier state the first one left behind - the self-cleaning property the hipGraph replay of the decode step relies on)
         launch_ar_mlp_fused(g, s);
@@ -336,9 +358,7 @@ int bevgen_op_mlp_fused(bevgen_ctx* ctx, const float* x, const float* ln_w, cons
         r.base = zero; r.ld = D; r.partial = part; r.ns = MLP_FUSED_PLANES; r.pstride = (long)M * D; r.pld = D; r.bias = b2;
         launch_rowsrc_materialize(r, out, M, D, nullptr, s);
         HIP_CHECK(hipStreamSynchronize(s));
-        const unsigned e = *err_h;
-        (void)hipHostFree(err_h);
-        BG_REQUIRE(e == 0, "op_mlp_fused: the launch reported error word %u (1 = barrier timeout, 2 = a workgroup off the XCD its index implies)", e);
+        ctx->check_status("op_mlp_fused");
     });
 }
 

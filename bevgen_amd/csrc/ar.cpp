@@ -17,9 +17,11 @@ namespace bevgen {
 
 // Decode steps that contain a launch whose workgroups wait for each other (ar_mlp_fused_kernel: every workgroup of an XCD must be resident at once) must not interleave
 // with another such stream of launches on the same device: two half-resident grids could starve each other until the bounded spin gives up.  One context is one stream
-// of strictly ordered launches; with SEVERAL Route-A contexts alive in the process, their decode calls are chained on the device by one event per device (the second
-// call's launches wait until the first call's have drained) and on the host by a mutex held while a call enqueues.  Nothing happens with a single context.
-std::atomic<int> g_live_ar_contexts{0};
+// of strictly ordered launches; the decode calls of ALL Route-A contexts of the process are chained on the device by one event per device (a call's launches wait until
+// the previous call's have drained) and on the host by a mutex held while a call enqueues: one uncontended lock, one stream wait and one event record per call - taken
+// unconditionally (a "more than one context alive" fast path would race with a context created while another one is decoding).  Another PROCESS on the same GPU is not
+// covered: there the bounded spin times out, the launch poisons itself (later launches return at once), the status word reports it and the context falls back to the
+// two-launch form (Ctx::check_status).
 namespace {
 std::mutex g_spin_mu;
 hipEvent_t g_spin_ev[64] = {};
@@ -28,7 +30,7 @@ struct SpinSerial {
     hipEvent_t ev = nullptr;
     hipStream_t q = nullptr;
     SpinSerial(const Ctx& c, hipStream_t stream) {
-        if (!c.mlpf_sync || g_live_ar_contexts.load(std::memory_order_relaxed) < 2) return;
+        if (!c.mlpf_sync || c.mlpf_disabled) return;
         lk = std::unique_lock<std::mutex>(g_spin_mu);
         hipEvent_t& e = g_spin_ev[c.device >= 0 && c.device < 64 ? c.device : 0];
         if (!e) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -73,7 +75,7 @@ bool split_supported(const Ctx& c, int B) {
 // B = 1 1.116 / 0.919, 2 1.091 / 0.945, 3 1.094 / 1.044, 4 1.094 / 1.072, 6 1.095 / 1.186: the split layer up to four sequences, as before.
 int effective_decode_path(const Ctx& c, int B, int G) {
     if (c.cfg.decode_path != BEVGEN_DECODE_AUTO) return c.cfg.decode_path;
-    if (c.cfg.decode_weight_dtype == BEVGEN_W_F16 && G <= 1 && c.mlpf_sync && mlp_fused_supported(B, c.D, true)) return BEVGEN_DECODE_FUSED;
+    if (c.cfg.decode_weight_dtype == BEVGEN_W_F16 && G <= 1 && c.mlpf_sync && !c.mlpf_disabled && mlp_fused_supported(B, c.D, true)) return BEVGEN_DECODE_FUSED;
     return (B / std::max(G, 1) <= 4 && split_supported(c, B)) ? BEVGEN_DECODE_SPLIT : BEVGEN_DECODE_FUSED;
 }
 
@@ -90,11 +92,11 @@ bool fused_path(const Ctx& c, int B, int G) {
 
 size_t part_floats(const Ctx& c, int B) { return (size_t)std::max(skinny_fused_ksplit(c.D, 4 * c.D), MLP_FUSED_PLANES) * B * c.D; }
 
-// Both MLP projections of a layer in one launch (ar_mlp_fused_kernel): the fused three-launch layer, one chain, at most 16 rows, ln2 folded, a device whose CUs hold the
+// Both MLP projections of a layer in one launch (ar_mlp_fused_kernel): the fused three-launch layer, one chain, at most 64 rows (row chunks of 16), ln2 folded, a device whose CUs hold the
 // whole grid at once.  Otherwise the two skinny launches.
 bool mlp_fused_step(const Ctx& c, int Bc, bool split, int chains) {
     static const int ln2_fold = getenv("BEVGEN_LN2_FOLD") ? atoi(getenv("BEVGEN_LN2_FOLD")) : 1;
-    return !split && chains == 1 && ln2_fold && c.mlpf_sync && skinny_fused_ksplit(c.D, 4 * c.D) > 1 &&
+    return !split && chains == 1 && ln2_fold && c.mlpf_sync && !c.mlpf_disabled && skinny_fused_ksplit(c.D, 4 * c.D) > 1 &&
            mlp_fused_supported(Bc, c.D, c.cfg.decode_weight_dtype == BEVGEN_W_F16);
 }
 
@@ -193,7 +195,6 @@ void sparse_self_attention_op(Ctx& c, const float* q, const float* k, const floa
 // samples_per_layout = S > 1 (BASELINE config 5): consecutive groups of S sequences share their condition (BEV ids and cameras), so the condition
 // prefix is pushed through the stack once per LAYOUT (B / S sequences) and its K/V rows are then replicated into the S cache slots of the group.
 void ar_prefill(Ctx& c, const int64_t* cond, const float* I_inv, const float* E_inv, int B, hipStream_t s, int samples_per_layout) {
-    c.check_mlpf_error();   // (a fused MLP launch of an EARLIER call that reported a timeout: the host-visible word is read without synchronising)
     const auto& g = c.cfg;
     BG_REQUIRE(g.route == BEVGEN_ROUTE_AR, "context was not created for the autoregressive route");
     BG_REQUIRE(B >= 1, "batch must be positive");
@@ -423,7 +424,7 @@ static void decode_chain_launch(Ctx& c, StepWs& w, const int64_t* tok, int r0, i
             mf.ln_w = l.ln2_w; mf.ln_cs = l.mlp0_cs; mf.ln_ds = l.mlp0_ds; mf.eps = 1e-5f;
             mf.Wup = l.mlp0_wp; mf.Wdn = l.mlp2_wp; mf.w_f16 = wf16;
             mf.hidden = m1; mf.C = part;
-            mf.sync = c.mlpf_sync; mf.err = c.mlpf_err_dev;
+            mf.sync = c.mlpf_sync; mf.err = c.status_dev;
             mf.M = Bc; mf.D = D;
             mf.trace = c.trace ? c.trace + 4096 * 8 : nullptr;
             launch_ar_mlp_fused(mf, s);
@@ -535,7 +536,6 @@ void ar_decode_step(Ctx& c, const int64_t* tok, hipStream_t s) {
     auto& st = c.ars;
     BG_REQUIRE(st.B > 0, "bevgen_ar_prefill must be called first");
     BG_REQUIRE(st.step < c.N, "all %d image tokens have already been decoded", c.N);
-    c.check_mlpf_error();
     c.arena.reset();
     StepWs w = step_ws(c, st.B);
     st.pick_embeds = false;   // the caller's tokens: embed them here

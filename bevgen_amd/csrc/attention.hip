@@ -285,7 +285,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attention_kernel(DecodeAttnArg
             void* cache = const_cast<void*>(is_v ? a.vcache : a.kcache);
             const long idx = (cache_row0 + row) * 64 + d;
             if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
-            else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)val;
+            else {
+                const _Float16 hv = (_Float16)val;
+                unsigned bad = 0;
+                guard_half(hv, bad);
+                if (bad) status_raise(a.status, BG_ST_F16_RANGE);
+                reinterpret_cast<_Float16*>(cache)[idx] = hv;
+            }
         }
         __syncthreads();
     }
@@ -410,6 +416,7 @@ size_t decode_attention_ws_bytes(int B, int H, int S) { return (size_t)B * H * S
 void launch_decode_attention_ws(const DecodeAttnArgs& a0, float* ws, int S, hipStream_t s) {
     DecodeAttnArgs a = a0;
     a.vis = vis_fix(a.vis, a.q);
+    a.status = status_current();
     BG_REQUIRE(a.d_n || (a.n > 0 && a.n <= a.Lmax), "decode attention: n=%d out of range (Lmax=%d)", a.n, a.Lmax);
     BG_REQUIRE(a.group <= 1, "decode attention: shared-prefix groups not implemented in this kernel");
     dim3 grid(S, a.H, a.B);

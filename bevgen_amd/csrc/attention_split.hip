@@ -282,6 +282,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     }
     const float inv = 1.f / l_tot;
     if (qvalid) {
+        unsigned bad = 0;
         const long orow = (long)b * a.o_bstride + (long)qrow * a.o_qstride + (long)head * a.o_hstride;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -291,9 +292,10 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
                 float o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (oM[t][4 * g + j] + oC[t][4 * g + j] * kLoI) * inv;
-                if (a.Op) store_planes4(a.Op + ((long)b * a.Nq + qrow) * 2 * (a.H * 64), head * 64 + d, make_float4(o[0], o[1], o[2], o[3]));
+                if (a.Op) store_planes4(a.Op + ((long)b * a.Nq + qrow) * 2 * (a.H * 64), head * 64 + d, make_float4(o[0], o[1], o[2], o[3]), bad);
                 else *reinterpret_cast<float4*>(a.O + orow + d) = make_float4(o[0], o[1], o[2], o[3]);
             }
+        if (bad) status_raise(a.status, BG_ST_F16_RANGE);
     }
 }
 
@@ -355,12 +357,15 @@ __global__ __launch_bounds__(256) void attention_split_combine_kernel(AttnSplitA
     }
     const float inv = 1.f / l;
     o.x *= inv; o.y *= inv; o.z *= inv; o.w *= inv;
-    if (a.Op) store_planes4(a.Op + ((long)b * a.Nq + q) * 2 * (a.H * 64), head * 64 + d, o);
+    unsigned bad = 0;
+    if (a.Op) store_planes4(a.Op + ((long)b * a.Nq + q) * 2 * (a.H * 64), head * 64 + d, o, bad);
     else *reinterpret_cast<float4*>(a.O + (long)b * a.o_bstride + (long)q * a.o_qstride + (long)head * a.o_hstride + d) = o;
+    if (bad) status_raise(a.status, BG_ST_F16_RANGE);
 }
 
 void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
     AttnSplitArgs a = a0;
+    a.status = status_current();
     if (a.ksplit < 1) a.ksplit = 1;
     BG_REQUIRE(a.ksplit == 1 || (a.kws && a.Nk_pad / SKT >= a.ksplit), "attention_split: key split %d needs a workspace and at least one key tile per range", a.ksplit);
     BG_REQUIRE(a.Nk_pad % SKT == 0 && a.Nk_pad > 0, "attention_split: Nk_pad=%d must be a positive multiple of %d", a.Nk_pad, SKT);
@@ -393,42 +398,48 @@ void launch_attention_split(const AttnSplitArgs& a0, hipStream_t s) {
 // fp32 q [B,H,Nq,64], k / v [B,H,Nk_pad,64] -> the kernel's operand images: Q planes with qmul (= score scale x log2 e) folded in, K planes, V^T planes
 __global__ __launch_bounds__(256) void attn_split_operands_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, _Float16* __restrict__ Qh,
                                                                  _Float16* __restrict__ Ql, _Float16* __restrict__ Kh, _Float16* __restrict__ Kl, _Float16* __restrict__ VTh,
-                                                                 _Float16* __restrict__ VTl, long nq, long nk, int Nk_pad, float qmul) {
+                                                                 _Float16* __restrict__ VTl, long nq, long nk, int Nk_pad, float qmul, unsigned* __restrict__ status) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned bad = 0;
     if (i < nq) {
         const float x = q[i] * qmul;
         const _Float16 hi = (_Float16)x;
+        guard_half(hi, bad);
         Qh[i] = hi; Ql[i] = (_Float16)((x - (float)hi) * kLo);
     }
     if (i < nk) {
         const float x = k[i];
         const _Float16 hi = (_Float16)x;
+        guard_half(hi, bad);
         Kh[i] = hi; Kl[i] = (_Float16)((x - (float)hi) * kLo);
         const long bh = i / ((long)Nk_pad * 64), r = i % ((long)Nk_pad * 64);
         const int j = (int)(r / 64), d = (int)(r % 64);
         const float y = v[i];
         const _Float16 vh = (_Float16)y;
+        guard_half(vh, bad);
         const long dst = bh * (long)Nk_pad * 64 + (long)d * Nk_pad + j;
         VTh[dst] = vh; VTl[dst] = (_Float16)((y - (float)vh) * kLo);
     }
+    if (bad) status_raise(status, BG_ST_F16_RANGE);
 }
 void launch_attn_split_operands(const float* q, const float* k, const float* v, void* Qh, void* Ql, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nq, int Nk_pad,
                                 float qmul, hipStream_t s) {
     const long nq = (long)B * H * Nq * 64, nk = (long)B * H * Nk_pad * 64;
     hipLaunchKernelGGL(attn_split_operands_kernel, dim3((unsigned)cdiv(std::max(nq, nk), 256L)), dim3(256), 0, s, q, k, v, reinterpret_cast<_Float16*>(Qh), reinterpret_cast<_Float16*>(Ql),
-                       reinterpret_cast<_Float16*>(Kh), reinterpret_cast<_Float16*>(Kl), reinterpret_cast<_Float16*>(VTh), reinterpret_cast<_Float16*>(VTl), nq, nk, Nk_pad, qmul);
+                       reinterpret_cast<_Float16*>(Kh), reinterpret_cast<_Float16*>(Kl), reinterpret_cast<_Float16*>(VTh), reinterpret_cast<_Float16*>(VTl), nq, nk, Nk_pad, qmul, status_current());
     LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------------------------ q / kv preparation with split outputs
 // (muse_maskgit_pytorch.py:132-146: x8, null-kv concat, l2norm eps 1e-12, q_scale / k_scale), then hi/lo split; V is written transposed.
-__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo, unsigned& bad) {
     hi = (_Float16)v;
     lo = (_Float16)((v - (float)hi) * kLo);
+    guard_half(hi, bad);
 }
 
 __global__ __launch_bounds__(256) void muse_q_prep_split_kernel(const float* __restrict__ qraw, const float* __restrict__ q_scale, _Float16* __restrict__ Qh,
-                                                                _Float16* __restrict__ Ql, int H, int Nq, long total, float post) {
+                                                                _Float16* __restrict__ Ql, int H, int Nq, long total, float post, unsigned* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= total) return;
@@ -440,16 +451,18 @@ __global__ __launch_bounds__(256) void muse_q_prep_split_kernel(const float* __r
     const float nrm = fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);
     const float q = ((v / nrm) * q_scale[lane]) * post;
     _Float16 hi, lo;
-    split1(q, hi, lo);
+    unsigned bad = 0;
+    split1(q, hi, lo, bad);
     const long dst = ((b * H + h) * Nq + n) * 64 + lane;
     Qh[dst] = hi;
     Ql[dst] = lo;
+    if (bad) status_raise(status, BG_ST_F16_RANGE);
 }
 
 void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, float post, hipStream_t s) {
     const long total = (long)B * Nq * H;
     hipLaunchKernelGGL(muse_q_prep_split_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, s, qraw, q_scale, reinterpret_cast<_Float16*>(Qh),
-                       reinterpret_cast<_Float16*>(Ql), H, Nq, total, post);
+                       reinterpret_cast<_Float16*>(Ql), H, Nq, total, post, status_current());
     LAUNCH_CHECK();
 }
 
@@ -457,8 +470,9 @@ void launch_muse_q_prep_split(const float* qraw, const float* q_scale, void* Qh,
 // [64 dims][keys] image is written with contiguous 128-byte segments
 __global__ __launch_bounds__(256) void muse_kv_prep_split_kernel(const float* __restrict__ kvraw, const float* __restrict__ null_kv, const float* __restrict__ k_scale,
                                                                  _Float16* __restrict__ Kh, _Float16* __restrict__ Kl, _Float16* __restrict__ VTh,
-                                                                 _Float16* __restrict__ VTl, int H, int Nk, int Nk_pad) {
+                                                                 _Float16* __restrict__ VTl, int H, int Nk, int Nk_pad, unsigned* __restrict__ status) {
     __shared__ float vt[64][65];
+    unsigned bad = 0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j0 = blockIdx.x * 64, h = blockIdx.y;
     const long b = blockIdx.z;
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(256) void muse_kv_prep_split_kernel(const float* __
             const float nrm = fmaxf(sqrtf(wave_sum(kv * kv)), 1e-12f);
             const float k = (kv / nrm) * k_scale[lane];
             _Float16 hi, lo;
-            split1(k, hi, lo);
+            split1(k, hi, lo, bad);
             Kh[kbase + (long)j * 64 + lane] = hi;
             Kl[kbase + (long)j * 64 + lane] = lo;
         }
@@ -489,29 +503,33 @@ __global__ __launch_bounds__(256) void muse_kv_prep_split_kernel(const float* __
         const int j = j0 + lane;
         if (j < Nk_pad) {
             _Float16 hi, lo;
-            split1(vt[lane][d], hi, lo);
+            split1(vt[lane][d], hi, lo, bad);
             VTh[kbase + (long)d * Nk_pad + j] = hi;
             VTl[kbase + (long)d * Nk_pad + j] = lo;
         }
     }
+    if (bad) status_raise(status, BG_ST_F16_RANGE);
 }
 
 // prepared null key / value of one attention module for the fused to_kv epilogue (EPI_MUSE_KV): out = [k_hi | k_lo | v_hi | v_lo][H][64] halves
-__global__ __launch_bounds__(64) void muse_null_kv_prep_kernel(const float* __restrict__ null_kv, const float* __restrict__ k_scale, _Float16* __restrict__ out, int H) {
+__global__ __launch_bounds__(64) void muse_null_kv_prep_kernel(const float* __restrict__ null_kv, const float* __restrict__ k_scale, _Float16* __restrict__ out, int H,
+                                                               unsigned* __restrict__ status) {
     const int h = blockIdx.x, lane = threadIdx.x;
     const float kv = null_kv[h * 64 + lane], vv = null_kv[(long)H * 64 + h * 64 + lane];
     const float nrm = fmaxf(sqrtf(wave_sum(kv * kv)), 1e-12f);
     const float k = (kv / nrm) * k_scale[lane];
     _Float16 hi, lo;
-    split1(k, hi, lo);
+    unsigned bad = 0;
+    split1(k, hi, lo, bad);
     out[h * 64 + lane] = hi;
     out[H * 64 + h * 64 + lane] = lo;
-    split1(vv, hi, lo);
+    split1(vv, hi, lo, bad);
     out[2 * H * 64 + h * 64 + lane] = hi;
     out[3 * H * 64 + h * 64 + lane] = lo;
+    if (bad) status_raise(status, BG_ST_F16_RANGE);
 }
 void launch_muse_null_kv_prep(const float* null_kv, const float* k_scale, void* out, int H, hipStream_t s) {
-    hipLaunchKernelGGL(muse_null_kv_prep_kernel, dim3(H), dim3(64), 0, s, null_kv, k_scale, reinterpret_cast<_Float16*>(out), H);
+    hipLaunchKernelGGL(muse_null_kv_prep_kernel, dim3(H), dim3(64), 0, s, null_kv, k_scale, reinterpret_cast<_Float16*>(out), H, status_current());
     LAUNCH_CHECK();
 }
 
@@ -519,7 +537,7 @@ void launch_muse_kv_prep_split(const float* kvraw, const float* null_kv, const f
                                int Nk_pad, hipStream_t s) {
     dim3 grid(cdiv(Nk_pad, 64), H, B);
     hipLaunchKernelGGL(muse_kv_prep_split_kernel, grid, dim3(256), 0, s, kvraw, null_kv, k_scale, reinterpret_cast<_Float16*>(Kh), reinterpret_cast<_Float16*>(Kl),
-                       reinterpret_cast<_Float16*>(VTh), reinterpret_cast<_Float16*>(VTl), H, Nk, Nk_pad);
+                       reinterpret_cast<_Float16*>(VTh), reinterpret_cast<_Float16*>(VTl), H, Nk, Nk_pad, status_current());
     LAUNCH_CHECK();
 }
 

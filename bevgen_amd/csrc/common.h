@@ -79,24 +79,58 @@ __device__ __forceinline__ void xcd_tile_banded(int gx, int gy, int R, int& tx, 
     ty = band * R + (within - tx * h);
 }
 
+// -------- device status word: what the reference asserts on the host every step (gpt:383,388 finite inputs / logits, ar_lm:202 finite logits) is flagged on the DEVICE
+// here - no host synchronisation on the sampling path - into one host-visible word per context (mapped host memory, Ctx::status_host), read by the host wherever
+// it synchronises anyway (bevgen_synchronize, the entry of every C-ABI call, bevgen_destroy).  A raised bit costs one system-scope atomic; the normal case costs the compare.
+enum : unsigned {
+    BG_ST_MLP_BARRIER = 1u,      // ar_mlp_fused_kernel: an XCD-local barrier timed out (the launch did not have the GPU to itself)
+    BG_ST_MLP_PLACEMENT = 2u,    // ar_mlp_fused_kernel: a workgroup was not placed on the XCD its index implies
+    BG_ST_NONFINITE_LOGITS = 4u, // a sampler saw a NaN / inf logit or critic score (the reference: assert (~logits.isfinite()).sum() == 0)
+    BG_ST_F16_RANGE = 8u,        // a value written as an f16 operand (hi/lo planes of precision = f16x3, fp16 KV cache, fp16 decode activations) was NaN or |v| >= 65520:
+                                 // the f16 image is inf / NaN where the reference's bf16 / fp32 arithmetic has an 8-bit exponent
+    BG_ST_NONFINITE_PIXELS = 16u // the VQGAN decoder produced a NaN / inf pixel
+};
+// device address of the status word of the context whose C-ABI call is executing on this host thread (null outside a call): the launchers of the flagged kernels read it
+unsigned* status_current();
+unsigned* status_set_current(unsigned* dev);   // returns the previous one
+__device__ __forceinline__ void status_raise(unsigned* st, unsigned bits) {
+    if (st) __hip_atomic_fetch_or(st, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// both halves of a packed f16 pair: non-zero where the exponent field is all ones (inf / NaN) - three integer operations per pair
+__device__ __forceinline__ unsigned f16x2_nonfinite(unsigned packed) { return ((packed & 0x7C007C00u) + 0x04000400u) & 0x80008000u; }
+__device__ __forceinline__ bool nonfinite(float v) { return (__float_as_uint(v) & 0x7F800000u) == 0x7F800000u; }
+
 // -------- split precision: v = hi + lo * 2^-11 with hi, lo in f16 (gemm_split.hip); interleaved plane layout [row][k/32][hi 32 | lo 32]
 __device__ __forceinline__ _Float16 split_hi(float v) { return (_Float16)v; }
 __device__ __forceinline__ _Float16 split_lo(float v, _Float16 hi) { return (_Float16)((v - (float)hi) * 2048.f); }
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half8_guard_t __attribute__((ext_vector_type(8)));
+// range guard of the plane writers: `bad` collects (per thread) whether any hi half written so far is inf / NaN; the kernel raises BG_ST_F16_RANGE once at its end
+__device__ __forceinline__ void guard_half4(half4_t h, unsigned& bad) {
+    const uint2 w = __builtin_bit_cast(uint2, h);
+    bad |= f16x2_nonfinite(w.x) | f16x2_nonfinite(w.y);
+}
+__device__ __forceinline__ void guard_half8(half8_guard_t h, unsigned& bad) {
+    const uint4 w = __builtin_bit_cast(uint4, h);
+    bad |= f16x2_nonfinite(w.x) | f16x2_nonfinite(w.y) | f16x2_nonfinite(w.z) | f16x2_nonfinite(w.w);
+}
+__device__ __forceinline__ void guard_half(_Float16 h, unsigned& bad) { bad |= ((unsigned)__builtin_bit_cast(unsigned short, h) & 0x7C00u) == 0x7C00u ? 1u : 0u; }
 // store 4 (2) consecutive elements starting at column `col` (a multiple of 4 (2)) of one plane row
-__device__ __forceinline__ void store_planes4(_Float16* row, int col, float4 v) {
+__device__ __forceinline__ void store_planes4(_Float16* row, int col, float4 v, unsigned& bad) {
     half4_t h, l;
     h[0] = split_hi(v.x); h[1] = split_hi(v.y); h[2] = split_hi(v.z); h[3] = split_hi(v.w);
     l[0] = split_lo(v.x, h[0]); l[1] = split_lo(v.y, h[1]); l[2] = split_lo(v.z, h[2]); l[3] = split_lo(v.w, h[3]);
+    guard_half4(h, bad);
     _Float16* p = row + (col >> 5) * 64 + (col & 31);
     *reinterpret_cast<half4_t*>(p) = h;
     *reinterpret_cast<half4_t*>(p + 32) = l;
 }
-__device__ __forceinline__ void store_planes2(_Float16* row, int col, float2 v) {
+__device__ __forceinline__ void store_planes2(_Float16* row, int col, float2 v, unsigned& bad) {
     half2_t h, l;
     h[0] = split_hi(v.x); h[1] = split_hi(v.y);
     l[0] = split_lo(v.x, h[0]); l[1] = split_lo(v.y, h[1]);
+    bad |= f16x2_nonfinite(__builtin_bit_cast(unsigned, h));
     _Float16* p = row + (col >> 5) * 64 + (col & 31);
     *reinterpret_cast<half2_t*>(p) = h;
     *reinterpret_cast<half2_t*>(p + 32) = l;

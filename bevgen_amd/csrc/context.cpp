@@ -72,16 +72,31 @@ Ctx::~Ctx() {
     for (void* p : owned) (void)hipFree(p);
     arena.release();
     persist.release();
-    if (mlpf_err_host) { (void)hipHostFree(mlpf_err_host); g_live_ar_contexts.fetch_sub(1, std::memory_order_relaxed); }
+    if (status_host) (void)hipHostFree(status_host);
 }
 
-void Ctx::check_mlpf_error() {
-    if (!mlpf_err_host || !*mlpf_err_host) return;
-    const unsigned e = *mlpf_err_host;
-    *mlpf_err_host = 0;
-    fail(BEVGEN_ERR_INTERNAL, "the fused MLP launch of the decode step failed (error word %u:%s%s): the tokens of the affected call are invalid.  BEVGEN_MLP_FUSE=0 selects "
-         "the two-launch form without an in-kernel exchange", e, (e & 1u) ? " an XCD-local barrier timed out - the launch did not have the GPU to itself;" : "",
-         (e & 2u) ? " a workgroup was not placed on the XCD its index implies" : "");
+// The host side of the device status word (common.h).  Called where the host is synchronised anyway (bevgen_synchronize, bevgen_finalize) and - without synchronising - at the
+// entry of every C-ABI call, so that a flag raised by an earlier asynchronous call surfaces at the next one at the latest.  The word is cleared: one report per event.
+void Ctx::check_status(const char* when) {
+    if (!status_host) return;
+    const unsigned e = __atomic_load_n(status_host, __ATOMIC_ACQUIRE);
+    if (!e) return;
+    __atomic_store_n(status_host, 0u, __ATOMIC_RELEASE);
+    std::string m = std::string("device status word ") + std::to_string(e) + " (" + when + "): the results of the affected call are INVALID.";
+    if (e & BG_ST_NONFINITE_LOGITS)
+        m += "  A sampler read a NaN / inf logit or critic score (the reference asserts finite logits every step: mingpt_sparse.py:383,388, cond_transformer_multi_view.py:202).";
+    if (e & BG_ST_F16_RANGE)
+        m += "  A value written as an f16 operand (hi / lo planes of precision='f16x3', fp16 KV cache, fp16 decode activations) was NaN or had |v| >= 65520: the f16 split has a "
+             "5-bit exponent where the reference's bf16 / fp32 arithmetic has 8.  Run this checkpoint with precision='fp32' (and kv_cache='f32').";
+    if (e & BG_ST_NONFINITE_PIXELS) m += "  The VQGAN decoder produced a NaN / inf pixel.";
+    if (e & (BG_ST_MLP_BARRIER | BG_ST_MLP_PLACEMENT)) {
+        m += std::string("  The fused MLP launch of the decode step failed:") + ((e & BG_ST_MLP_BARRIER) ? " an XCD-local barrier timed out - the launch did not have the GPU to itself;" : "") +
+             ((e & BG_ST_MLP_PLACEMENT) ? " a workgroup was not placed on the XCD its index implies;" : "") +
+             " this context now runs the two-launch form without an in-kernel exchange - repeat the call ($BEVGEN_MLP_FUSE=0 selects that form from the start).";
+        mlpf_disabled = true;
+        if (graph_exec) { retire_graph(graph_exec, graph); graph_exec = nullptr; graph = nullptr; }   // the captured step contains the fused launch
+    }
+    fail((e & (BG_ST_NONFINITE_LOGITS | BG_ST_F16_RANGE | BG_ST_NONFINITE_PIXELS)) ? BEVGEN_ERR_NUMERIC : BEVGEN_ERR_INTERNAL, "%s", m.c_str());
 }
 const DevTensor* Ctx::find(const std::string& name) const {
     auto it = params.find(name);
@@ -317,12 +332,6 @@ static void finalize_ar(Ctx& c) {
         HIP_CHECK(hipMemset(c.mlpf_sync, 0, mlp_fused_sync_words() * sizeof(unsigned)));
         (void)mlp_fused_supported(1, D, wf16);   // (runs the device's one-time placement probe here, never inside a stream capture)
 
-        if (!c.mlpf_err_host) {
-            HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&c.mlpf_err_host), 64, hipHostMallocMapped));
-            *c.mlpf_err_host = 0;
-            HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&c.mlpf_err_dev), c.mlpf_err_host, 0));
-            g_live_ar_contexts.fetch_add(1, std::memory_order_relaxed);
-        }
     }
     if (fused_like) {
         c.head_wp = reinterpret_cast<float*>(c.own(skinny_packed_floats(g.vocab_size, D) * (wf16 ? sizeof(_Float16) : sizeof(float))));
@@ -461,6 +470,7 @@ void ctx_finalize(Ctx& c) {
     }
     if (g.vq_ch > 0) vq_finalize(c);
     HIP_CHECK(hipDeviceSynchronize());
+    c.check_status("bevgen_finalize: a weight matrix");   // (a weight outside the f16 range of the split planes / the fp16 decode images)
     c.finalized = true;
 }
 

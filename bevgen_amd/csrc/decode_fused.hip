@@ -313,7 +313,13 @@ __device__ __forceinline__ void af_append_attend_store(const ArAttnFusedArgs& a,
         void* cache = is_v ? a.vcache : a.kcache;
         const long idx = ((((long)(b0 + g)) * a.H + head) * a.Lmax + row) * 64 + d;
         if (DT == 0) reinterpret_cast<float*>(cache)[idx] = val;
-        else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)val;
+        else {
+            const _Float16 hv = (_Float16)val;
+            unsigned bad = 0;
+            guard_half(hv, bad);   // a key / value outside the fp16 range of the cache (or NaN)
+            if (bad) status_raise(a.status, BG_ST_F16_RANGE);
+            reinterpret_cast<_Float16*>(cache)[idx] = hv;
+        }
     }
     const int n_old = n - 1;   // keys the walk covers
 
@@ -857,6 +863,7 @@ void launch_ar_attn_fused(const ArAttnFusedArgs& a0, hipStream_t s) {
     if (pre) { a.x = RowSrc{}; a.x.base = a.qkv; a.x.ld = 3 * a.D; }
     a.x = rowsrc_fix(a.x);
     a.has_bias = a.bias != nullptr;
+    a.status = status_current();
     a.vis = vis_fix(a.vis, a.x.base);
     if (!a.bias) { a.bias = a.x.base; a.ldbias = 0; }
     BG_REQUIRE(a.G == 1 || a.prefix % 16 == 0, "fused decode attention: a shared prefix must be a multiple of 16 keys (prefix=%d)", a.prefix);
@@ -1212,19 +1219,25 @@ __global__ __launch_bounds__(SF_WAVES * 64) void skinny_fused_kernel(SkinnyFused
 //
 // The barrier word is a monotonic arrival counter (one per XCD at sync[64 x], a 256-byte slot each): nothing has to be reset between launches, so the launch replays inside
 // a hipGraph; sync[512 + i] records the XCD workgroup i saw.
+// After a timeout the launch is POISONED (sync[MLPF_POISON] = 1): the decode steps already enqueued behind it (up to 2100 x 24 launches of a replayed graph) return at once
+// instead of spinning 200 ms each; their output is garbage, which the status word has already said.  The host reads the word at its next synchronisation point
+// (bevgen_synchronize / the next call), reports the call as failed and takes this context to the two-launch form (Ctx::check_status).
+constexpr int MLPF_POISON = 1024;
 size_t mlp_fused_sync_words() { return 512 + 1024; }
 
 // fp16 weight storage: the product of 8 consecutive k of a row with the weight fragment on the f16 matrix pipe instead of eight v_mfma_f32_16x16x4_f32 (32 cycles of
 // the SIMD's matrix pipe each, 40 as a dependent chain: the 32 + 32 of a workgroup's two projections were ~2 us of the launch's 10.7).  The fp32 activation is split
 // a = hi + lo 2^-11 (two f16 numbers, as everywhere in Route M; the fp16 weight is exact), so a w = hi w + 2^-11 lo w with both products exact in the fp32 accumulators:
 // two v_mfma_f32_16x16x32_f16 (~17 cycles each) on separate accumulators, merged by mlpf_merge.  Lane (r, q) holds row r, k = 8 q .. 8 q + 7 of both operands - the
-// same (lane, element) -> k map on either side, which is all a matrix instruction needs.  Range: hi overflows for |a| >= 65520 -> inf / NaN (loud); the operands here
-// are ln2's output scaled by gamma and the GELU output.
-__device__ __forceinline__ void mlpf_mma_f16(const float4& a0, const float4& a1, const half8_t& w, f32x4& acc_hi, f32x4& acc_lo) {
+// same (lane, element) -> k map on either side, which is all a matrix instruction needs.  Range: hi overflows for |a| >= 65520 -> inf / NaN, flagged (BG_ST_F16_RANGE).
+// The phase-1 operands are the RAW residual-stream rows times gamma (the LayerNorm is folded in after the product: mean / rstd enter in the epilogue), so what has to stay
+// below 65520 is |x gamma| - not the normalised value; phase 2's are the GELU outputs.
+__device__ __forceinline__ void mlpf_mma_f16(const float4& a0, const float4& a1, const half8_t& w, f32x4& acc_hi, f32x4& acc_lo, unsigned& bad) {
     half8_t ah, al;
     const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ah[e] = split_hi(av[e]); al[e] = split_lo(av[e], ah[e]); }
+    guard_half8(ah, bad);
     acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, w, acc_hi, 0, 0, 0);
     acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, w, acc_lo, 0, 0, 0);
 }
@@ -1252,6 +1265,8 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     const int slice = K2 >> 3, kper2 = slice / SF_WAVES;                                 // phase 2: this XCD's K slice of the down-projection (512), per wave (64)
 #define MF_TRACE(i) do { if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     MF_TRACE(0);
+    if (__hip_atomic_load(g.sync + MLPF_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (uniform: an earlier launch on this buffer timed out)
+    unsigned bad = 0;   // an activation outside the f16 operand range (WT = 1)
     unsigned* cnt = g.sync + 64 * xcd;   // monotonic arrival counter of this XCD's workgroups (never reset: per_xcd arrivals per launch, compared modulo 2^32)
     // ---- requests, in the order the results are needed: rows, gamma, row constants, up weights, down weights
     const int n_mc = (g.M + 15) >> 4;   // row chunks of 16 (M <= 64): the weight slices stay in registers across them
@@ -1345,7 +1360,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
         f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (32 * u < kper) mlpf_mma_f16(aop[2 * u], aop[2 * u + 1], wh[u], acc, acc_lo);
+            if (32 * u < kper) mlpf_mma_f16(aop[2 * u], aop[2 * u + 1], wh[u], acc, acc_lo, bad);
         acc = mlpf_merge(acc, acc_lo);
     } else {
 #pragma unroll
@@ -1403,8 +1418,17 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     }
     __syncthreads();
     MF_TRACE(3);
-    if (tid < per_xcd && g.sync[512 + 8 * tid + xcd] != my_xcc) atomicOr(g.err, 2u);   // a peer that is NOT on this XCD: its stores are not in this L2 (placement assumption broken)
-    if (!flag_s) { if (tid == 0) atomicOr(g.err, 1u); }
+    if (tid < per_xcd && g.sync[512 + 8 * tid + xcd] != my_xcc) status_raise(g.err, BG_ST_MLP_PLACEMENT);   // a peer that is NOT on this XCD: its stores are not in this L2 (placement assumption broken)
+    if (!flag_s) {
+        if (tid == 0) {
+            status_raise(g.err, BG_ST_MLP_BARRIER);
+            __hip_atomic_store(g.sync + MLPF_POISON, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // acquire side of the exchange: the peers' hidden columns sit in this XCD's L2 (acknowledged stores, counted arrivals); this CU's vector L1 may still hold lines of
+    // g.hidden from THIS workgroup's own phase-1 stores - it wrote 64 bytes of each 128-byte line it reads back below, the neighbouring tile owns the other half - so
+    // the L1 is invalidated before the slice is read (one buffer_inv per wave, no L2 traffic).
+    asm volatile("buffer_inv sc1" ::: "memory");
     // ---- phase 2: down-projection of this XCD's hidden slice, 2 x 16 output columns per workgroup, into partial plane `xcd`
     const int nch2 = slice >> 2;   // 128 chunks of 4
     for (int mc = 0; mc < n_mc; ++mc) {
@@ -1429,6 +1453,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) { ah[e] = split_hi(av[e]); al[e] = split_lo(av[e], ah[e]); }
+            guard_half8(ah, bad);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, dh[2 * t + u], acc2[t], 0, 0, 0);
@@ -1467,6 +1492,7 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     }
     if (mc + 1 < n_mc) __syncthreads();   // As / red are rewritten by the next row chunk
     }
+    if (WT && bad) status_raise(g.err, BG_ST_F16_RANGE);
     MF_TRACE(5);
 #undef MF_TRACE
 }
@@ -1540,7 +1566,7 @@ __global__ __launch_bounds__(256) void pack_skinny_weight_kernel(const float* __
     reinterpret_cast<float4*>(Wp)[i] = v;
 }
 // fp16 image: [N/16 column tiles][K/32 k-chunks][64 lanes][8 halves]; lane l = r + 16 q holds W[16 tile + r][32 chunk + 8 q .. + 7] rounded to fp16
-__global__ __launch_bounds__(256) void pack_skinny_weight_f16_kernel(const float* __restrict__ W, _Float16* __restrict__ Wp, int N, int K) {
+__global__ __launch_bounds__(256) void pack_skinny_weight_f16_kernel(const float* __restrict__ W, _Float16* __restrict__ Wp, int N, int K, unsigned* __restrict__ status) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-half group of the packed image
     const long total = (long)((N + 15) / 16) * (K >> 5) * 64;
     if (i >= total) return;
@@ -1552,12 +1578,15 @@ __global__ __launch_bounds__(256) void pack_skinny_weight_f16_kernel(const float
     half8_t v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = n < N ? (_Float16)W[(long)n * K + k + e] : (_Float16)0.f;
+    unsigned bad = 0;
+    guard_half8(v, bad);
+    if (bad) status_raise(status, BG_ST_F16_RANGE);
     reinterpret_cast<half8_t*>(Wp)[i] = v;
 }
 void launch_pack_skinny_weight_f16(const float* W, void* Wp, int N, int K, hipStream_t s) {
     BG_REQUIRE(K % 32 == 0, "pack_skinny_weight_f16: K=%d must be a multiple of 32", K);
     const long total = (long)cdiv(N, 16) * (K >> 5) * 64;
-    hipLaunchKernelGGL(pack_skinny_weight_f16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, W, reinterpret_cast<_Float16*>(Wp), N, K);
+    hipLaunchKernelGGL(pack_skinny_weight_f16_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, W, reinterpret_cast<_Float16*>(Wp), N, K, status_current());
     LAUNCH_CHECK();
 }
 size_t skinny_packed_floats(int N, int K) { return (size_t)cdiv(N, 16) * 16 * K; }

@@ -163,13 +163,17 @@ void launch_muse_kv_prep(const float* kvraw, const float* null_kv, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------- Route A q/k/v scatter into the KV cache
-__device__ __forceinline__ void cache_store(void* cache, int kv_dtype, long idx, float v) {
+__device__ __forceinline__ void cache_store(void* cache, int kv_dtype, long idx, float v, unsigned& bad) {
     if (kv_dtype == 0) reinterpret_cast<float*>(cache)[idx] = v;
-    else reinterpret_cast<_Float16*>(cache)[idx] = (_Float16)v;   // fp16 storage (round to nearest even)
+    else {
+        const _Float16 h = (_Float16)v;   // fp16 storage (round to nearest even)
+        guard_half(h, bad);               // (a key / value outside the fp16 range: BG_ST_F16_RANGE)
+        reinterpret_cast<_Float16*>(cache)[idx] = h;
+    }
 }
 
 __global__ __launch_bounds__(256) void ar_qkv_scatter_kernel(const float* __restrict__ qkv, float* __restrict__ Q, void* kcache, void* vcache, int kv_dtype,
-                                                             int H, int n, int pos0, const int* __restrict__ d_pos, int Lmax, long total) {
+                                                             int H, int n, int pos0, const int* __restrict__ d_pos, int Lmax, long total, unsigned* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b*n + i)*H + h
     if (w >= total) return;
@@ -181,19 +185,21 @@ __global__ __launch_bounds__(256) void ar_qkv_scatter_kernel(const float* __rest
     const int pos = (d_pos ? *d_pos : 0) + pos0 + i;
     if (Q) Q[((b * H + h) * n + i) * 64 + lane] = src[0];
     const long dst = ((b * H + h) * Lmax + pos) * 64 + lane;
-    cache_store(kcache, kv_dtype, dst, src[H * 64]);
-    cache_store(vcache, kv_dtype, dst, src[2 * H * 64]);
+    unsigned bad = 0;
+    cache_store(kcache, kv_dtype, dst, src[H * 64], bad);
+    cache_store(vcache, kv_dtype, dst, src[2 * H * 64], bad);
+    if (bad) status_raise(status, BG_ST_F16_RANGE);
 }
 
 void launch_ar_qkv_scatter(const float* qkv, float* Q, void* kcache, void* vcache, int kv_dtype, int B, int H, int n, int pos0, int Lmax, hipStream_t s) {
     const long total = (long)B * n * H;
-    hipLaunchKernelGGL(ar_qkv_scatter_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, s, qkv, Q, kcache, vcache, kv_dtype, H, n, pos0, (const int*)nullptr, Lmax, total);
+    hipLaunchKernelGGL(ar_qkv_scatter_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, s, qkv, Q, kcache, vcache, kv_dtype, H, n, pos0, (const int*)nullptr, Lmax, total, status_current());
     LAUNCH_CHECK();
 }
 
 void launch_ar_kv_append(const float* qkv, void* kcache, void* vcache, int kv_dtype, int B, int H, int pos0, const int* d_pos, int Lmax, hipStream_t s) {
     const long total = (long)B * H;
-    hipLaunchKernelGGL(ar_qkv_scatter_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, s, qkv, (float*)nullptr, kcache, vcache, kv_dtype, H, 1, pos0, d_pos, Lmax, total);
+    hipLaunchKernelGGL(ar_qkv_scatter_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, s, qkv, (float*)nullptr, kcache, vcache, kv_dtype, H, 1, pos0, d_pos, Lmax, total, status_current());
     LAUNCH_CHECK();
 }
 

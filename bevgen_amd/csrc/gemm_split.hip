@@ -89,13 +89,14 @@ __device__ __forceinline__ void load_b(const GemmArgs& g, int n0, int k0, int ti
     }
 }
 
-__device__ __forceinline__ void store_a(_Float16* __restrict__ Shi, _Float16* __restrict__ Slo, int tid, const AFrag& r) {
+__device__ __forceinline__ void store_a(_Float16* __restrict__ Shi, _Float16* __restrict__ Slo, int tid, const AFrag& r, unsigned& bad) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int e = tid + 256 * i;
         const int row = e >> 2, c8 = e & 3;
         half8 hi, lo;
         split8(r.v[i][0], r.v[i][1], hi, lo);
+        guard_half8(hi, bad);   // an activation outside the f16 operand range (BG_ST_F16_RANGE, raised once at the end of the kernel)
         *reinterpret_cast<half8*>(Shi + row * SLD + c8 * 8) = hi;
         *reinterpret_cast<half8*>(Slo + row * SLD + c8 * 8) = lo;
     }
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs g) {
     BFrag rb;
     load_a<MODE>(g, A, m0, 0, tid, ra, rowinfo);
     load_b(g, n0, 0, tid, rb);
-    store_a(stage0, stage0 + PLANE, tid, ra);
+    unsigned bad = 0;
+    store_a(stage0, stage0 + PLANE, tid, ra, bad);
     store_b(stage0 + 2 * PLANE, stage0 + 3 * PLANE, tid, rb);
     __syncthreads();
 
@@ -198,13 +200,14 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs g) {
         }
         if (more) {
             _Float16* nx = cur ? stage0 : stage1;
-            store_a(nx, nx + PLANE, tid, ra);
+            store_a(nx, nx + PLANE, tid, ra, bad);
             store_b(nx + 2 * PLANE, nx + 3 * PLANE, tid, rb);
         }
         __syncthreads();
         cur ^= 1;
     }
 
+    if (bad) status_raise(g.status, BG_ST_F16_RANGE);
     float* C = g.C + (long)bz * g.strideC;
     const float* R = g.R ? g.R + (long)bz * g.strideR : nullptr;
 #pragma unroll
@@ -236,6 +239,7 @@ void launch_gemm_split(const GemmArgs& g_in, hipStream_t stream) {
         if (g.conv_win == 0) g.conv_win = g.conv_up ? g.conv_w / 2 : g.conv_w;
     }
     BG_REQUIRE(g.B_hi && g.B_lo, "gemm_split: the B operand has not been split");
+    g.status = status_current();
     BG_REQUIRE(g.K % SBK == 0 && g.lda % 4 == 0 && g.ldb % 8 == 0, "gemm_split: K %% 32, lda %% 4, ldb %% 8 required (K=%d lda=%d ldb=%d)", g.K, g.lda, g.ldb);
     BG_REQUIRE(g.batch == 1 || g.strideB == 0, "gemm_split: batched B operands are not split");
     if (g.mode == MODE_CONV3) BG_REQUIRE(g.conv_cin % SBK == 0 && g.K == 9 * g.conv_cin, "conv3x3: Cin=%d must be a multiple of 32", g.conv_cin);
@@ -260,19 +264,22 @@ void launch_gemm_split(const GemmArgs& g_in, hipStream_t stream) {
 //     planes[row][k/32][0][k%32] = hi,  planes[row][k/32][1][k%32] = lo          (2 halves per element, 128 bytes per (row, 32-k block))
 // so that the 32 hi and 32 lo values of one k-block share one 128-byte line: the LDS-DMA GEMM moves whole lines (a 64-byte half-line
 // request still costs a full line of L2->L1 bandwidth, measured) and a row needs one DMA piece instead of two.
-__global__ void split_weight_kernel(const float* __restrict__ w, _Float16* __restrict__ planes, long n) {
+__global__ void split_weight_kernel(const float* __restrict__ w, _Float16* __restrict__ planes, long n, unsigned* __restrict__ status) {
+    unsigned bad = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = w[i];
         const _Float16 h = (_Float16)v;
+        guard_half(h, bad);
         const long o = (i >> 5) * 64 + (i & 31);
         planes[o] = h;
         planes[o + 32] = (_Float16)((v - (float)h) * kLoScale);
     }
+    if (bad) status_raise(status, BG_ST_F16_RANGE);   // (weights: bevgen_finalize synchronises and reports it)
 }
 
 void launch_split_weight(const float* w, void* planes, long n, hipStream_t s) {
     BG_REQUIRE(n % 32 == 0, "split_weight: element count %ld must be a multiple of 32", n);
-    hipLaunchKernelGGL(split_weight_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(planes), n);
+    hipLaunchKernelGGL(split_weight_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(planes), n, status_current());
     LAUNCH_CHECK();
 }
 

@@ -331,6 +331,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
         _Float16* Ql = reinterpret_cast<_Float16*>(qkv ? g.epi_ql : g.epi_lo);
         const float* qsc = qkv ? g.epi_qscale : g.epi_scale;
         const int head = (n0 + wn * 64) >> 6;
+        unsigned bad = 0;   // a prepared operand that is NaN / outside the f16 range (l2norm bounds q and k: only a non-finite projection gets here; v is unbounded)
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
@@ -361,10 +362,12 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                         hi4[e] = split_hi(qv);
                         lo4[e] = split_lo(qv, hi4[e]);
                     }
+                    guard_half4(hi4, bad);
                     *reinterpret_cast<half4_t*>(Qh + dst + d) = hi4;
                     *reinterpret_cast<half4_t*>(Ql + dst + d) = lo4;
                 }
         }
+        if (bad) status_raise(g.status, BG_ST_F16_RANGE);
         return;
     }
     if (MODE == MODE_PLAIN && (g.epi == EPI_MUSE_KV || qkv)) {
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
         const bool is_v = ncol >= HD;
         const int head = (is_v ? ncol - HD : ncol) >> 6;
         const _Float16* aux = reinterpret_cast<const _Float16*>(g.epi_aux);
+        unsigned bad = 0;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
@@ -410,6 +414,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                             hi4[e] = split_hi(kv);
                             lo4[e] = split_lo(kv, hi4[e]);
                         }
+                        guard_half4(hi4, bad);
                         *reinterpret_cast<half4_t*>(Kh + dst + d) = hi4;
                         *reinterpret_cast<half4_t*>(Kl + dst + d) = lo4;
                         if (nk == 0) {   // the learned null key of this (batch, head): row 0
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                     for (int q = 0; q < 16; ++q) {
                         const int d = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
                         const _Float16 hi = split_hi(v[j][q]);
+                        guard_half(hi, bad);
                         Vh[base + (long)d * g.epi_ld] = hi;
                         Vl[base + (long)d * g.epi_ld] = split_lo(v[j][q], hi);
                         if (nk == 0) {
@@ -436,6 +442,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                     }
             }
         }
+        if (bad) status_raise(g.status, BG_ST_F16_RANGE);
         return;
     }
     if (MODE == MODE_PLAIN && g.epi == EPI_GEGLU) {   // (compiled out of the convolution variant: its register budget has no room for a third epilogue)
@@ -547,6 +554,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         g.a_bytes = (int)(unsigned)a_bytes;
     }
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
+    g.status = status_current();
     if (g.gn_part)
         BG_REQUIRE(g.mode == MODE_CONV3 && g.epi == 0 && g.ksplit <= 1 && g.M % 256 == 0 && g.m_base == 0 && g.N % GBN == 0 && g.ldc == g.N && (g.ldc & 3) == 0 &&
                        (!g.R || (g.ldr & 3) == 0) && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.R || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0) && !g.bias_m,

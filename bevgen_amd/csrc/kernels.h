@@ -76,6 +76,7 @@ struct GemmArgs {
     int m_base = 0;                   // first row of this launch (the launcher cuts a problem whose last round of tiles would be nearly empty into two row ranges; M stays the END row)
     bool no_row_split = false;        // launcher-internal
     int force_wm = 0;                 // launcher-internal: 4 = keep 256-row blocks (the whole-rounds part of a row-split launch)
+    unsigned* status = nullptr;       // the context's device status word (common.h BG_ST_*), filled in by the launchers: an operand outside the f16 range raises BG_ST_F16_RANGE
 };
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
 void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);
@@ -163,6 +164,7 @@ struct AttnSplitArgs {
     // (query block, head, batch, range); each writes its unnormalised output row, running maximum and row sum to `kws` and a combine kernel merges the ranges
     int ksplit = 1;
     float* kws = nullptr;             // attn_split_ws_floats(B, H, Nq, ksplit) floats
+    unsigned* status = nullptr;       // the context's device status word, filled in by the launcher (an output plane value outside the f16 range: BG_ST_F16_RANGE)
 };
 inline long attn_split_ws_floats(int B, int H, int Nq, int ksplit) { return (long)ksplit * B * H * Nq * 66; }
 long attn_bias_packed_floats(int Nq, int Nk_pad);
@@ -218,6 +220,7 @@ struct DecodeAttnArgs {
     int kv_dtype = 0;                // 0 = fp32, 1 = fp16 storage (fp32 accumulate)
     int shared_prefix = 0;           // reserved: leading keys shared by groups of `group` consecutive sequences
     int group = 1;
+    unsigned* status = nullptr;      // the context's device status word, filled in by the launcher
 };
 int decode_attention_splits(int B, int H, int n_max);
 size_t decode_attention_ws_bytes(int B, int H, int S);
@@ -265,6 +268,7 @@ struct ArAttnFusedArgs {
     // from HBM.  -1 = the launcher's choice ($BEVGEN_KV_STAGE overrides), 0 = off
     int stage_cap = -1;
     int has_bias = 0;                  // filled in by the launcher
+    unsigned* status = nullptr;        // the context's device status word, filled in by the launcher (fp16 cache: a key / value outside the fp16 range raises BG_ST_F16_RANGE)
 };
 bool ar_attn_fused_supported(int B, int G, int D, int H);
 // per-row constants of LayerNorm folded into a projection: cs[j] = sum_k W[j][k] gamma[k], ds[j] = sum_k W[j][k] beta[k] + b[j]   (W [N, K] row-major; fp64 accumulation)
@@ -303,7 +307,7 @@ struct MlpFusedArgs {
     float* hidden = nullptr;                           // [M][4 D] scratch (the GELU output, exchanged through L2)
     float* C = nullptr;                                // [8][M][D] partial sums of the down-projection
     unsigned* sync = nullptr;                          // mlp_fused_sync_words() words of device memory, zeroed once (barrier state per XCD + placement check)
-    unsigned* err = nullptr;                           // host-visible error word (non-zero: a barrier timed out / a workgroup was not on the XCD its index implies)
+    unsigned* err = nullptr;                           // the context's host-visible status word (common.h BG_ST_*): barrier timeout, wrong placement, f16 operand range
     int M = 0, D = 0;
     long long* trace = nullptr;
 };

@@ -172,8 +172,10 @@ struct Ctx {
     // under the tail of their K/V walk.  Measured slower on the same box (1.55 -> 1.65 / 1.61 ms/step, profiles/r03_ab_prefetch.txt): default off
     // fused MLP launch of the decode step (decode_fused.hip ar_mlp_fused_kernel): barrier words (device, zeroed at finalize) and the host-visible error word
     unsigned* mlpf_sync = nullptr;
-    unsigned *mlpf_err_host = nullptr, *mlpf_err_dev = nullptr;
-    void check_mlpf_error();      // throws when a fused MLP launch reported a timeout / a broken placement assumption
+    bool mlpf_disabled = false;   // a fused MLP launch of this context reported a timeout / wrong placement: every later step takes the two-launch form
+    // device status word (common.h BG_ST_*): one mapped host word per context, allocated at bevgen_create; kernels OR bits into it, the host reads it without synchronising
+    unsigned *status_host = nullptr, *status_dev = nullptr;
+    void check_status(const char* when);   // throws (and clears the word) when a kernel of an earlier / the synchronised call raised a bit
     long long* trace = nullptr;   // diagnostics (bevgen_set_trace_buffer): phase timestamps of the fused decode kernels, [3 kinds][4096 workgroups][8]
     void retire_graph(hipGraphExec_t e, hipGraph_t g);  // destroyed once the stream has drained (next call or destroy)
 
@@ -187,7 +189,6 @@ struct Ctx {
 // context.cpp
 void ctx_load_tensor(Ctx& c, const char* name, const void* h, int dtype, int ndim, const int64_t* shape);
 void ctx_finalize(Ctx& c);
-extern std::atomic<int> g_live_ar_contexts;   // Route-A contexts alive in this process that may issue workgroup-cooperative launches (ar.cpp: SpinSerial)
 void ctx_pack_split_qkv(Ctx& c, hipStream_t s);   // decode_path = auto: QKV operand image of the split decode layer, packed on first need
 // muse.cpp
 void muse_forward(Ctx& c, const int64_t* ids, const int64_t* cond, const float* I_inv, const float* E_inv, int B, float* logits, float* embed, hipStream_t s);

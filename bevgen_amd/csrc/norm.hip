@@ -38,7 +38,7 @@ constexpr int LN_MAXV = 12;  // float4 per lane -> D <= 3072
 // MAXV: float4 per lane the instantiation holds (4: rows up to 1024 wide - 16 row registers instead of 48, eight waves per SIMD instead of five)
 template <bool PLANES, int MAXV = LN_MAXV>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ y, int ldy, int rows, int D, float eps) {
+                                                            float* __restrict__ y, int ldy, int rows, int D, float eps, unsigned* __restrict__ status) {
     // D need not be a multiple of 4 (Route M: LayerNorm over F = 2730 columns of a row padded to 2752): the last vector of a row is then partly
     // padding - read (the row storage is ldx >= round_up(D, 4) wide), excluded from the statistics, written as zero.
     const int lane = threadIdx.x & 63;
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
     float4* yr = reinterpret_cast<float4*>(y + (long)row * ldy);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
+    unsigned bad = 0;   // PLANES: an output outside the f16 operand range (or NaN) - raised once per thread at the end (BG_ST_F16_RANGE)
     if (PLANES && (D & 255) == 0 && ldy == D) {
         // Whole rows of full vectors (the transformer widths): neighbouring lanes trade halves so that every lane stores 16 contiguous bytes - the even lane the hi
         // parts of the pair's 8 columns, the odd lane the lo parts - and a wave's store instruction covers 1 KiB of whole 128-byte lines (the generic path below writes
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
                 half4_t h, l;
                 h[0] = split_hi(o.x); h[1] = split_hi(o.y); h[2] = split_hi(o.z); h[3] = split_hi(o.w);
                 l[0] = split_lo(o.x, h[0]); l[1] = split_lo(o.y, h[1]); l[2] = split_lo(o.z, h[2]); l[3] = split_lo(o.w, h[3]);
+                guard_half4(h, bad);
                 const uint2 hw = __builtin_bit_cast(uint2, h), lw = __builtin_bit_cast(uint2, l);
                 const uint2 send = odd ? hw : lw;
                 const uint2 recv = make_uint2((unsigned)__builtin_amdgcn_mov_dpp((int)send.x, 0xB1, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)send.y, 0xB1, 0xf, 0xf, true));
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
                 *reinterpret_cast<uint4*>(prow + (c >> 5) * 64 + (c & 31) + (odd ? 32 : 0)) = out;
             }
         }
+        if (bad) status_raise(status, BG_ST_F16_RANGE);
         return;
     }
 #pragma unroll
@@ -121,13 +124,14 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
                 }
                 o = make_float4(out[0], out[1], out[2], out[3]);
             }
-            if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 4, o);
+            if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 4, o, bad);
             else yr[i] = o;
         } else if (i < (ldy >> 2)) {
-            if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+            if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 4, make_float4(0.f, 0.f, 0.f, 0.f), bad);
             else yr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    if (PLANES && bad) status_raise(status, BG_ST_F16_RANGE);
 }
 
 void launch_layernorm(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, int rows, int D, float eps, hipStream_t s) {
@@ -135,9 +139,9 @@ void launch_layernorm(const float* x, int ldx, const float* gamma, const float* 
     const bool vec = ldx % 4 == 0 && ldy % 4 == 0 && ldx >= round_up(D, 4) && ldy >= round_up(D, 4) && D <= 256 * LN_MAXV && ldy <= 256 * LN_MAXV &&
                      (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0;
     if (vec && D <= 1024 && ldy <= 1024)
-        hipLaunchKernelGGL((layernorm_vec_kernel<false, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+        hipLaunchKernelGGL((layernorm_vec_kernel<false, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, (unsigned*)nullptr);
     else if (vec)
-        hipLaunchKernelGGL(layernorm_vec_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
+        hipLaunchKernelGGL(layernorm_vec_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps, (unsigned*)nullptr);
     else
         hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, rows, D, eps);
     LAUNCH_CHECK();
@@ -149,9 +153,9 @@ void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const 
                    (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0,
                "layernorm_planes: unsupported shape D=%d ldx=%d ldy=%d", D, ldx, ldy);
     if (D <= 1024 && ldy <= 1024)
-        hipLaunchKernelGGL((layernorm_vec_kernel<true, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps);
+        hipLaunchKernelGGL((layernorm_vec_kernel<true, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps, status_current());
     else
-        hipLaunchKernelGGL(layernorm_vec_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps);
+        hipLaunchKernelGGL(layernorm_vec_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, ldx, gamma, beta, reinterpret_cast<float*>(planes), ldy, rows, D, eps, status_current());
     LAUNCH_CHECK();
 }
 
@@ -160,10 +164,11 @@ constexpr int GEGLU_MAX_PER_LANE = 48;  // F <= 3072
 
 template <bool PLANES>
 __global__ __launch_bounds__(256) void geglu_layernorm_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ gamma,
-                                                              float* __restrict__ y, int ldy, int rows, int F, float eps) {
+                                                              float* __restrict__ y, int ldy, int rows, int F, float eps, unsigned* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    unsigned bad = 0;
     const float* a = h + (long)row * ldh;
     const float* gate = a + F;
     float g[GEGLU_MAX_PER_LANE];
@@ -194,12 +199,14 @@ __global__ __launch_bounds__(256) void geglu_layernorm_kernel(const float* __res
             if (PLANES) {
                 _Float16* p = reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy + (i >> 5) * 64 + (i & 31);
                 const _Float16 hi = split_hi(o);
+                guard_half(hi, bad);
                 p[0] = hi; p[32] = split_lo(o, hi);
             } else {
                 yr[i] = o;
             }
         }
     }
+    if (PLANES && bad) status_raise(status, BG_ST_F16_RANGE);
 }
 
 // 8-byte-vectorised variant for even F (F = 2730 at D = 1024): `a` and `gate` rows are 8-byte aligned, all loads of a row are issued
@@ -208,10 +215,11 @@ constexpr int GEGLU_MAX2 = 24;  // float2 per lane -> F <= 3072
 
 template <bool PLANES>
 __global__ __launch_bounds__(256) void geglu_layernorm_vec2_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ gamma, float* __restrict__ y,
-                                                                   int ldy, int rows, int F, float eps) {
+                                                                   int ldy, int rows, int F, float eps, unsigned* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    unsigned bad = 0;
     const float2* a2 = reinterpret_cast<const float2*>(h + (long)row * ldh);
     const float2* g2 = reinterpret_cast<const float2*>(h + (long)row * ldh + F);
     const int n2 = F >> 1;
@@ -247,13 +255,14 @@ __global__ __launch_bounds__(256) void geglu_layernorm_vec2_kernel(const float* 
         if (i < n2) {
             const float2 g = gam[i];
             const float2 o = make_float2((av[j].x - mean) * rstd * g.x, (av[j].y - mean) * rstd * g.y);
-            if (PLANES) store_planes2(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 2, o);
+            if (PLANES) store_planes2(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 2, o, bad);
             else yr[i] = o;
         } else if (i < (ldy >> 1)) {
-            if (PLANES) store_planes2(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 2, make_float2(0.f, 0.f));
+            if (PLANES) store_planes2(reinterpret_cast<_Float16*>(y) + (long)row * 2 * ldy, i * 2, make_float2(0.f, 0.f), bad);
             else yr[i] = make_float2(0.f, 0.f);
         }
     }
+    if (PLANES && bad) status_raise(status, BG_ST_F16_RANGE);
 }
 
 void launch_geglu_layernorm(const float* h, int ldh, const float* gamma, float* y, int ldy, int rows, int F, float eps, hipStream_t s) {
@@ -262,9 +271,9 @@ void launch_geglu_layernorm(const float* h, int ldh, const float* gamma, float* 
     const bool vec = F % 2 == 0 && ldh % 2 == 0 && ldy % 2 == 0 && F <= 128 * GEGLU_MAX2 && ldy <= 128 * GEGLU_MAX2 &&
                      (reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma)) % 8 == 0;
     if (vec)
-        hipLaunchKernelGGL(geglu_layernorm_vec2_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps);
+        hipLaunchKernelGGL(geglu_layernorm_vec2_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps, (unsigned*)nullptr);
     else
-        hipLaunchKernelGGL(geglu_layernorm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps);
+        hipLaunchKernelGGL(geglu_layernorm_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, y, ldy, rows, F, eps, (unsigned*)nullptr);
     LAUNCH_CHECK();
 }
 
@@ -274,9 +283,9 @@ void launch_geglu_layernorm_planes(const float* h, int ldh, const float* gamma, 
     const bool vec = F % 2 == 0 && ldh % 2 == 0 && F <= 128 * GEGLU_MAX2 && ldy <= 128 * GEGLU_MAX2 &&
                      (reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(gamma)) % 8 == 0;
     if (vec)
-        hipLaunchKernelGGL(geglu_layernorm_vec2_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, reinterpret_cast<float*>(planes), ldy, rows, F, eps);
+        hipLaunchKernelGGL(geglu_layernorm_vec2_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, reinterpret_cast<float*>(planes), ldy, rows, F, eps, status_current());
     else
-        hipLaunchKernelGGL(geglu_layernorm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, reinterpret_cast<float*>(planes), ldy, rows, F, eps);
+        hipLaunchKernelGGL(geglu_layernorm_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, s, h, ldh, gamma, reinterpret_cast<float*>(planes), ldy, rows, F, eps, status_current());
     LAUNCH_CHECK();
 }
 
@@ -291,9 +300,9 @@ __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __r
     const int tid = threadIdx.x;
     const int chunk = blockIdx.x, n = blockIdx.y;
     const int q4 = C >> 2;                 // float4 per pixel
-    const int cq = tid % q4, psub = tid / q4, pstep = 256 / q4;
+    const int cq = tid % q4, psub = tid / q4, pstep = 256 / q4;   // (q4 not a divisor of 256 - C = 96, 192, 384 -: the last 256 - pstep q4 threads sit out)
     const int p_begin = chunk * GN_PIX_PER_BLOCK;
-    const int p_end = min(hw, p_begin + GN_PIX_PER_BLOCK);
+    const int p_end = psub < pstep ? min(hw, p_begin + GN_PIX_PER_BLOCK) : 0;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     const float* base = x + ((long)n * hw) * C + cq * 4;
     // four independent loads in flight per thread (one load per iteration left the pass latency bound: 0.59 ms per scene for ONE read of every activation, where the apply
@@ -356,7 +365,7 @@ __global__ void groupnorm_finalize_kernel(const double* __restrict__ part, float
 size_t groupnorm_ws_bytes(int n, int hw) { return (size_t)n * cdiv(hw, GN_PIX_PER_BLOCK) * GN_GROUPS * 2 * sizeof(double); }
 
 void launch_groupnorm_stats(const float* x, float* stats, void* ws, int n, int hw, int C, float eps, hipStream_t s) {
-    BG_REQUIRE(C % GN_GROUPS == 0 && C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0, "groupnorm: unsupported channel count %d", C);
+    BG_REQUIRE(C % GN_GROUPS == 0 && C % 4 == 0 && C <= 1024, "groupnorm: unsupported channel count %d", C);
     const int chunks = cdiv(hw, GN_PIX_PER_BLOCK);
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(chunks, n), dim3(256), 0, s, x, part, hw, C, chunks);
@@ -407,7 +416,7 @@ void launch_groupnorm_stats_from_partials(const float* part, float* stats, int n
 
 template <bool PLANES>   // PLANES: y is the interleaved (hi, lo) f16 plane image [pixel][C/32][2][32] read by the LDS-DMA split-precision convolution
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ y, int hw, int C, int do_swish) {
+                                                              const float* __restrict__ beta, float* __restrict__ y, int hw, int C, int do_swish, unsigned* __restrict__ status) {
     const int n = blockIdx.y;
     const int cpg = C / GN_GROUPS, q4 = C >> 2;
     const long per_img4 = (long)hw * q4;                           // float4 per image
@@ -428,6 +437,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
     }
     const float4* xin = reinterpret_cast<const float4*>(x) + (long)n * per_img4;
     const int lg = 31 - __builtin_clz(q4);
+    unsigned bad = 0;
     for (long i = i0; i < per_img4; i += stride) {
         const float4 v = xin[i];
         float out[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
@@ -435,37 +445,80 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[k] = out[k] / (1.f + expf(-out[k]));
         }
-        if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + ((long)n * hw + (i >> lg)) * 2 * C, cq * 4, make_float4(out[0], out[1], out[2], out[3]));
+        if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + ((long)n * hw + (i >> lg)) * 2 * C, cq * 4, make_float4(out[0], out[1], out[2], out[3]), bad);
         else reinterpret_cast<float4*>(y)[(long)n * per_img4 + i] = make_float4(out[0], out[1], out[2], out[3]);
     }
+    if (PLANES && bad) status_raise(status, BG_ST_F16_RANGE);
 }
 
+// Any channel count with whole quads (C % 4 == 0, C % 32 == 0 groups): the channel quad of an element is found by a division per element.  Only reached where C / 4 is not a
+// power of two (a VQGAN with ch_mult 3: C = 384) - the reference configurations (ch = 128, ch_mult 1 / 1 / 2 / 2 / 4) all take the kernel above.
+template <bool PLANES>
+__global__ __launch_bounds__(256) void groupnorm_apply_generic_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, float* __restrict__ y, int hw, int C, int do_swish,
+                                                                      unsigned* __restrict__ status) {
+    const int n = blockIdx.y;
+    const int cpg = C / GN_GROUPS, q4 = C >> 2;
+    const long per_img4 = (long)hw * q4;
+    const float4* xin = reinterpret_cast<const float4*>(x) + (long)n * per_img4;
+    unsigned bad = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_img4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / q4;
+        const int cq = (int)(i - pix * q4);
+        const float4 v = xin[i];
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cq * 4 + k;
+            float o = in[k];
+            if (stats) {
+                const float* st = stats + ((long)n * GN_GROUPS + c / cpg) * 2;
+                const float sck = st[1] * gamma[c];
+                o = fmaf(o, sck, beta[c] - st[0] * sck);   // (the same two roundings as the power-of-two kernel)
+            }
+            if (do_swish) o = o / (1.f + expf(-o));
+            out[k] = o;
+        }
+        if (PLANES) store_planes4(reinterpret_cast<_Float16*>(y) + ((long)n * hw + pix) * 2 * C, cq * 4, make_float4(out[0], out[1], out[2], out[3]), bad);
+        else reinterpret_cast<float4*>(y)[(long)n * per_img4 + i] = make_float4(out[0], out[1], out[2], out[3]);
+    }
+    if (PLANES && bad) status_raise(status, BG_ST_F16_RANGE);
+}
+
+static bool groupnorm_apply_pow2(int C) {
+    const int q4 = C >> 2;
+    return C % 4 == 0 && q4 > 0 && (q4 & (q4 - 1)) == 0 && (q4 <= 256 ? 256 % q4 == 0 : q4 % 256 == 0);
+}
 static dim3 groupnorm_apply_grid(int n, int hw, int C) {
     const int q4 = C >> 2;
-    BG_REQUIRE(C % 4 == 0 && (q4 & (q4 - 1)) == 0 && (q4 <= 256 ? 256 % q4 == 0 : q4 % 256 == 0), "groupnorm apply: C / 4 = %d must be a power of two", q4);
+    BG_REQUIRE(C % 4 == 0 && C % GN_GROUPS == 0, "groupnorm apply: C = %d must be a multiple of 32", C);
     const long per_img4 = (long)hw * q4;
     long bx = std::max<long>(1, std::min<long>((per_img4 + 255) / 256, std::max<long>(1, 4096 / std::max(n, 1))));
-    if (q4 > 256) bx = std::max<long>(q4 / 256, bx / (q4 / 256) * (q4 / 256));   // stride = 256 bx must stay a multiple of q4
+    if (groupnorm_apply_pow2(C) && q4 > 256) bx = std::max<long>(q4 / 256, bx / (q4 / 256) * (q4 / 256));   // stride = 256 bx must stay a multiple of q4
     return dim3((unsigned)bx, (unsigned)n);
+}
+template <bool PLANES>
+static void groupnorm_apply_launch(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s) {
+    unsigned* st = PLANES ? status_current() : nullptr;
+    if (groupnorm_apply_pow2(C)) hipLaunchKernelGGL(groupnorm_apply_kernel<PLANES>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, stats, gamma, beta, y, hw, C, do_swish, st);
+    else hipLaunchKernelGGL(groupnorm_apply_generic_kernel<PLANES>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, stats, gamma, beta, y, hw, C, do_swish, st);
+    LAUNCH_CHECK();
 }
 
 void launch_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta, float* y, int n, int hw, int C, int do_swish, hipStream_t s) {
-    hipLaunchKernelGGL(groupnorm_apply_kernel<false>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, stats, gamma, beta, y, hw, C, do_swish);
-    LAUNCH_CHECK();
+    groupnorm_apply_launch<false>(x, stats, gamma, beta, y, n, hw, C, do_swish, s);
 }
 
 // fp32 NHWC activation -> the (hi, lo) plane image the LDS-DMA convolution reads, values unchanged (x 1 + 0 is exact)
 void launch_to_planes(const float* x, void* planes, int n, int hw, int C, hipStream_t s) {
     BG_REQUIRE(C % 32 == 0, "to_planes: C=%d must be a multiple of 32", C);
-    hipLaunchKernelGGL(groupnorm_apply_kernel<true>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       reinterpret_cast<float*>(planes), hw, C, 0);
-    LAUNCH_CHECK();
+    groupnorm_apply_launch<true>(x, nullptr, nullptr, nullptr, reinterpret_cast<float*>(planes), n, hw, C, 0, s);
 }
 
 void launch_groupnorm_apply_planes(const float* x, const float* stats, const float* gamma, const float* beta, void* planes, int n, int hw, int C, int do_swish, hipStream_t s) {
     BG_REQUIRE(C % 32 == 0, "groupnorm_apply_planes: C=%d must be a multiple of 32", C);
-    hipLaunchKernelGGL(groupnorm_apply_kernel<true>, groupnorm_apply_grid(n, hw, C), dim3(256), 0, s, x, stats, gamma, beta, reinterpret_cast<float*>(planes), hw, C, do_swish);
-    LAUNCH_CHECK();
+    groupnorm_apply_launch<true>(x, stats, gamma, beta, reinterpret_cast<float*>(planes), n, hw, C, do_swish, s);
 }
 
 // ------------------------------------------------------------------------------------------------ row softmax (VQGAN AttnBlock, s1model:179-181)

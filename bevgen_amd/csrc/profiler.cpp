@@ -8,6 +8,7 @@ namespace bevgen {
 
 namespace {
 thread_local Profiler* t_current = nullptr;
+thread_local unsigned* t_status = nullptr;   // device address of the executing context's status word (common.h)
 
 hipEvent_t get_event(Profiler& p) {
     if (p.pool_used == p.pool.size()) {
@@ -26,6 +27,13 @@ Profiler* prof_set_current(Profiler* p) {
 }
 
 bool prof_enabled() { return t_current && t_current->on; }
+
+unsigned* status_current() { return t_status; }
+unsigned* status_set_current(unsigned* dev) {
+    unsigned* old = t_status;
+    t_status = dev;
+    return old;
+}
 
 ProfScope::ProfScope(int kind, double work, hipStream_t s, bool attach_) : attach(attach_), p(nullptr), idx(-1), stream(s), uncaught(std::uncaught_exceptions()) {
     if (!t_current || !t_current->on) return;

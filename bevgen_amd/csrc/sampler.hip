@@ -73,7 +73,7 @@ void launch_remask(int64_t* ids, const float* scores, const int64_t* init_ids, i
 // (can_remask_prev_masked = False); 2 = 1 - softmax(logits)[pred] everywhere, pred drawn for EVERY position (can_remask_prev_masked = True)
 __global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__ ids, const float* __restrict__ logits, int ldl, const float* __restrict__ gumbel_u,
                                                            long rows, int V, int k, float temp_div, int64_t mask_id, unsigned long long seed, unsigned iter,
-                                                           float* __restrict__ conf_scores, int conf_mode) {
+                                                           float* __restrict__ conf_scores, int conf_mode, unsigned* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void maskgit_pick_kernel(int64_t* __restrict__
         valid[j] = i < V;
         x[j] = valid[j] ? lr[i] : 0.f;
         key[j] = ordered_key(x[j]);
+    }
+    {   // the reference's Route A asserts finite logits on the host every step (ar_lm:202, gpt:388); here the sampler that reads every logit of the row anyway flags it
+        bool nf = false;
+#pragma unroll
+        for (int j = 0; j < VPL_MAX; ++j) nf |= nonfinite(x[j]);
+        if (nf) status_raise(status, BG_ST_NONFINITE_LOGITS);
     }
     const bool noisy = gumbel_u != nullptr || seed != 0;   // explicit uniforms, or drawn in registers (Philox keyed by seed / iteration / element)
     uint32_t thr = 0;
@@ -140,14 +146,14 @@ void launch_maskgit_pick(int64_t* ids, const float* logits, int ldl, const float
     BG_REQUIRE(conf_mode == 0 || conf_scores, "maskgit_pick: confidence scores requested without an output buffer");
     const float temp_div = fmaxf(temperature, 1e-10f);
     hipLaunchKernelGGL(maskgit_pick_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, ids, logits, ldl, gumbel_u, (long)rows, V, k, temp_div, mask_id, seed, iter, conf_scores,
-                       conf_mode);
+                       conf_mode, status_current());
     LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------------- self-critic scores
 __global__ __launch_bounds__(256) void critic_scores_kernel(const float* __restrict__ embed, int lde, const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ u, float noise_scale, float frac, float* __restrict__ scores, long rows, int D,
-                                                            unsigned long long seed, unsigned iter) {
+                                                            unsigned long long seed, unsigned iter, unsigned* __restrict__ status) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -163,6 +169,7 @@ __global__ __launch_bounds__(256) void critic_scores_kernel(const float* __restr
         float sc = acc + b[0];
         const float uu = u ? u[row] : (seed ? philox_uniform(seed, (unsigned long long)row, iter, 1u) : 0.5f);
         sc += ((uu - 0.5f) * noise_scale) * frac;
+        if (nonfinite(sc)) status_raise(status, BG_ST_NONFINITE_LOGITS);   // (a NaN score would silently rank first in the re-masking)
         scores[row] = sc;
     }
 }
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void critic_scores_kernel(const float* __restr
 void launch_critic_scores(const float* embed, int lde, const float* w, const float* b, const float* u, float noise_scale, float frac, float* scores, int rows, int D, hipStream_t s,
                           unsigned long long seed, unsigned iter) {
     BG_REQUIRE(D % 4 == 0, "critic_scores: D must be a multiple of 4");
-    hipLaunchKernelGGL(critic_scores_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, embed, lde, w, b, u, noise_scale, frac, scores, (long)rows, D, seed, iter);
+    hipLaunchKernelGGL(critic_scores_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, embed, lde, w, b, u, noise_scale, frac, scores, (long)rows, D, seed, iter, status_current());
     LAUNCH_CHECK();
 }
 
@@ -208,7 +215,8 @@ __device__ __forceinline__ void ar_pick_tail(const ArPickTail& t, const int* d_s
 }
 
 __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ u_base, const int* __restrict__ d_step,
-                                                     const int64_t* __restrict__ forced, int64_t* __restrict__ out, int V, int top_k, float temperature, ArPickTail tail) {
+                                                     const int64_t* __restrict__ forced, int64_t* __restrict__ out, int V, int top_k, float temperature, ArPickTail tail,
+                                                     unsigned* __restrict__ status) {
     const int lane = threadIdx.x;
     const long row = blockIdx.x;
     // partial decoding (ar_lm:161-165, 181-182): positions of the fixed cameras keep their given token, laid out [steps, rows] like the noise
@@ -231,7 +239,9 @@ __global__ __launch_bounds__(64) void ar_pick_kernel(const float* __restrict__ l
     for (int j = 0; j < VPL_MAX; ++j) {
         const int i = lane * per + j;
         valid[j] = j < per && i < V;
-        x[j] = valid[j] ? lr[i] / temperature : -INFINITY;
+        const float raw = valid[j] ? lr[i] : 0.f;
+        if (nonfinite(raw)) status_raise(status, BG_ST_NONFINITE_LOGITS);   // ar_lm:202 / gpt:388: assert (~logits.isfinite()).sum() == 0 (forced positions: their head row is
+        x[j] = valid[j] ? raw / temperature : -INFINITY;                    // not read here; a non-finite activation still reaches the next drawn position through the KV cache)
         key[j] = ordered_key(x[j]);
     }
     if (top_k > 0 && top_k < V) {
@@ -295,7 +305,7 @@ void launch_ar_pick(const float* logits, int ldl, const float* u, const int* d_s
     BG_REQUIRE(V <= 64 * VPL_MAX, "ar_pick: vocabulary %d > %d", V, 64 * VPL_MAX);
     BG_REQUIRE(!tail || !tail->out_all || d_step, "ar_pick: the fused tail reads the step from the device counter");
     BG_REQUIRE(!tail || !tail->x || tail->D % 4 == 0, "ar_pick: the fused embedding needs D %% 4 == 0");
-    hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, d_step, forced, out, V, top_k, temperature, tail ? *tail : ArPickTail{});
+    hipLaunchKernelGGL(ar_pick_kernel, dim3(rows), dim3(64), 0, s, logits, ldl, u, d_step, forced, out, V, top_k, temperature, tail ? *tail : ArPickTail{}, status_current());
     LAUNCH_CHECK();
 }
 

@@ -154,15 +154,18 @@ void launch_replicate_prefix(void* kc, void* vc, int layers, int B, int H, int L
 
 // decode_weights = f16: the matrix is replaced by its fp16-representable rounding (so that every consumer - prefill GEMMs, split planes, decode kernels - sees
 // the same values) and a packed fp16 copy is written for the kernels that stream it
-__global__ void round_to_f16_kernel(float* __restrict__ w, _Float16* __restrict__ h, long n) {
+__global__ void round_to_f16_kernel(float* __restrict__ w, _Float16* __restrict__ h, long n, unsigned* __restrict__ status) {
+    unsigned bad = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const _Float16 v = (_Float16)w[i];
+        guard_half(v, bad);
         w[i] = (float)v;
         if (h) h[i] = v;
     }
+    if (bad) status_raise(status, BG_ST_F16_RANGE);   // a weight with |w| >= 65520 has no fp16 image (reported by bevgen_finalize)
 }
 void launch_round_to_f16(float* w, void* h, long n, hipStream_t s) {
-    hipLaunchKernelGGL(round_to_f16_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(h), n);
+    hipLaunchKernelGGL(round_to_f16_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(h), n, status_current());
     LAUNCH_CHECK();
 }
 

@@ -25,13 +25,15 @@ void launch_codebook_gather(const int64_t* ids, const float* codebook, float* ou
 
 // x [n, hw, ldc] (first C channels used) -> y [n, C, hw]
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int hw, int C, int ldc,
-                                                           const float* __restrict__ mean, const float* __restrict__ stdv, int clamp01, uint8_t* __restrict__ y8) {
+                                                           const float* __restrict__ mean, const float* __restrict__ stdv, int clamp01, uint8_t* __restrict__ y8,
+                                                           unsigned* __restrict__ status) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int p = (int)(i % hw);
         const long nc = i / hw;
         const int c = (int)(nc % C);
         const long n = nc / C;
         float v = x[(n * hw + p) * ldc + c];
+        if (nonfinite(v)) status_raise(status, BG_ST_NONFINITE_PIXELS);   // (the clamp below would turn a NaN into a valid-looking pixel)
         if (mean) v = v * stdv[c] + mean[c];
         if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
         if (y8) y8[i] = (uint8_t)fminf(fmaxf(rintf(v * 255.0f), 0.f), 255.f);   // round(x*255) (half to even, like torch.round), the storage format of the images
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 
 void launch_nhwc_to_nchw(const float* x, float* y, int n, int hw, int C, int ldc, const float* mean, const float* stdv, int clamp01, hipStream_t s, uint8_t* y8) {
     const long total = (long)n * C * hw;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, y, total, hw, C, ldc, mean, stdv, clamp01, y8);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, y, total, hw, C, ldc, mean, stdv, clamp01, y8, status_current());
     LAUNCH_CHECK();
 }
 
@@ -56,7 +58,7 @@ constexpr int OC_T = 16, OC_HALO = OC_T + 2, OC_CC = 32, OC_PS = 36;
 template <int COUT>
 __global__ __launch_bounds__(256) void vq_out_conv_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ wgt, const float* __restrict__ bias, const float* __restrict__ mean, const float* __restrict__ stdv,
-                                                          int clamp01, float* __restrict__ y, uint8_t* __restrict__ y8, int H, int W, int C) {
+                                                          int clamp01, float* __restrict__ y, uint8_t* __restrict__ y8, int H, int W, int C, unsigned* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) float tile[OC_HALO * OC_HALO * OC_PS];
     const int tid = threadIdx.x, px = tid & 15, py = tid >> 4;
     const int x0 = blockIdx.x * OC_T, y0 = blockIdx.y * OC_T, n = blockIdx.z;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void vq_out_conv_kernel(const float* __restric
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
             float v = acc[co] + (bias ? bias[co] : 0.f);
+            if (nonfinite(v)) status_raise(status, BG_ST_NONFINITE_PIXELS);   // (the clamp below would turn a NaN into a valid-looking pixel)
             if (mean) v = v * stdv[co] + mean[co];
             if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
             const long o = (((long)n * COUT + co) * H + oy) * W + ox;
@@ -127,7 +130,7 @@ bool vq_out_conv_supported(int C, int cout) { return cout == 3 && C % 32 == 0 &&
 void launch_vq_out_conv(const float* x, const float* stats, const float* gamma, const float* beta, const float* wgt, const float* bias, const float* mean, const float* stdv, int clamp01,
                         float* y, uint8_t* y8, int n, int H, int W, int C, int cout, hipStream_t s) {
     BG_REQUIRE(vq_out_conv_supported(C, cout), "vq_out_conv: C=%d cout=%d", C, cout);
-    hipLaunchKernelGGL((vq_out_conv_kernel<3>), dim3(cdiv(W, OC_T), cdiv(H, OC_T), n), dim3(256), 0, s, x, stats, gamma, beta, wgt, bias, mean, stdv, clamp01, y, y8, H, W, C);
+    hipLaunchKernelGGL((vq_out_conv_kernel<3>), dim3(cdiv(W, OC_T), cdiv(H, OC_T), n), dim3(256), 0, s, x, stats, gamma, beta, wgt, bias, mean, stdv, clamp01, y, y8, H, W, C, status_current());
     LAUNCH_CHECK();
 }
 

@@ -90,5 +90,6 @@ class GPT(RuntimeOptionsMixin, nn.Module):
             rows.append(ctx.ar_logits())
             if s + 1 < N:
                 ctx.ar_decode_step(flat[:, int(cfg.forward_shuffle_idx[s])])
+        ctx.synchronize()   # gpt:383,388 (finite inputs / logits asserted by the reference): the device status word of the N step calls, read once
         logits = torch.stack(rows, dim=1)  # decode order
         return logits[:, cfg.backward_shuffle_idx.to(logits.device)]

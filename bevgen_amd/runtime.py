@@ -127,18 +127,52 @@ class Context:
 
     # ------------------------------------------------------------------------------------------ lifecycle
     def close(self):
+        """Destroys the context.  A status word nobody has read yet (asynchronous calls, no synchronize()) is reported here: an explicit close() raises after the
+        context is gone; the garbage-collector path (__del__) leaves it to the library's message on stderr."""
         if getattr(self, "_h", None):
+            pending = 0
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize(self.device)
+                    pending = self.status()
+            except Exception:
+                pending = 0
             self.lib.bevgen_destroy(self._h)
             self._h = None
+            if pending:
+                raise _lib.BevgenError(_lib.ERR_NUMERIC if pending & 28 else -4, f"context closed with device status word {pending} pending: results of its last calls were invalid "
+                                       "(include/bevgen_hip.h BEVGEN_STATUS_*)")
 
     def __del__(self):
         try:
-            self.close()
+            if getattr(self, "_h", None):
+                self.lib.bevgen_destroy(self._h)   # (prints a pending status word to stderr)
+                self._h = None
         except Exception:
             pass
 
     def _check(self, code):
         _lib.check(self._h, code)
+
+    # ------------------------------------------------------------------------------------------ device status word
+    def synchronize(self) -> None:
+        """Wait for this context's stream and raise ``BevgenError`` (code ``ERR_NUMERIC`` / internal) if a kernel of the calls enqueued so far flagged a non-finite
+        logit / pixel, an operand outside the f16 range of the chosen precision, or a failed fused-MLP launch (include/bevgen_hip.h "Device status word").  This is where
+        the reference's per-step ``assert (~logits.isfinite()).sum() == 0`` (gpt:383,388, ar_lm:202) lands: once per call instead of once per token."""
+        self._check(self.lib.bevgen_synchronize(self._h, self._s()))
+
+    def status(self) -> int:
+        """The raw status word as the host sees it now (no synchronisation, nothing cleared): ``_lib.STATUS_*`` bits."""
+        w = C.c_uint(0)
+        self._check(self.lib.bevgen_status(self._h, C.byref(w)))
+        return int(w.value)
+
+    def _done(self, check: bool) -> None:
+        """End of a whole-call wrapper.  check=True (the default of every wrapper that hands results back): synchronise and surface the status word NOW, so a caller can
+        never read tokens / pixels of a call that flagged itself.  check=False keeps the call asynchronous (pipelined callers, bench.py); the word is then reported by the next
+        call on this context at the latest, or by an explicit ``synchronize()``."""
+        if check:
+            self.synchronize()
 
     def _s(self):
         """The current torch stream of THIS context's device (not of whatever device is current)."""
@@ -182,7 +216,7 @@ class Context:
         self._finalized = True
 
     # ------------------------------------------------------------------------------------------ Route M
-    def muse_forward(self, ids, cond_ids, I_inv, E_inv, want_logits=True, want_embed=True):
+    def muse_forward(self, ids, cond_ids, I_inv, E_inv, want_logits=True, want_embed=True, check=True):
         cfg = self.cfg
         d = self.device
         ids = _req(ids, torch.int64, d, "ids")
@@ -194,10 +228,11 @@ class Context:
         logits = torch.empty((rows, cfg.num_cam_tokens, cfg.vocab_size), dtype=torch.float32, device=d) if want_logits else None
         embed = torch.empty((rows, cfg.num_cam_tokens, cfg.num_embed), dtype=torch.float32, device=d) if want_embed else None
         self._check(self.lib.bevgen_muse_forward(self._h, _ptr(ids), _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, _ptr(logits), _ptr(embed), self._s()))
+        self._done(check)
         return logits, embed
 
     def maskgit_generate(self, cond_ids, I_inv, E_inv, *, timesteps=18, temperature=1.0, topk_filter_thres=0.9, critic_noise_scale=1.0,
-                         gumbel_u=None, critic_u=None, init_ids=None, noise_seed=0, use_token_critic=True, can_remask_prev_masked=False, samples_per_layout=1):
+                         gumbel_u=None, critic_u=None, init_ids=None, noise_seed=0, use_token_critic=True, can_remask_prev_masked=False, samples_per_layout=1, check=True):
         """gumbel_u / critic_u: explicit uniforms (parity tests); else noise_seed != 0: the samplers draw them in registers (Philox); else deterministic.
         use_token_critic=False: scores = 1 - softmax(logits)[pred] (muse_net:611-622; no critic forwards), can_remask_prev_masked as the reference's flag.
         samples_per_layout S: consecutive groups of S scenes share their condition (cross-attention K / V built once per layout)."""
@@ -224,6 +259,7 @@ class Context:
         self._check(self.lib.bevgen_maskgit_generate_ex(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, timesteps, sched_c, float(temperature),
                                                          topk_count(topk_filter_thres, cfg.vocab_size), float(critic_noise_scale), _ptr(gumbel_u), _ptr(critic_u),
                                                          _ptr(init_ids), _ptr(out), C.c_uint64(int(noise_seed) & 0xFFFFFFFFFFFFFFFF), score_mode, int(samples_per_layout), self._s()))
+        self._done(check)
         return out.reshape(rows, cfg.cam_latent_h, cfg.cam_latent_w)
 
     def philox_uniform(self, seed, it, stream_id, n, V=0):
@@ -253,9 +289,11 @@ class Context:
         self._ar_B = cond_ids.shape[0]
         self._check(self.lib.bevgen_ar_prefill(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), self._ar_B, self._s()))
 
-    def ar_logits(self):
+    def ar_logits(self, check=False):
+        """(step-level calls stay asynchronous by default: the status word surfaces at the next call or at synchronize())"""
         out = torch.empty((self._ar_B, self.cfg.vocab_size), dtype=torch.float32, device=self.device)
         self._check(self.lib.bevgen_ar_logits(self._h, _ptr(out), self._s()))
+        self._done(check)
         return out
 
     def ar_decode_step(self, token):
@@ -263,7 +301,7 @@ class Context:
         self._check(self.lib.bevgen_ar_decode_step(self._h, _ptr(token), self._s()))
 
     def ar_sample(self, cond_ids, I_inv, E_inv, *, steps=None, top_k=None, temperature=1.0, greedy=True, noise_u=None, samples_per_layout=1, return_logits=False,
-                  forced_ids=None):
+                  forced_ids=None, check=True):
         """Route A sampling with the KV cache.  forced_ids [steps, B] int64 in decode order (>= 0: emit this token, < 0: draw) = partial decoding."""
         cfg = self.cfg
         d = self.device
@@ -282,6 +320,7 @@ class Context:
             assert tuple(forced_ids.shape) == (steps, B)
         self._check(self.lib.bevgen_ar_sample_forced(self._h, _ptr(cond_ids), _ptr(I_inv), _ptr(E_inv), B, steps, int(top_k or 0), float(temperature), int(bool(greedy)),
                                                       _ptr(noise_u), int(samples_per_layout), _ptr(forced_ids), _ptr(out), _ptr(logits), self._s()))
+        self._done(check)
         return (out, logits) if return_logits else out
 
     # ------------------------------------------------------------------------------------------ stage 1
@@ -298,7 +337,7 @@ class Context:
             raise ValueError(f"{tokens} token ids per image do not fill the {lh} x {lw} latent grid: pass latent_hw=cam_latent_res")
         return lh, lw
 
-    def vq_decode(self, ids, denormalize=True, latent_hw=None, uint8=False):
+    def vq_decode(self, ids, denormalize=True, latent_hw=None, uint8=False, check=True):
         """ids [n, lat_h*lat_w] -> [n, out_ch, H, W] fp32 (raw or denormalised to [0,1]) or, with uint8=True, the round(255 x) storage format."""
         dd = self.vq_ddconfig
         ids = _req(ids, torch.int64, self.device, "ids")
@@ -309,9 +348,10 @@ class Context:
         mode = _lib.VQ_OUT_U8 if uint8 else (_lib.VQ_OUT_DENORM if denormalize else _lib.VQ_OUT_RAW)
         out = torch.empty((n, dd["out_ch"], lh * f, lw * f), dtype=torch.uint8 if uint8 else torch.float32, device=self.device)
         self._check(self.lib.bevgen_vq_decode(self._h, _ptr(ids), n, lh, lw, mode, _ptr(out), self._s()))
+        self._done(check)
         return out
 
-    def vq_encode(self, x):
+    def vq_encode(self, x, check=True):
         """VQModel.encode -> token ids: x [n, in_channels, H, W] fp32 (NCHW; H, W multiples of 2^(levels-1)) -> ids [n, h*w] int64."""
         dd = self.vq_ddconfig
         x = _req(x, torch.float32, self.device, "x")
@@ -321,9 +361,10 @@ class Context:
             raise ValueError(f"vq_encode: input {tuple(x.shape)} needs {dd['in_channels']} channels and sides divisible by {f}")
         ids = torch.empty((n, (H // f) * (W // f)), dtype=torch.int64, device=self.device)
         self._check(self.lib.bevgen_vq_encode(self._h, _ptr(x), n, H, W, _ptr(ids), self._s()))
+        self._done(check)
         return ids
 
-    def vq_decode_latents(self, zq, denormalize=False):
+    def vq_decode_latents(self, zq, denormalize=False, check=True):
         """VQModel.decode(quant): zq [n, embed_dim, h, w] fp32."""
         dd = self.vq_ddconfig
         zq = _req(zq, torch.float32, self.device, "zq")
@@ -331,6 +372,7 @@ class Context:
         f = 1 << self._vq_levels()
         out = torch.empty((n, dd["out_ch"], lh * f, lw * f), dtype=torch.float32, device=self.device)
         self._check(self.lib.bevgen_vq_decode_latents(self._h, _ptr(zq), n, lh, lw, _lib.VQ_OUT_DENORM if denormalize else _lib.VQ_OUT_RAW, _ptr(out), self._s()))
+        self._done(check)
         return out
 
     # ------------------------------------------------------------------------------------------ per-kernel HIP-event timing
@@ -385,7 +427,7 @@ class Context:
         return out[0] if ks.value == 1 else out[:ks.value].sum(0)
 
     def op_mlp_fused(self, x, ln_w, ln_b, w1, b1, w2, b2, w_f16=False, eps=1e-5):
-        """Both MLP projections of a Route A decode layer in one launch: Linear2(GELU(Linear1(LayerNorm(x)))) for M <= 16 rows, without the residual."""
+        """Both MLP projections of a Route A decode layer in one launch: Linear2(GELU(Linear1(LayerNorm(x)))) for M <= 64 rows, without the residual."""
         M, D = x.shape
         out = torch.empty((M, D), dtype=torch.float32, device=self.device)
         self._check(self.lib.bevgen_op_mlp_fused(self._h, _ptr(x), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), int(w_f16), _ptr(out), M, D, self._s()))

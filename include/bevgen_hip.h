@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BEVGEN_ABI_VERSION 5   /* 5: bevgen_op_mlp_fused; a context without max_batch <= 4 packs the split decode layer lazily (see Conventions).  4: 4: BEVGEN_PROFILE_KINDS 5 -> 6 (bevgen_profile_end writes 18 doubles), bevgen_cfg.decode_chains, decode_path values 2 / 3 */
+#define BEVGEN_ABI_VERSION 6   /* 6: device status word (bevgen_synchronize, bevgen_status, BEVGEN_ERR_NUMERIC, BEVGEN_STATUS_*).  5: bevgen_op_mlp_fused; a context without max_batch <= 4 packs the split decode layer lazily (see Conventions).  4: 4: BEVGEN_PROFILE_KINDS 5 -> 6 (bevgen_profile_end writes 18 doubles), bevgen_cfg.decode_chains, decode_path values 2 / 3 */
 
 enum { BEVGEN_ROUTE_MASKGIT = 0, BEVGEN_ROUTE_AR = 1 };
 /* FP32  : every product and accumulation in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32) - bit-exact greedy tokens vs the CPU reference.
@@ -47,7 +47,26 @@ enum {
     BEVGEN_ERR_INVALID = -1,   /* bad argument / missing tensor / unsupported size */
     BEVGEN_ERR_HIP = -2,       /* a HIP runtime call failed */
     BEVGEN_ERR_STATE = -3,     /* call order violated (e.g. generate before finalize) */
-    BEVGEN_ERR_INTERNAL = -4
+    BEVGEN_ERR_INTERNAL = -4,
+    BEVGEN_ERR_NUMERIC = -5    /* a kernel flagged a non-finite logit / pixel or an operand outside the f16 range of the chosen precision (device status word, below):
+                                  the results of the call that raised it are invalid */
+};
+
+/* Device status word.  The reference asserts on the HOST, every decode step, that the transformer's inputs and logits are finite
+ * (transformer/mingpt_sparse.py:383,388; stage2/cond_transformer_multi_view.py:202).  This library never synchronises on the sampling path; instead the kernels
+ * that touch the values anyway OR a bit into one host-visible word per context (mapped host memory) and the host reads it
+ *   - in bevgen_synchronize (after waiting for the stream: the call a caller makes before it trusts / copies the results),
+ *   - at the entry of EVERY later entry point on the context (no synchronisation: an error raised by an earlier asynchronous call is reported by the next call at the latest),
+ *   - in bevgen_finalize (weights outside the f16 range of the chosen precision) and, as a message on stderr, in bevgen_destroy.
+ * A raised word is returned as BEVGEN_ERR_NUMERIC (bits 4, 8, 16) or BEVGEN_ERR_INTERNAL (bits 1, 2) and then cleared.
+ * Policy for precision = F16X3 / fp16 storage modes: an operand whose f16 image would be inf / NaN (|v| >= 65520) is an ERROR, not rescaled - the split keeps fp32-class
+ * mantissas but f16's exponent range, where the reference's bf16 / fp32 arithmetic has 8 exponent bits; such a checkpoint must run with BEVGEN_PRECISION_FP32. */
+enum {
+    BEVGEN_STATUS_MLP_BARRIER = 1,        /* fused MLP launch of the decode step: an XCD-local barrier timed out (the GPU was shared); the context falls back to two launches */
+    BEVGEN_STATUS_MLP_PLACEMENT = 2,      /* ...: a workgroup was not placed on the XCD its index implies */
+    BEVGEN_STATUS_NONFINITE_LOGITS = 4,   /* a sampler read a NaN / inf logit or critic score */
+    BEVGEN_STATUS_F16_RANGE = 8,          /* a value written as an f16 operand (hi / lo planes, fp16 KV cache, fp16 decode activations, fp16 weights) was NaN or |v| >= 65520 */
+    BEVGEN_STATUS_NONFINITE_PIXELS = 16   /* the VQGAN decoder produced a NaN / inf pixel */
 };
 
 /* Sizes of the stage-2 transformer (mirror of GPTConfig, modules/transformer/mingpt_sparse.py:26-102) and of the
@@ -104,6 +123,11 @@ int bevgen_create(const bevgen_cfg* cfg, int device, bevgen_ctx** out);
 void bevgen_destroy(bevgen_ctx* ctx);
 const char* bevgen_last_error(const bevgen_ctx* ctx);   /* ctx may be NULL: error of the last failed bevgen_create */
 int bevgen_abi_version(void);
+/* Wait for `stream` (and the library's own decode stream) and report what the kernels of the calls enqueued so far flagged: 0, or BEVGEN_ERR_NUMERIC / BEVGEN_ERR_INTERNAL
+ * with the details in bevgen_last_error.  This is where the reference's per-step `assert isfinite` lands (see "Device status word" above). */
+int bevgen_synchronize(bevgen_ctx* ctx, void* stream);
+/* The raw status word (BEVGEN_STATUS_* bits) as the host sees it right now: no synchronisation, nothing cleared. */
+int bevgen_status(bevgen_ctx* ctx, unsigned* word);
 
 /* Upload one tensor (synchronous H2D copy).  `name` is the reference state_dict key
  * (utils/general.py:119-160 loader semantics: names listed in bevgen_amd/weights.py), with the prefixes

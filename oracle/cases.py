@@ -25,6 +25,7 @@ class Case:
     timesteps: int = 6  # Route M
     steps: int = 0  # Route A decode steps (0 = all)
     layout_seed: int = 0  # density < 1: torch seed under which the imported reference drew the per-layer layouts of the golden
+    heavy: int = 0  # != 0: trained-like heavy-tailed weights (heavy_tail below, this seed) instead of the reference's N(0, 0.02) initialisation
 
 
 CASES: Dict[str, Case] = {
@@ -46,6 +47,10 @@ CASES: Dict[str, Case] = {
     # perm:125-143) and keeps them as the `master_layout` buffer; the goldens carry the layouts the imported reference drew (layout_seed)
     "a_tiny_d06": Case("a_tiny_d06", "a", lambda: presets.tiny_route_a(3, block=4, density=0.6), 1234, 7, 2, layout_seed=4242),
     "a_config4_d035_head": Case("a_config4_d035_head", "a", lambda: presets.config4(density=0.35), 1234, 0, 1, steps=6, layout_seed=4242),
+    # trained-like weights (heavy_tail): a few outlier channels x 30-100 in the LayerNorm gains and the MLP / feed-forward up-projection rows - activations
+    # leave the O(1-10) range every N(0, 0.02) fixture lives in; the f16 hi / lo splits of precision = 'f16x3' must still give the reference's tokens
+    "m_tiny_heavy": Case("m_tiny_heavy", "m", lambda: presets.tiny_route_m(3, legacy=False), 1234, 8, 2, heavy=31),
+    "a_tiny_heavy": Case("a_tiny_heavy", "a", lambda: presets.tiny_route_a(3, block=16), 1234, 9, 2, heavy=37),
 }
 
 
@@ -66,6 +71,45 @@ gpt_state_dict = W.gpt_state_dict
 vq_state_dict = W.vq_state_dict
 
 
+def heavy_tail(sd, seed: int, n_out: int = 4, lo: float = 30.0, hi: float = 100.0):
+    """Trained-like heavy tails on top of the reference-initialisation weights (TEST INFRASTRUCTURE): trained transformers carry a handful of outlier channels whose
+    LayerNorm gains and up-projection rows are one to two orders of magnitude above the rest; the N(0, 0.02) initialisation (gpt:310-317) has none, so activations of every
+    other fixture stay O(1-10).  For every tensor of the kinds below, ``n_out`` channels (drawn per tensor from ``seed``) are multiplied by a factor in [lo, hi]:
+      * LayerNorm / GroupNorm gains:  ``*.ln1.weight, *.ln2.weight, ln_f.weight`` (Route A), ``*.norm.gamma, *.2.0.gamma, *.2.3.gamma`` (Route M), ``*.norm*.weight`` (VQGAN)
+      * up-projection ROWS:           ``*.mlp.0.weight`` (+ its bias), ``*.2.1.weight`` (GEGLU up: x and gate halves), VQGAN ``nin_shortcut`` / ``conv_in`` output channels
+    The aliased ``token_critic.net.*`` tensors of a MaskGit follow their ``transformer.*`` originals.  Deterministic in (seed, key); returns a new dict."""
+    out = dict(sd)
+
+    def pick(key, n):
+        g = torch.Generator().manual_seed((seed * 1000003 + W.zlib.crc32(key.encode())) % (2 ** 31))
+        idx = torch.randperm(n, generator=g)[:n_out]
+        fac = lo + (hi - lo) * torch.rand(n_out, generator=g)
+        return idx, fac
+
+    for k, v in sd.items():
+        if k.startswith("token_critic.net."):
+            continue
+        gain = k.endswith((".ln1.weight", ".ln2.weight", "ln_f.weight", ".norm.gamma", ".2.0.gamma", ".2.3.gamma")) or (".norm" in k and k.endswith(".weight") and v.dim() == 1)
+        rows = k.endswith((".mlp.0.weight", ".mlp.0.bias", ".2.1.weight", ".nin_shortcut.weight", ".nin_shortcut.bias", "decoder.conv_in.weight", "decoder.conv_in.bias"))
+        if k.startswith(("transformer.norm.", "transformer.self_cond_to_init_embed.")) or not (gain or rows) or not v.is_floating_point():
+            continue
+        key = k[:-5] + ".weight" if k.endswith(".bias") else k   # a bias shares the channels of its weight
+        idx, fac = pick(key, v.shape[0])
+        t = v.clone()
+        t[idx] = t[idx] * fac.reshape(-1, *([1] * (t.dim() - 1))).to(t.dtype)
+        out[k] = t
+    for k in sd:
+        if k.startswith("token_critic.net."):
+            out[k] = out["transformer." + k[len("token_critic.net."):]]
+    return out
+
+
+def case_state_dict(case: Case, cfg):
+    """Weights of a case: the deterministic reference-initialisation weights, heavy-tailed when the case says so."""
+    sd = (maskgit_state_dict if case.route == "m" else gpt_state_dict)(cfg, case.weight_seed)
+    return heavy_tail(sd, case.heavy) if case.heavy else sd
+
+
 def inputs(case: Case, cfg):
     return synthetic.make_batch(cfg, case.batch, seed=case.input_seed)
 
@@ -79,6 +123,7 @@ def maskgit_noise(case: Case, cfg, seed: int = 5):
 VQ_TINY = dict(dd=presets.VQ_DDCONFIG_TINY, n_embed=64, embed_dim=64, seed=99, n_images=3)
 # the released first-stage decoder at full size (f16: ch 128, ch_mult [1,1,2,2,4], 256x256, codebook 1024 x 256, configs/model/stage_2.yaml:36-55)
 VQ_FULL = dict(dd=presets.VQ_DDCONFIG_F16, n_embed=1024, embed_dim=256, seed=99, n_images=1)
+VQ_TINY_HEAVY = dict(dd=presets.VQ_DDCONFIG_TINY, n_embed=64, embed_dim=64, seed=99, n_images=2, heavy=41)   # vq_tiny with heavy_tail (nin_shortcut / conv_in / norm gains)
 VQ_TINY_SEG = dict(dd=dict(presets.VQ_DDCONFIG_TINY, in_channels=7, out_ch=7), n_embed=64, embed_dim=64, seed=77, n_images=2)  # BEV cond stage (7 Argoverse classes)
 
 
@@ -87,7 +132,7 @@ def golden_state_dict(case: Case, cfg, g):
     configuration's layout in the `master_layout` buffers."""
     import numpy as np
 
-    sd = gpt_state_dict(cfg, case.weight_seed)
+    sd = case_state_dict(case, cfg)
     if "layer_layout_bits" in g.files:
         shape = tuple(int(v) for v in g["layer_layout_shape"])
         lay = np.unpackbits(g["layer_layout_bits"])[: int(np.prod(shape))].reshape(shape).astype(np.int64)

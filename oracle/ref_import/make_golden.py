@@ -90,7 +90,7 @@ def golden_tables():
 # ------------------------------------------------------------------------------------------------ Route M
 def golden_route_m(case: cases.Case, full: bool):
     cfg = case.make_cfg()
-    sd = cases.maskgit_state_dict(cfg, case.weight_seed)
+    sd = cases.case_state_dict(case, cfg)
     mg, _ = RM.build_ref_maskgit(cfg, sd)
     bt = cases.inputs(case, cfg)
     batch = {"intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
@@ -113,6 +113,9 @@ def golden_route_m(case: cases.Case, full: bool):
     out = dict(ids_in=ids.to(torch.int16), cond_ids=bt["cond_ids"].to(torch.int16), I_inv=bt["intrinsics_inv"], E_inv=bt["extrinsics_inv"],
                gen_greedy=gen_ref.to(torch.int16), trace_ids=torch.stack([t["ids"] for t in trace]).to(torch.int16),
                min_margin_greedy=np.array(min(top2_margin(t["logits"]) for t in trace)), ref_forward_seconds=np.array(t_fwd))
+    if case.heavy:   # how far the activations of this fixture leave the O(1-10) range of the N(0, 0.02) fixtures (recorded, and asserted to be far)
+        out.update(logits_absmax=np.array(float(lr.abs().max())), embed_absmax=np.array(float(er.abs().max())))
+        assert float(lr.abs().max()) > 50.0, "the heavy-tailed case was expected to produce large logits"
     if not full:
         noise = cases.maskgit_noise(case, cfg)
         with RM.deterministic_maskgit_noise(noise), torch.no_grad():
@@ -226,7 +229,7 @@ class _RefSampler:
 
 def golden_route_a(case: cases.Case, full: bool):
     cfg = case.make_cfg()
-    sd = cases.gpt_state_dict(cfg, case.weight_seed)
+    sd = cases.case_state_dict(case, cfg)
     bt = cases.inputs(case, cfg)
     batch = {"intrinsics_inv": bt["intrinsics_inv"], "extrinsics_inv": bt["extrinsics_inv"]}
     B, C, T, N = case.batch, cfg.num_cams, cfg.num_cam_tokens, cfg.num_img_tokens
@@ -380,6 +383,25 @@ def golden_vq():
     save("vq_tiny", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd, **enc)
 
 
+def golden_vq_heavy():
+    """vq_tiny with trained-like heavy-tailed weights (cases.heavy_tail: outlier channels x 30-100 in the GroupNorm gains, the nin_shortcut 1x1 convolutions - which
+    run on UN-normalised tensors - and conv_in): decode by the imported reference, asserted against the restatement."""
+    v = cases.VQ_TINY_HEAVY
+    dd = v["dd"]
+    sd = cases.heavy_tail(cases.vq_state_dict(dd, v["n_embed"], v["embed_dim"], v["seed"], with_encoder=True), v["heavy"])
+    lat = dd["resolution"] // 2 ** (len(dd["ch_mult"]) - 1)
+    vq = RM.build_ref_vqmodel(dd, v["n_embed"], v["embed_dim"], sd, (dd["resolution"],) * 2, (lat, lat))
+    g = torch.Generator().manual_seed(43)
+    ids = torch.randint(0, v["n_embed"], (v["n_images"], lat * lat), generator=g)
+    with torch.no_grad():
+        zq = vq.quantize.get_codebook_entry(ids.reshape(-1), shape=(v["n_images"], lat, lat, v["embed_dim"]))
+        xr = vq.decode(zq)
+        xd = stubs.import_reference().util.denormalize_tensor(xr, keep_tensor=True)
+    xo = R.vq_decode_ids(sd, dd, ids, (lat, lat), denorm=False)
+    assert rel(xo, xr) < 2e-5, rel(xo, xr)
+    save("vq_tiny_heavy", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd, raw_absmax=np.array(float(xr.abs().max())))
+
+
 def golden_vq_rect():
     """Non-square latents (the reference's nuScenes experiment: cam_res [224, 400], cam_latent_res [14, 25], configs/experiment/muse_stage_two_multi_view.yaml)
     through the fully convolutional decoder / encoder: tiny model with full tensors, and the released f16 architecture at 14 x 25 -> 224 x 400
@@ -481,6 +503,9 @@ def main():
     if want("vq"):
         print("vq")
         golden_vq()
+    if want("vq_heavy"):
+        print("vq_heavy")
+        golden_vq_heavy()
     if want("vq_rect"):
         print("vq_rect")
         golden_vq_rect()
