@@ -234,6 +234,22 @@ static void finalize_muse(Ctx& c) {
             c.split_weight(l.ff_w1_geglu, 2L * c.Fpad * D);
         }
         c.split_weight(l.ff_w4_padded, (long)D * c.Fpad);
+        if (g.precision == BEVGEN_PRECISION_F16X3 && g.weight_dtype != BEVGEN_W_F16 && l.ff_w1_geglu) {
+            // consumer-side constants of the folded LayerNorms (muse.cpp muse_blocks; weight_dtype = f16 keeps the LayerNorm kernels: W o gamma is not f16-representable
+            // and that mode's contract is "the fp32-class evaluation of the ROUNDED matrices")
+            auto fold = [&](const float* W, const float* gamma, int N, int K, int Kg, float*& Wg, float*& cs) {
+                Wg = reinterpret_cast<float*>(c.own((size_t)N * K * sizeof(float)));
+                cs = reinterpret_cast<float*>(c.own((size_t)N * sizeof(float)));
+                launch_ln_fold_weight(W, gamma, Wg, cs, N, K, Kg, 0);
+                c.split_weight(Wg, (long)N * K);
+            };
+            fold(l.ff_w4_padded, l.ff_g3, D, c.Fpad, F, l.fold_w4, l.fold_w4_cs);
+            fold(l.to_qkv_self, l.norm_g[0], 3 * inner, D, D, l.fold_qkv, l.fold_qkv_cs);
+            fold(l.to_q[0], l.norm_g[0], inner, D, D, l.fold_q_self, l.fold_q_self_cs);
+            fold(l.to_kv[0], l.norm_g[0], 2 * inner, D, D, l.fold_kv_self, l.fold_kv_self_cs);
+            fold(l.to_q[1], l.norm_g[1], inner, D, D, l.fold_q_cross, l.fold_q_cross_cs);
+            fold(l.ff_w1_geglu, l.ff_g0, 2 * c.Fpad, D, D, l.fold_w1, l.fold_w1_cs);
+        }
     }
     c.split_weight(c.pf(p + "to_logits.weight"), (long)g.vocab_size * D);
     // attention bias matrices with the null-key column

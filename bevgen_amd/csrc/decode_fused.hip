@@ -1265,7 +1265,6 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
     const int slice = K2 >> 3, kper2 = slice / SF_WAVES;                                 // phase 2: this XCD's K slice of the down-projection (512), per wave (64)
 #define MF_TRACE(i) do { if (g.trace && tid == 0) g.trace[(long)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     MF_TRACE(0);
-    if (__hip_atomic_load(g.sync + MLPF_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // (uniform: an earlier launch on this buffer timed out)
     unsigned bad = 0;   // an activation outside the f16 operand range (WT = 1)
     unsigned* cnt = g.sync + 64 * xcd;   // monotonic arrival counter of this XCD's workgroups (never reset: per_xcd arrivals per launch, compared modulo 2^32)
     // ---- requests, in the order the results are needed: rows, gamma, row constants, up weights, down weights
@@ -1408,8 +1407,12 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
         const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (old / (unsigned)per_xcd + 1u) * (unsigned)per_xcd;
         if (old + 1u != target) {
+            // (an earlier launch on this buffer timed out: do not spin again - the results are garbage either way, and the status word has said so.  Read only by a workgroup
+            // that has to wait anyway: nothing on the fast path)
+            const bool poisoned = __hip_atomic_load(g.sync + MLPF_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
             const long long t_in = __builtin_amdgcn_s_memrealtime();
-            while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // (an L2-coherent read: the vector L1 never serves it)
+            if (poisoned) ok = 0;
+            else while ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // (an L2-coherent read: the vector L1 never serves it)
                 __builtin_amdgcn_s_sleep(1);
                 if (__builtin_amdgcn_s_memrealtime() - t_in > MLPF_TIMEOUT_TICKS) { ok = 0; break; }
             }
@@ -1425,20 +1428,32 @@ __global__ __launch_bounds__(SF_WAVES * 64) void ar_mlp_fused_kernel(MlpFusedArg
             __hip_atomic_store(g.sync + MLPF_POISON, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // acquire side of the exchange: the peers' hidden columns sit in this XCD's L2 (acknowledged stores, counted arrivals); this CU's vector L1 may still hold lines of
-    // g.hidden from THIS workgroup's own phase-1 stores - it wrote 64 bytes of each 128-byte line it reads back below, the neighbouring tile owns the other half - so
-    // the L1 is invalidated before the slice is read (one buffer_inv per wave, no L2 traffic).
-    asm volatile("buffer_inv sc1" ::: "memory");
+    // acquire side of the exchange: the peers' hidden columns sit in this XCD's L2 (acknowledged stores, counted arrivals).  This CU's vector L1 could in principle still
+    // hold lines of g.hidden from THIS workgroup's own phase-1 stores - it wrote 64 bytes of each 128-byte line it reads back below, the neighbouring tile owns the other
+    // half.  g.acq: 1 = the slice is read with sc1 loads (served by the L2, whatever the L1 holds; the default), 2 = buffer_inv sc1 in front of plain loads (the
+    // textbook agent-scope acquire: on this part it also drops the XCD's non-local L2 lines - measured +15 us per launch), 0 = plain loads (round 5)
+    if (g.acq == 2) asm volatile("buffer_inv sc1" ::: "memory");
     // ---- phase 2: down-projection of this XCD's hidden slice, 2 x 16 output columns per workgroup, into partial plane `xcd`
     const int nch2 = slice >> 2;   // 128 chunks of 4
     for (int mc = 0; mc < n_mc; ++mc) {
     {
         const int mr = min(16 * mc + r, g.M - 1);
+        f32x4 hv[4];
+        if (g.acq == 1) {   // four sc1 loads in flight, ONE wait (the "+v" operands tie every later use of the values to the wait)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* hp = g.hidden + (long)mr * K2 + xcd * slice + 4 * min(q + 4 * wave + 32 * j, nch2 - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hv[j]) : "v"(hp) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]) : : "memory");
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hv[j] = *reinterpret_cast<const f32x4*>(g.hidden + (long)mr * K2 + xcd * slice + 4 * min(q + 4 * wave + 32 * j, nch2 - 1));
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = q + 4 * wave + 32 * j;
-            const float4 hv = *reinterpret_cast<const float4*>(g.hidden + (long)mr * K2 + xcd * slice + 4 * min(c, nch2 - 1));
-            if (c < nch2) As[c * 16 + r] = hv;
+            if (c < nch2) As[c * 16 + r] = make_float4(hv[j][0], hv[j][1], hv[j][2], hv[j][3]);
         }
     }
     __syncthreads();
@@ -1535,17 +1550,20 @@ bool mlp_fused_supported(int M, int D, bool w_f16) {
 }
 
 void launch_ar_mlp_fused(const MlpFusedArgs& g, hipStream_t s) {
+    MlpFusedArgs ga = g;
     BG_REQUIRE(mlp_fused_supported(g.M, g.D, g.w_f16 != 0), "ar_mlp_fused: unsupported shape M=%d D=%d (or a device with fewer CUs than workgroups)", g.M, g.D);
     BG_REQUIRE(g.A && g.ln_w && g.ln_cs && g.ln_ds && g.Wup && g.Wdn && g.hidden && g.C && g.sync && g.err && g.lda % 4 == 0, "ar_mlp_fused: missing operand");
+    static const int acq_env = getenv("BEVGEN_MLPF_ACQ") ? atoi(getenv("BEVGEN_MLPF_ACQ")) : 1;
+    ga.acq = acq_env;
     const dim3 grid(4 * g.D / 16);
     // work = algorithmic bytes: both weight matrices once + rows in, hidden out and back, partial planes out
     ProfScope prof(PROF_GEMM_SKINNY, 8.0 * g.D * g.D * (g.w_f16 ? 2 : 4) + ((double)g.M * g.D + 2.0 * g.M * 4 * g.D + (double)MLP_FUSED_PLANES * g.M * g.D) * sizeof(float), s, true);
     if (g.w_f16) {
-        if (prof.attached()) hipExtLaunchKernelGGL(ar_mlp_fused_kernel<1>, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, g);
-        else hipLaunchKernelGGL(ar_mlp_fused_kernel<1>, grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (prof.attached()) hipExtLaunchKernelGGL(ar_mlp_fused_kernel<1>, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, ga);
+        else hipLaunchKernelGGL(ar_mlp_fused_kernel<1>, grid, dim3(SF_WAVES * 64), 0, s, ga);
     } else {
-        if (prof.attached()) hipExtLaunchKernelGGL(ar_mlp_fused_kernel<0>, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, g);
-        else hipLaunchKernelGGL(ar_mlp_fused_kernel<0>, grid, dim3(SF_WAVES * 64), 0, s, g);
+        if (prof.attached()) hipExtLaunchKernelGGL(ar_mlp_fused_kernel<0>, grid, dim3(SF_WAVES * 64), 0, s, prof.ev_a(), prof.ev_b(), 0, ga);
+        else hipLaunchKernelGGL(ar_mlp_fused_kernel<0>, grid, dim3(SF_WAVES * 64), 0, s, ga);
     }
     LAUNCH_CHECK();
 }

@@ -254,6 +254,26 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
 #pragma unroll
     for (int s = 0; s < S; ++s)
         if (s < nk) { issue_a_half(s, 0); issue_a_half(s, 1); issue_b(s); }
+    // Folded LayerNorm, consumer side (GemmArgs::ln_in_*): (mean, rstd) of this lane's TI rows from the producer's per-32-column (sum, sum of squares) pairs, added in fp64
+    // in group order (the two lane halves of a row take the even / odd groups, one exchange at the end: deterministic).  Done HERE, in the shadow of the first tiles' DMA
+    // latency, and parked in LDS behind the stage ring (4 KiB, this wave's own slots: the throughput instantiation has no VGPR to carry four values through its main loop).
+    float* ln_slot = reinterpret_cast<float*>(smem_g + S * STAGE_H) + (wave * TI * 32 + r) * 2;
+    if (MODE == MODE_PLAIN && g.ln_in_stats) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int m = min(m0 + wm * WROWS + i * 32 + r, g.M - 1);
+            const float2* st = reinterpret_cast<const float2*>(g.ln_in_stats) + m;
+            double s1 = 0.0, s2 = 0.0;
+            for (int gi = h; gi < g.ln_in_groups; gi += 2) {
+                const float2 v = st[(long)gi * g.ln_rows];
+                s1 += (double)v.x; s2 += (double)v.y;
+            }
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            const double mean = s1 / (double)g.ln_in_count;
+            const double var = fmax(s2 / (double)g.ln_in_count - mean * mean, 0.0);
+            if (h == 0) *reinterpret_cast<float2*>(ln_slot + i * 64) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)g.ln_eps)));
+        }
+    }
     wait_tiles<DMA, S - 1>(nk - 1);   // tile 0 landed; the other tiles of the prologue stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -317,6 +337,28 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     }
     for (; kt < nk; ++kt) body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
 
+    // ---- folded LayerNorm, consumer side: LN(x) W^T = rstd (x (W o gamma)^T - mean cs) applied to the tile sums in place, so that every epilogue below sees the projection
+    // of the normalised rows (it is linear in the sums: alpha, bias, activation and residual follow unchanged)
+    if (MODE == MODE_PLAIN && g.ln_in_stats) {
+        float ln_mean[TI], ln_rstd[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) { const float2 mr = *reinterpret_cast<const float2*>(ln_slot + i * 64); ln_mean[i] = mr.x; ln_rstd[i] = mr.y; }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int n = min(n0 + wn * WCOLS + j * 32 + 8 * qq + 4 * h, g.N - 4);   // (columns past N feed accumulator columns no epilogue stores)
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(g.ln_in_cs + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = qq * 4 + e;
+                        accM[i][j][q] = ln_rstd[i] * ((accM[i][j][q] + accC[i][j][q] * kGLoInv) - ln_mean[i] * cs[e]);
+                        accC[i][j][q] = 0.f;
+                    }
+                }
+    }
     // ---- epilogue.  The MFMAs were issued with the operands swapped (B fragment first), so the accumulators hold the TRANSPOSED 32x32
     // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
@@ -450,10 +492,13 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
         // wave's MFMA column tile j = 0 holds 32 `x` columns and j = 1 the 32 matching `gate` columns; the product leaves as ONE [M, N/2] matrix
         // (half the bytes of the raw projection, and the separate GEGLU pass over [M, N] disappears: its LayerNorm half runs on the result).
         float* C = g.C;
+        _Float16* Pp = reinterpret_cast<_Float16*>(g.ln_out_planes);   // folded LayerNorm, producer side: raw planes + per-(row, 32 columns) statistics instead of fp32 C
+        unsigned bad = 0;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
-            if (m >= g.M) continue;
+            const int mc = min(m, g.M - 1);
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int o = (n0 >> 1) + wn * 32 + 8 * qq + 4 * h;   // output column: this tile's 64 outputs start at n0 / 2
@@ -465,9 +510,31 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                     const float gt = (accM[i][1][q] + accC[i][1][q] * kGLoInv) * g.alpha;
                     v[e] = gt * gelu_erf(xa);
                 }
-                if (C) *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + o) = v;
+                if (Pp) {
+                    // 16-byte plane stores: the lane halves of a row hold neighbouring 4-column groups - the lower half stores the hi parts of the pair's 8 columns,
+                    // the upper half the lo parts (one exchange of two registers; the layernorm kernel's store shape)
+                    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                    s2 += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+                    half4_t hi4, lo4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hi4[e] = split_hi(v[e]); lo4[e] = split_lo(v[e], hi4[e]); }
+                    guard_half4(hi4, bad);
+                    const uint2 hw = __builtin_bit_cast(uint2, hi4), lw = __builtin_bit_cast(uint2, lo4);
+                    const uint2 send = h ? hw : lw;
+                    const uint2 recv = make_uint2(__float_as_uint(xor32(__uint_as_float(send.x))), __float_as_uint(xor32(__uint_as_float(send.y))));
+                    const uint4 out = h ? make_uint4(recv.x, recv.y, lw.x, lw.y) : make_uint4(hw.x, hw.y, recv.x, recv.y);
+                    const int c8 = (n0 >> 1) + wn * 32 + 8 * qq;   // first of the pair's 8 columns
+                    if (m < g.M) *reinterpret_cast<uint4*>(Pp + (long)m * 2 * g.ln_out_ld + (c8 >> 5) * 64 + (c8 & 31) + (h ? 32 : 0)) = out;
+                } else if (m < g.M && C) {
+                    *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + o) = v;
+                }
+            }
+            if (Pp) {   // (uniform: every lane takes part in the exchange)
+                s1 += xor32(s1); s2 += xor32(s2);
+                if (h == 0 && m < g.M) reinterpret_cast<float2*>(g.ln_out_stats)[(long)((n0 >> 6) + wn) * g.ln_rows + mc] = make_float2(s1, s2);
             }
         }
+        if (bad) status_raise(g.status, BG_ST_F16_RANGE);
         return;
     }
     if (KS && ksl > 1) {   // raw tile sums of this k slice; launch_splitk_reduce adds the slices in order and applies the epilogue
@@ -491,6 +558,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     }
     float* C = g.C;
     const float* Rp = g.R;
+    unsigned ln_bad = 0;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!Rp || (reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
 #pragma unroll
@@ -498,6 +566,9 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
         const int m = m0 + wm * WROWS + i * 32 + r;
         if (m >= g.M) continue;
         const float bm = g.bias_m ? g.bias_m[m] : 0.f;
+        float ln_s1[TJ], ln_s2[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) { ln_s1[j] = 0.f; ln_s2[j] = 0.f; }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
 #pragma unroll
@@ -521,6 +592,24 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                     }
                     f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
                     *reinterpret_cast<f32x4*>(cp) = o;
+                    if (MODE == MODE_PLAIN && g.ln_out_planes) {
+                        // folded LayerNorm, producer side (the residual-stream projections): besides the fp32 row the residual needs, the raw (hi, lo) planes the next
+                        // projection reads and this lane's share of the row's (sum, sum of squares) over the 32 columns of MFMA tile j (completed below)
+                        ln_s1[j] += (v[0] + v[1]) + (v[2] + v[3]);
+                        ln_s2[j] += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+                        half4_t hi4, lo4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hi4[e] = split_hi(v[e]); lo4[e] = split_lo(v[e], hi4[e]); }
+                        guard_half4(hi4, ln_bad);
+                        // 16-byte stores: the lane halves of a row hold neighbouring 4-column groups; the lower half stores the hi parts of the pair's 8 columns, the upper
+                        // half the lo parts (both halves of a row are active together: m depends on lane & 31 only; the launcher guarantees N % 8 == 0)
+                        const uint2 hw = __builtin_bit_cast(uint2, hi4), lw = __builtin_bit_cast(uint2, lo4);
+                        const uint2 send = h ? hw : lw;
+                        const uint2 recv = make_uint2(__float_as_uint(xor32(__uint_as_float(send.x))), __float_as_uint(xor32(__uint_as_float(send.y))));
+                        const uint4 pk = h ? make_uint4(recv.x, recv.y, lw.x, lw.y) : make_uint4(hw.x, hw.y, recv.x, recv.y);
+                        const int c8 = n - 4 * h;
+                        *reinterpret_cast<uint4*>(reinterpret_cast<_Float16*>(g.ln_out_planes) + (long)m * 2 * g.ln_out_ld + (c8 >> 5) * 64 + (c8 & 31) + (h ? 32 : 0)) = pk;
+                    }
                     if (CONV && g.gn_part) {
                         // GroupNorm statistics of the output tensor: this lane's 4 consecutive channels of its row, summed over the 32 rows (lanes) of the half -
                         // one (sum, sum of squares) pair per (32 rows, 4 channels).  The launcher guarantees whole tiles (every lane here, no tail), so the DPP row sums
@@ -537,8 +626,14 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
                         if (n + e < g.N) cp[e] = v[e] + (Rp ? Rp[(long)m * g.ldr + n + e] : 0.f);
                 }
             }
+            if (MODE == MODE_PLAIN && g.ln_out_planes) {   // the row's pair for the 32 columns of MFMA tile j: the two lane halves hold 16 columns each
+                const float t1 = ln_s1[j] + xor32(ln_s1[j]), t2 = ln_s2[j] + xor32(ln_s2[j]);
+                const int grp = (n0 + wn * WCOLS + j * 32) >> 5;
+                if (h == 0 && grp * 32 < g.N) reinterpret_cast<float2*>(g.ln_out_stats)[(long)grp * g.ln_rows + m] = make_float2(t1, t2);
+            }
         }
     }
+    if (MODE == MODE_PLAIN && ln_bad) status_raise(g.status, BG_ST_F16_RANGE);
 }
 
 void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
@@ -576,6 +671,14 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     if (g.epi == EPI_MUSE_Q)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");
+    if (g.ln_in_stats)
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_in_cs && g.ln_in_groups > 0 && g.ln_in_count > 0 && g.ln_rows >= g.M && g.N % 4 == 0 && g.ksplit <= 1,
+                   "gemm_split_glds: bad folded-LayerNorm consumer arguments (groups=%d count=%d rows=%d N=%d ksplit=%d)", g.ln_in_groups, g.ln_in_count, g.ln_rows, g.N, g.ksplit);
+    if (g.ln_out_planes)
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_out_stats && g.ln_rows >= g.M && g.ln_out_ld % 32 == 0 && g.ksplit <= 1 &&
+                       (g.epi == EPI_GEGLU ? g.ln_out_ld * 2 >= g.N : (g.epi == 0 && g.ln_out_ld >= g.N && g.N % 32 == 0 && (g.ldc & 3) == 0 && (!g.R || (g.ldr & 3) == 0) &&
+                                                                        (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.R || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0))),
+                   "gemm_split_glds: bad folded-LayerNorm producer arguments (ld=%d N=%d epi=%d)", g.ln_out_ld, g.N, g.epi);
     g.tile_band = 4;   // band height of the XCD-aware tile order (measured optimum for 256 x 128 tiles)
     static const int band_env = getenv("BEVGEN_GEMM_BAND") ? atoi(getenv("BEVGEN_GEMM_BAND")) : 0;   // A/B switch (tools/ab.sh m env BEVGEN_GEMM_BAND=2,4,8)
     if (band_env > 0) g.tile_band = band_env;
@@ -629,37 +732,37 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
     dim3 grid(cdiv(g.N, GBN), cdiv(rows, tbm), g.ksplit);
-    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16);
+    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16) + (g.ln_in_stats ? 4096 : 0);   // (+ the folded LayerNorm's per-row (mean, rstd) slots)
     static std::atomic<bool> attr_set[kMaxDevices];
     const int dslot = device_slot();
     if (!attr_set[dslot].load(std::memory_order_acquire)) {
 #define BG_SET(K, BYTES) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2 + 4096);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2 + 4096);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3>), 3 * 384 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2 + 4096);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2 + 4096);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), 2 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1, 1>), 4 * 192 * 2 * GBK * 2);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
 #undef BG_SET
         attr_set[dslot].store(true, std::memory_order_release);
     }

@@ -42,8 +42,12 @@ struct MuseLayer {
     void* null_self = nullptr;      // split-precision mode: prepared null key / value of the self-attention ([k_hi|k_lo|v_hi|v_lo][H][64] halves, owned)
     float* ff_w1_geglu = nullptr;   // split-precision mode: [2 Fpad, D] rows ordered for the fused GEGLU epilogue (owned)
     float* to_qkv_self = nullptr;   // split-precision mode: to_q | to_kv of the self-attention as one [3 H 64, D] matrix (owned): one projection with the EPI_MUSE_QKV epilogue
-    // LayerNorm folded into the GEMMs (split-precision mode, GemmArgs::ln_*): colsum[n] = sum_k gamma_k W[n,k] of every consumer projection, gamma of the
-    // feed-forward's inner LayerNorm padded with zeros to Fpad (owned)
+    // LayerNorm folded across the GEMMs around it (split-precision mode, fp32 weights; GemmArgs::ln_*): W o gamma of every consumer projection (owned; registered as split
+    // weights) and cs[n] = sum_k gamma_k W[n][k].  w4 = the feed-forward down-projection behind the inner LayerNorm (gamma = .2.3.gamma, zero beyond F); qkv / q_self /
+    // kv_self = the self-attention projections behind norm.gamma of module 0; q_cross behind module 1's; w1 = the GEGLU up-projection behind .2.0.gamma
+    float *fold_w4 = nullptr, *fold_w4_cs = nullptr;
+    float *fold_qkv = nullptr, *fold_qkv_cs = nullptr, *fold_q_self = nullptr, *fold_q_self_cs = nullptr, *fold_kv_self = nullptr, *fold_kv_self_cs = nullptr;
+    float *fold_q_cross = nullptr, *fold_q_cross_cs = nullptr, *fold_w1 = nullptr, *fold_w1_cs = nullptr;
 };
 
 struct ArLayer {

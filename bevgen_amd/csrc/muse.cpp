@@ -25,7 +25,23 @@ struct MuseWs {
     float *x = nullptr, *xn = nullptr, *qraw = nullptr, *kvraw = nullptr, *Q = nullptr, *Ks = nullptr, *Vs = nullptr, *att = nullptr, *h = nullptr, *g = nullptr;
     float* attn_ws = nullptr; int attn_ks = 1;   // key-split self-attention of the low-latency path (pick_attn_ksplit): partial rows of the key ranges
     float* kpart = nullptr;   // split-K partial tiles of the narrow (N = D) projections when the batch is too small to fill the chip (low-latency path)
+    float *stats_d = nullptr, *stats_f = nullptr;   // folded LayerNorms: per-(32 columns, row) (sum, sum of squares) of the residual rows [D / 32][rows][2] / of the GEGLU rows [Fpad / 32][rows][2]
 };
+
+// LayerNorm folded across the GEMMs around it (GemmArgs::ln_*; needs the fold constants of bevgen_finalize: split-precision mode with fp32 weights).
+//   0  the LayerNorm kernels of rounds 1-5 everywhere
+//   1  the feed-forward's INNER LayerNorm (over F = 2730 columns, the widest pass: 3.3 % of the sixteen-scene step) disappears: the GEGLU epilogue writes raw planes +
+//      row statistics INSTEAD of its fp32 result (no extra bytes), the down-projection multiplies by W4 o gamma and applies rstd (acc - mean cs)
+//   2  all four LayerNorms of a layer (the residual-stream projections then write planes + statistics BESIDES their fp32 row)
+//   3  (default) 2 on the low-latency path (one or two scenes: every removed launch is a dependent ~5 us kernel + its ramp), 1 otherwise
+// $BEVGEN_LN_FOLD pins it (A/B runs, tests).
+int ln_fold_level(const Ctx& c, long rows) {
+    const char* e = getenv("BEVGEN_LN_FOLD");   // (read per forward, not cached: the tests switch it inside one process)
+    const int env = e ? atoi(e) : 3;
+    if (c.muse.empty() || !c.muse[0].fold_w4) return 0;
+    if (env == 3) return rows <= 3072 ? 2 : 1;
+    return std::max(0, std::min(env, 2));
+}
 
 // Low-latency path (one or two scenes per call, scripts/interactive_editing.py:273-277): a [rows, D] x [D, D] projection is only cdiv(rows, 128) * D / 128 tiles -
 // 96 workgroups at one six-view scene, on 256 CUs.  Its k range is cut into slices until the grid covers the chip; the slices' partial tiles are added in a fixed
@@ -77,6 +93,7 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
         const int ks = pick_attn_ksplit((long)cdiv(c.N, 256) * c.H * B, c.NkS_pad / 32);
         if (ks > 1) f += (size_t)attn_split_ws_floats(B, c.H, c.N, ks);
     }   // split-K partial tiles (small batches only)
+    f += rows * (size_t)(2 * (c.D / 32) + 2 * (c.Fpad / 32) + 4);   // folded-LayerNorm row statistics
     return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256;
 }
 
@@ -89,20 +106,35 @@ void gemm(const float* A, int lda, const float* W, int ldb, float* C, int ldc, i
 }
 
 // same with A given as interleaved (hi, lo) f16 planes [M][lda/32][2][32] (split-precision mode: the producer kernel wrote them)
-void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s, float* kpart = nullptr) {
+// folded-LayerNorm roles of a projection (GemmArgs::ln_*): `in` = it consumes raw planes + the statistics of `in_groups` 32-column groups over `in_count` real columns
+// (B must then be the W o gamma matrix, cs its row sums); `out_planes` = it produces raw planes + statistics of its own output rows
+struct LnFold {
+    const float* in_stats = nullptr; const float* in_cs = nullptr; int in_groups = 0, in_count = 0;
+    void* out_planes = nullptr; float* out_stats = nullptr; int out_ld = 0;
+};
+void set_fold(GemmArgs& g, const LnFold* f, int rows) {
+    if (!f) return;
+    g.ln_in_stats = f->in_stats; g.ln_in_cs = f->in_cs; g.ln_in_groups = f->in_groups; g.ln_in_count = f->in_count;
+    g.ln_out_planes = f->out_planes; g.ln_out_stats = f->out_stats; g.ln_out_ld = f->out_ld;
+    g.ln_rows = rows; g.ln_eps = 1e-5f;
+}
+
+void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s, float* kpart = nullptr,
+                 const LnFold* fold = nullptr) {
     GemmArgs g;
     g.A_hi = reinterpret_cast<const uint16_t*>(Aplanes); g.A_lo = g.A_hi + 32;
     g.B = W; g.C = C; g.R = R;
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
-    if (kpart && N <= 1024) { g.ksplit = pick_ksplit(M, N, K); g.kpart = kpart; }   // the workspace holds KSPLIT_MAX slices of [rows, D]
+    if (kpart && N <= 1024 && !fold) { g.ksplit = pick_ksplit(M, N, K); g.kpart = kpart; }   // the workspace holds KSPLIT_MAX slices of [rows, D] (a folded projection keeps its
+    set_fold(g, fold, M);                                                                      // epilogue: the split-K reduce kernel has none of it)
     launch_gemm(g, s);
 }
 
 // to_q projection with the query preparation (l2norm, q_scale, hi/lo split, head-major layout) fused into the GEMM epilogue
 void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, int D, hipStream_t s, float* kpart = nullptr,
-                   float* qraw = nullptr) {
-    if (kpart && qraw && H * 64 <= 1024 && pick_ksplit((long)B * Nq, H * 64, D) > 1) {
+                   float* qraw = nullptr, const LnFold* fold = nullptr) {
+    if (!fold && kpart && qraw && H * 64 <= 1024 && pick_ksplit((long)B * Nq, H * 64, D) > 1) {
         // small batch: the projection split over K into qraw, then the query preparation as its own (tiny) kernel
         gemm_planes(Aplanes, lda, W, D, qraw, H * 64, B * Nq, H * 64, D, nullptr, 0, s, kpart);
         launch_muse_q_prep_split(qraw, q_scale, Qh, Ql, B, H, Nq, 8.0f * kLog2e, s);
@@ -115,6 +147,7 @@ void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_
     g.lda = lda; g.ldb = D; g.ldc = H * 64;
     g.epi = EPI_MUSE_Q; g.epi_scale = q_scale; g.epi_hi = Qh; g.epi_lo = Ql; g.epi_rows = Nq; g.epi_heads = H;
     g.epi_post = 8.0f * kLog2e;   // sim = 8 q.k (muse_net:150) in the base-2 domain of the split attention kernel
+    set_fold(g, fold, B * Nq);
     launch_gemm(g, s);
 }
 
@@ -149,6 +182,8 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.kpart = std::max(pick_ksplit(w.rows, D, D), pick_ksplit(w.rows, D, c.Fpad)) > 1 ? a.get<float>((size_t)KSPLIT_MAX * w.rows * D) : nullptr;
     w.attn_ks = pick_attn_ksplit((long)cdiv(c.N, 256) * H * B, c.NkS_pad / 32);
     w.attn_ws = w.attn_ks > 1 ? a.get<float>((size_t)attn_split_ws_floats(B, H, c.N, w.attn_ks)) : nullptr;
+    w.stats_d = a.get<float>((size_t)w.rows * 2 * (D / 32));
+    w.stats_f = a.get<float>((size_t)w.rows * 2 * (c.Fpad / 32));
     HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
     HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
 
@@ -194,19 +229,29 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
 // one transformer pass over the current ids: leaves LayerNorm(x) (= `embed`, muse_net:202) in w.xn
 void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
     const auto& g = c.cfg;
-    // (LayerNorm folded into the GEMMs around it was built in round 3, token-exact, and measured slower than the LayerNorm kernels it replaces - 10.12 -> 9.86 scenes/s,
-    // profiles/r03_ab_ln_fold.txt, EXPERIMENTS.md; the code path was removed in round 4)
+    // (Round 3 built a first LayerNorm fold - producers wrote (row x gamma) planes + per-group (mean, M2), a merge kernel per LayerNorm - token-exact and SLOWER, 10.12 ->
+    // 9.86 scenes/s, profiles/r03_ab_ln_fold.txt; removed in round 4.  Round 6's form (ln_fold_level above) has no merge launch - the consumer adds the group sums itself, in the
+    // shadow of its first DMA - no gamma in the producer (it sits in W o gamma), and the inner LayerNorm's producer writes planes INSTEAD of its fp32 result.)
     const std::string p = "transformer.";
     const int D = c.D, H = c.H, B = w.B, N = c.N;
     const int rows = (int)w.rows;
     launch_token_embed(ids, c.pf(p + "token_emb.weight"), w.img, c.pf(p + "pos_emb.weight"), w.x, B, N, D, g.vocab_size + 1, s);
+    const bool split = g.precision == BEVGEN_PRECISION_F16X3;
+    const int fold = split ? ln_fold_level(c, rows) : 0;
+    // fold == 2: the residual-stream projections (to_out of both attention modules, the feed-forward's down-projection) write, besides the fp32 row, the raw planes of the
+    // row into w.xn and its statistics into w.stats_d: the next projection multiplies them by W o gamma.  `x_planes_ready`: w.xn / w.stats_d hold the current w.x
+    bool x_planes_ready = false;
+    LnFold prod_x;   // producer role of a residual-stream projection
+    prod_x.out_planes = w.xn; prod_x.out_stats = w.stats_d; prod_x.out_ld = D;
     for (int i = 0; i < g.num_layers; ++i) {
         const MuseLayer& l = c.muse[i];
         // ---- self attention
         // split-precision mode: every GEMM input is produced directly as (hi, lo) f16 planes (same bytes as the fp32 buffer they replace)
-        const bool split = g.precision == BEVGEN_PRECISION_F16X3;
         if (split) {
-            launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            LnFold cons_x;   // consumer role behind a LayerNorm over the D residual columns
+            cons_x.in_stats = w.stats_d; cons_x.in_groups = D / 32; cons_x.in_count = D;
+            const bool f0 = fold == 2 && x_planes_ready;   // (layer 0 reads the embedding: no projection produced it - its first LayerNorm stays a kernel)
+            if (!f0) launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
             // to_q and to_kv read the same LayerNorm planes (muse_net:126-132): ONE projection over the concatenated weight, query / key / value preparation in its
             // epilogue ($BEVGEN_QKV_MERGE=0: the two launches of rounds 2-4, for A/B runs)
             // Measured (same box, profiles/r05_ab_qkv_merge*.txt): one scene 161.9 -> 160.4 ms (two small-problem launches become one), sixteen scenes 10.31 -> 10.21
@@ -214,13 +259,17 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             // merged only on the low-latency path.  $BEVGEN_QKV_MERGE = 0 never, 2 always
             static const int qkv_merge = getenv("BEVGEN_QKV_MERGE") ? atoi(getenv("BEVGEN_QKV_MERGE")) : 1;
             const bool merged = l.to_qkv_self && (qkv_merge == 2 || (qkv_merge == 1 && rows <= 3072));
-            if (!merged) gemm_planes_q(w.xn, D, l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw);
+            if (!merged) {
+                cons_x.in_cs = l.fold_q_self_cs;
+                gemm_planes_q(w.xn, D, f0 ? l.fold_q_self : l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw,
+                              f0 ? &cons_x : nullptr);
+            }
             {   // to_kv with the key / value preparation in its epilogue: k planes [B, H, NkS_pad, 64], v planes transposed [B, H, 64, NkS_pad]
                 const size_t kvS_ = (size_t)B * H * c.NkS_pad * 64;
                 _Float16 *Kp = reinterpret_cast<_Float16*>(w.Ks), *Vp = reinterpret_cast<_Float16*>(w.Vs);
                 GemmArgs gk;
                 gk.A_hi = reinterpret_cast<const uint16_t*>(w.xn); gk.A_lo = gk.A_hi + 32;
-                gk.B = merged ? l.to_qkv_self : l.to_kv[0];
+                gk.B = merged ? (f0 ? l.fold_qkv : l.to_qkv_self) : (f0 ? l.fold_kv_self : l.to_kv[0]);
                 gk.M = rows; gk.N = (merged ? 3 : 2) * D; gk.K = D; gk.lda = D; gk.ldb = D; gk.ldc = gk.N;
                 gk.epi = merged ? EPI_MUSE_QKV : EPI_MUSE_KV;
                 gk.epi_scale = l.k_scale[0]; gk.epi_hi = Kp; gk.epi_lo = Kp + kvS_; gk.epi_hi2 = Vp; gk.epi_lo2 = Vp + kvS_;
@@ -229,6 +278,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
                     gk.epi_qh = w.Q; gk.epi_ql = reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D; gk.epi_qscale = l.q_scale[0];
                     gk.epi_post = 8.0f * kLog2e;   // sim = 8 q.k (muse_net:150) in the base-2 domain of the split attention kernel
                 }
+                if (f0) { cons_x.in_cs = merged ? l.fold_qkv_cs : l.fold_kv_self_cs; set_fold(gk, &cons_x, rows); }
                 launch_gemm(gk, s);
             }
         } else {
@@ -260,12 +310,15 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         a.ldbias = c.ldS; a.bias_head_stride = 0; a.scale = 8.0f;
         a.o_bstride = (long)N * D; a.o_qstride = D; a.o_hstride = 64;
         if (!split) launch_attention(a, s);
-        if (split) gemm_planes(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s, w.kpart);
-        else gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);  // x = to_out(att) + x
+        if (split) gemm_planes(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr);   // x = to_out(att) + x
+        else gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);
         // ---- cross attention
         if (split) {
-            launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            gemm_planes_q(w.xn, D, l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw);
+            LnFold cons_x;
+            cons_x.in_stats = w.stats_d; cons_x.in_groups = D / 32; cons_x.in_count = D; cons_x.in_cs = l.fold_q_cross_cs;
+            if (fold != 2) launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm_planes_q(w.xn, D, fold == 2 ? l.fold_q_cross : l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw,
+                          fold == 2 ? &cons_x : nullptr);
         } else {
             launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
             gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
@@ -286,23 +339,34 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         }
         // ---- feed forward
         if (split) {
-            gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s, w.kpart);
-            launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
+            gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr);
+            if (fold != 2) launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
             if (l.ff_w1_geglu) {
-                // GEGLU in the up-projection's epilogue: h = gate * gelu(x) as [rows, Fpad] (pad columns exactly 0), then the LayerNorm half on its own
+                // GEGLU in the up-projection's epilogue: h = gate * gelu(x) as [rows, Fpad] (pad columns exactly 0), then the LayerNorm half on its own - or (fold >= 1)
+                // folded away: the epilogue writes the raw planes of h and its row statistics, the down-projection multiplies by W4 o gamma
                 GemmArgs ge;
                 ge.A_hi = reinterpret_cast<const uint16_t*>(w.xn); ge.A_lo = ge.A_hi + 32;
-                ge.B = l.ff_w1_geglu; ge.C = w.h;
+                ge.B = fold == 2 ? l.fold_w1 : l.ff_w1_geglu; ge.C = w.h;
                 ge.M = rows; ge.N = 2 * c.Fpad; ge.K = D;
                 ge.lda = D; ge.ldb = D; ge.ldc = c.Fpad;
                 ge.epi = EPI_GEGLU;
+                LnFold fg;
+                if (fold == 2) { fg.in_stats = w.stats_d; fg.in_cs = l.fold_w1_cs; fg.in_groups = D / 32; fg.in_count = D; }
+                if (fold >= 1) { fg.out_planes = w.g; fg.out_stats = w.stats_f; fg.out_ld = c.Fpad; }
+                if (fold >= 1) set_fold(ge, &fg, rows);
                 launch_gemm(ge, s);
-                launch_layernorm_planes(w.h, c.Fpad, l.ff_g3, nullptr, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+                if (fold == 0) launch_layernorm_planes(w.h, c.Fpad, l.ff_g3, nullptr, w.g, c.Fpad, rows, c.F, 1e-5f, s);
             } else {
                 gemm_planes(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
                 launch_geglu_layernorm_planes(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
             }
-            gemm_planes(w.g, c.Fpad, l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s, w.kpart);
+            LnFold fd;   // the down-projection: consumer of the inner LayerNorm (fold >= 1), producer for the next layer's first LayerNorm (fold == 2, not behind the last layer)
+            if (fold >= 1 && l.ff_w1_geglu) { fd.in_stats = w.stats_f; fd.in_cs = l.fold_w4_cs; fd.in_groups = c.Fpad / 32; fd.in_count = c.F; }
+            const bool prod_next = fold == 2 && i + 1 < g.num_layers;
+            if (prod_next) { fd.out_planes = w.xn; fd.out_stats = w.stats_d; fd.out_ld = D; }
+            const bool any = fd.in_stats || fd.out_planes;
+            gemm_planes(w.g, c.Fpad, fd.in_stats ? l.fold_w4 : l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s, w.kpart, any ? &fd : nullptr);
+            x_planes_ready = prod_next;
         } else {
             gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
             launch_layernorm(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);

@@ -169,6 +169,27 @@ void launch_round_to_f16(float* w, void* h, long n, hipStream_t s) {
     LAUNCH_CHECK();
 }
 
+// Consumer-side constants of a LayerNorm folded into the projection behind it (GemmArgs::ln_in_*): Wg = W o gamma (columns scaled; columns >= Kg - the zero padding of a
+// padded matrix - stay 0) and cs[n] = sum_k Wg[n][k] in fp64.  One wave per row.
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const float* __restrict__ W, const float* __restrict__ gamma, float* __restrict__ Wg, float* __restrict__ cs, int N,
+                                                             int K, int Kg) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    double c = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float v = k < Kg ? W[(long)n * K + k] * gamma[k] : 0.f;
+        Wg[(long)n * K + k] = v;
+        c += (double)v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) cs[n] = (float)c;
+}
+void launch_ln_fold_weight(const float* W, const float* gamma, float* Wg, float* cs, int N, int K, int Kg, hipStream_t s) {
+    hipLaunchKernelGGL(ln_fold_weight_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, gamma, Wg, cs, N, K, Kg);
+    LAUNCH_CHECK();
+}
+
 // Row order of the GEGLU up-projection weight for the fused epilogue (EPI_GEGLU): W [2F, D] (rows 0..F-1 = x, F..2F-1 = gate, muse_net:74) ->
 // Wo [2 Fpad, D], 64-row groups: group (t, wn) = [x rows 64t + 32wn .. +31 | gate rows of the same 32 outputs]; rows of outputs >= F are zero
 __global__ void geglu_weight_order_kernel(const float* __restrict__ W, float* __restrict__ Wo, int F, int Fpad, int D) {

@@ -51,6 +51,10 @@ CASES: Dict[str, Case] = {
     # leave the O(1-10) range every N(0, 0.02) fixture lives in; the f16 hi / lo splits of precision = 'f16x3' must still give the reference's tokens
     "m_tiny_heavy": Case("m_tiny_heavy", "m", lambda: presets.tiny_route_m(3, legacy=False), 1234, 8, 2, heavy=31),
     "a_tiny_heavy": Case("a_tiny_heavy", "a", lambda: presets.tiny_route_a(3, block=16), 1234, 9, 2, heavy=37),
+    # the smallest Route-M shapes on which the GEGLU epilogue and the folded LayerNorms of the HIP path engage (F = int(dim 8 / 3) a multiple of 64: dim 192 -> F 512),
+    # with the reference initialisation and with heavy tails (the fold multiplies RAW residual rows by W o gamma and subtracts mean x column sums: cancellation is the risk)
+    "m_fold": Case("m_fold", "m", lambda: presets.route_m(3, num_layers=2, dim=192, heads=3, vocab=64, cam_res=(64, 64), cam_latent_res=(4, 4), bev_latent_res=(4, 4)), 1234, 10, 2),
+    "m_fold_heavy": Case("m_fold_heavy", "m", lambda: presets.route_m(3, num_layers=2, dim=192, heads=3, vocab=64, cam_res=(64, 64), cam_latent_res=(4, 4), bev_latent_res=(4, 4)), 1234, 11, 2, heavy=61),
 }
 
 
@@ -123,7 +127,9 @@ def maskgit_noise(case: Case, cfg, seed: int = 5):
 VQ_TINY = dict(dd=presets.VQ_DDCONFIG_TINY, n_embed=64, embed_dim=64, seed=99, n_images=3)
 # the released first-stage decoder at full size (f16: ch 128, ch_mult [1,1,2,2,4], 256x256, codebook 1024 x 256, configs/model/stage_2.yaml:36-55)
 VQ_FULL = dict(dd=presets.VQ_DDCONFIG_F16, n_embed=1024, embed_dim=256, seed=99, n_images=1)
-VQ_TINY_HEAVY = dict(dd=presets.VQ_DDCONFIG_TINY, n_embed=64, embed_dim=64, seed=99, n_images=2, heavy=41)   # vq_tiny with heavy_tail (nin_shortcut / conv_in / norm gains)
+VQ_TINY_HEAVY = dict(dd=presets.VQ_DDCONFIG_TINY, n_embed=64, embed_dim=64, seed=99, n_images=2, heavy=41)   # vq_tiny with heavy_tail (nin_shortcut / conv_in / norm gains x 30-100):
+# the un-normalised residual tensors between its two nin_shortcut convolutions pass 65504 - the f16x3 mode must REFUSE this checkpoint (BEVGEN_STATUS_F16_RANGE), fp32 runs it
+VQ_TINY_HEAVY_MILD = dict(dd=presets.VQ_DDCONFIG_TINY, n_embed=64, embed_dim=64, seed=99, n_images=2, heavy=43, lo=6.0, hi=16.0)   # outliers x 6-16: inside the f16 range, pixels within 1e-3
 VQ_TINY_SEG = dict(dd=dict(presets.VQ_DDCONFIG_TINY, in_channels=7, out_ch=7), n_embed=64, embed_dim=64, seed=77, n_images=2)  # BEV cond stage (7 Argoverse classes)
 
 

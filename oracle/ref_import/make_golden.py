@@ -383,12 +383,12 @@ def golden_vq():
     save("vq_tiny", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd, **enc)
 
 
-def golden_vq_heavy():
+def golden_vq_heavy(v=None, name="vq_tiny_heavy"):
     """vq_tiny with trained-like heavy-tailed weights (cases.heavy_tail: outlier channels x 30-100 in the GroupNorm gains, the nin_shortcut 1x1 convolutions - which
     run on UN-normalised tensors - and conv_in): decode by the imported reference, asserted against the restatement."""
-    v = cases.VQ_TINY_HEAVY
+    v = v or cases.VQ_TINY_HEAVY
     dd = v["dd"]
-    sd = cases.heavy_tail(cases.vq_state_dict(dd, v["n_embed"], v["embed_dim"], v["seed"], with_encoder=True), v["heavy"])
+    sd = cases.heavy_tail(cases.vq_state_dict(dd, v["n_embed"], v["embed_dim"], v["seed"], with_encoder=True), v["heavy"], lo=v.get("lo", 30.0), hi=v.get("hi", 100.0))
     lat = dd["resolution"] // 2 ** (len(dd["ch_mult"]) - 1)
     vq = RM.build_ref_vqmodel(dd, v["n_embed"], v["embed_dim"], sd, (dd["resolution"],) * 2, (lat, lat))
     g = torch.Generator().manual_seed(43)
@@ -399,7 +399,7 @@ def golden_vq_heavy():
         xd = stubs.import_reference().util.denormalize_tensor(xr, keep_tensor=True)
     xo = R.vq_decode_ids(sd, dd, ids, (lat, lat), denorm=False)
     assert rel(xo, xr) < 2e-5, rel(xo, xr)
-    save("vq_tiny_heavy", ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd, raw_absmax=np.array(float(xr.abs().max())))
+    save(name, ids=ids.to(torch.int16), pixels_raw=xr, pixels_denorm=xd, raw_absmax=np.array(float(xr.abs().max())))
 
 
 def golden_vq_rect():
@@ -506,6 +506,7 @@ def main():
     if want("vq_heavy"):
         print("vq_heavy")
         golden_vq_heavy()
+        golden_vq_heavy(cases.VQ_TINY_HEAVY_MILD, "vq_tiny_heavy_mild")
     if want("vq_rect"):
         print("vq_rect")
         golden_vq_rect()
