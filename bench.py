@@ -482,8 +482,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     sync = (lambda: None) if DRY_RUN else torch.cuda.synchronize
     Event = _CpuEvent if DRY_RUN else torch.cuda.Event
+    numa = None
     if not DRY_RUN:
         torch.cuda.set_device(local_rank)
+        from bevgen_amd.parallel import bind_to_gpu_numa_node
+
+        numa = bind_to_gpu_numa_node(local_rank)   # one rank = one GPU: keep its host thread on the GPU's NUMA node (launch jitter shows at 0.8 ms per replayed decode step)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -617,7 +621,7 @@ def main():
         "data": "synthetic" if not DRY_RUN else "DRY RUN: stub context on CPU, control flow only - no performance meaning",
         "config": {"workload": f"BASELINE configs[1]: Route M MaskGit, {args.cams}x256x256, batch {args.batch} scenes/GPU, 18 iterations, + VQGAN decode to uint8",
                    "global_batch": n_gpus * args.batch, "parallelism": f"scene-parallel x{n_gpus} (RCCL gather of uint8 pixels)", "precision_mode": args.precision},
-        "rccl_world_size": n_gpus, "per_rank_ms_per_step": parts["per_rank_ms_per_step"],
+        "rccl_world_size": n_gpus, "per_rank_ms_per_step": parts["per_rank_ms_per_step"], "host_numa_binding_rank0": numa,
         "ms_per_maskgit_iteration": float(np.mean(parts["generate"])) / args.timesteps,
         "vqgan_decode_ms_per_scene": float(np.mean(parts["vq_decode"])) / args.batch,
         "gather_ms_per_step": float(np.mean(parts["gather"])),

@@ -254,24 +254,16 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
 #pragma unroll
     for (int s = 0; s < S; ++s)
         if (s < nk) { issue_a_half(s, 0); issue_a_half(s, 1); issue_b(s); }
-    // Folded LayerNorm, consumer side (GemmArgs::ln_in_*): (mean, rstd) of this lane's TI rows from the producer's per-32-column (sum, sum of squares) pairs, added in fp64
-    // in group order (the two lane halves of a row take the even / odd groups, one exchange at the end: deterministic).  Done HERE, in the shadow of the first tiles' DMA
-    // latency, and parked in LDS behind the stage ring (4 KiB, this wave's own slots: the throughput instantiation has no VGPR to carry four values through its main loop).
+    // Folded LayerNorm, consumer side (GemmArgs::ln_in_*): (mean, rstd) of this lane's TI rows (launch_ln_stats_finalize merged the producer's group sums) - requested
+    // HERE, in the shadow of the first tiles' DMA latency, and parked in LDS behind the stage ring (this wave's own slots: the throughput instantiation has no VGPR to
+    // carry four values through its main loop).
     float* ln_slot = reinterpret_cast<float*>(smem_g + S * STAGE_H) + (wave * TI * 32 + r) * 2;
     if (MODE == MODE_PLAIN && g.ln_in_stats) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = min(m0 + wm * WROWS + i * 32 + r, g.M - 1);
-            const float2* st = reinterpret_cast<const float2*>(g.ln_in_stats) + m;
-            double s1 = 0.0, s2 = 0.0;
-            for (int gi = h; gi < g.ln_in_groups; gi += 2) {
-                const float2 v = st[(long)gi * g.ln_rows];
-                s1 += (double)v.x; s2 += (double)v.y;
-            }
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            const double mean = s1 / (double)g.ln_in_count;
-            const double var = fmax(s2 / (double)g.ln_in_count - mean * mean, 0.0);
-            if (h == 0) *reinterpret_cast<float2*>(ln_slot + i * 64) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)g.ln_eps)));
+            const float2 mr = reinterpret_cast<const float2*>(g.ln_in_stats)[m];
+            if (h == 0) *reinterpret_cast<float2*>(ln_slot + i * 64) = mr;
         }
     }
     wait_tiles<DMA, S - 1>(nk - 1);   // tile 0 landed; the other tiles of the prologue stay in flight
@@ -364,6 +356,8 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
     if constexpr (TJ == 2) {   // the fused epilogues and the split-K partial store assume 64-column wave patches
+    // (a width that is not a multiple of 128 - dim 192: three heads - leaves the last tile's second wave without columns: its 64-column patch is not a head / an x|gate pair)
+    if (MODE == MODE_PLAIN && g.epi != EPI_PLAIN && n0 + wn * 64 >= g.N) return;
     const bool qkv = MODE == MODE_PLAIN && g.epi == EPI_MUSE_QKV;
     if (g.epi == EPI_MUSE_Q || (qkv && n0 + wn * 64 < g.epi_heads * 64)) {
         // Route M query preparation fused into the to_q projection (muse_net:132-137; replaces muse_q_prep_split): the wave's 64 columns are
@@ -672,8 +666,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");
     if (g.ln_in_stats)
-        BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_in_cs && g.ln_in_groups > 0 && g.ln_in_count > 0 && g.ln_rows >= g.M && g.N % 4 == 0 && g.ksplit <= 1,
-                   "gemm_split_glds: bad folded-LayerNorm consumer arguments (groups=%d count=%d rows=%d N=%d ksplit=%d)", g.ln_in_groups, g.ln_in_count, g.ln_rows, g.N, g.ksplit);
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_in_cs && g.N % 4 == 0 && g.ksplit <= 1, "gemm_split_glds: bad folded-LayerNorm consumer arguments (N=%d ksplit=%d)", g.N, g.ksplit);
     if (g.ln_out_planes)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_out_stats && g.ln_rows >= g.M && g.ln_out_ld % 32 == 0 && g.ksplit <= 1 &&
                        (g.epi == EPI_GEGLU ? g.ln_out_ld * 2 >= g.N : (g.epi == 0 && g.ln_out_ld >= g.N && g.N % 32 == 0 && (g.ldc & 3) == 0 && (!g.R || (g.ldr & 3) == 0) &&

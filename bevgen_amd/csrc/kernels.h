@@ -80,18 +80,18 @@ struct GemmArgs {
     // LayerNorm folded across two LDS-DMA GEMMs (Route M, muse_net:62-69: gamma-only LayerNorm, beta is a zero buffer), no pass over the activation in between:
     //   PRODUCER (ln_out_planes != null; EPI_GEGLU, or the plain epilogue): the output rows leave (also / instead of C) as the RAW (hi, lo) planes [M][ln_out_ld / 32][hi | lo]
     //     the consumer reads, plus per (row, 32 output columns) the pair (sum, sum of squares) in ln_out_stats [ln_out_ld / 32][ln_rows][2] - fp32 over 32 values
-    //   CONSUMER (ln_in_stats != null; plain / EPI_MUSE_Q / _KV / _QKV / EPI_GEGLU): B holds W o gamma (columns scaled at finalize), A the raw planes; every workgroup adds
-    //     its rows' ln_in_groups pairs in fp64 (mean, var = S2 / n - mean^2 over ln_in_count real columns), and  LN(x) W^T = rstd (x (W o gamma)^T - mean cs),
-    //     cs[n] = sum_k gamma_k W[n][k] (ln_in_cs), is applied to the tile sums before the rest of the epilogue
+    //   launch_ln_stats_finalize: one thread per row adds the row's pairs in fp64, in group order -> (mean, rstd) [rows][2] (reads 8 bytes per 32 elements of the activation)
+    //   CONSUMER (ln_in_stats != null = that (mean, rstd) array; plain / EPI_MUSE_Q / _KV / _QKV / EPI_GEGLU): B holds W o gamma (columns scaled at finalize), A the raw
+    //     planes;  LN(x) W^T = rstd (x (W o gamma)^T - mean cs),  cs[n] = sum_k gamma_k W[n][k] (ln_in_cs), is applied to the tile sums before the rest of the epilogue
     void* ln_out_planes = nullptr;
     float* ln_out_stats = nullptr;
     int ln_out_ld = 0;
     const float* ln_in_stats = nullptr;
     const float* ln_in_cs = nullptr;
-    int ln_in_groups = 0, ln_in_count = 0;
-    int ln_rows = 0;                  // row stride of both statistics arrays (the whole problem's rows: a row-split launch keeps indexing by absolute row)
-    float ln_eps = 1e-5f;
+    int ln_rows = 0;                  // row stride of the producer's statistics array (the whole problem's rows: a row-split launch keeps indexing by absolute row)
 };
+// (sum, sum of squares) per (32 columns, row) [groups][rows][2] -> (mean, rstd) per row [rows][2]; `count` real columns (the zero padding of a padded row adds nothing to either sum)
+void launch_ln_stats_finalize(const float* group_sums, float* row_stats, int rows, int groups, int count, float eps, hipStream_t s);
 // W [N, K] -> Wg[n][k] = W[n][k] * gamma[k] (k < Kg, else 0 / W's own padding) and cs[n] = sum_k Wg[n][k] (fp64 accumulation): the consumer-side constants of a folded LayerNorm
 void launch_ln_fold_weight(const float* W, const float* gamma, float* Wg, float* cs, int N, int K, int Kg, hipStream_t s);
 void launch_gemm(const GemmArgs& g, hipStream_t stream);

@@ -26,6 +26,7 @@ struct MuseWs {
     float* attn_ws = nullptr; int attn_ks = 1;   // key-split self-attention of the low-latency path (pick_attn_ksplit): partial rows of the key ranges
     float* kpart = nullptr;   // split-K partial tiles of the narrow (N = D) projections when the batch is too small to fill the chip (low-latency path)
     float *stats_d = nullptr, *stats_f = nullptr;   // folded LayerNorms: per-(32 columns, row) (sum, sum of squares) of the residual rows [D / 32][rows][2] / of the GEGLU rows [Fpad / 32][rows][2]
+    float* rowstat = nullptr;                       // ... merged to (mean, rstd) per row [rows][2] by launch_ln_stats_finalize
 };
 
 // LayerNorm folded across the GEMMs around it (GemmArgs::ln_*; needs the fold constants of bevgen_finalize: split-precision mode with fp32 weights).
@@ -109,14 +110,14 @@ void gemm(const float* A, int lda, const float* W, int ldb, float* C, int ldc, i
 // folded-LayerNorm roles of a projection (GemmArgs::ln_*): `in` = it consumes raw planes + the statistics of `in_groups` 32-column groups over `in_count` real columns
 // (B must then be the W o gamma matrix, cs its row sums); `out_planes` = it produces raw planes + statistics of its own output rows
 struct LnFold {
-    const float* in_stats = nullptr; const float* in_cs = nullptr; int in_groups = 0, in_count = 0;
+    const float* in_stats = nullptr; const float* in_cs = nullptr;   // consumer: per-row (mean, rstd) [rows][2] and the column sums of W o gamma
     void* out_planes = nullptr; float* out_stats = nullptr; int out_ld = 0;
 };
 void set_fold(GemmArgs& g, const LnFold* f, int rows) {
     if (!f) return;
-    g.ln_in_stats = f->in_stats; g.ln_in_cs = f->in_cs; g.ln_in_groups = f->in_groups; g.ln_in_count = f->in_count;
+    g.ln_in_stats = f->in_stats; g.ln_in_cs = f->in_cs;
     g.ln_out_planes = f->out_planes; g.ln_out_stats = f->out_stats; g.ln_out_ld = f->out_ld;
-    g.ln_rows = rows; g.ln_eps = 1e-5f;
+    g.ln_rows = rows;
 }
 
 void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s, float* kpart = nullptr,
@@ -184,6 +185,7 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.attn_ws = w.attn_ks > 1 ? a.get<float>((size_t)attn_split_ws_floats(B, H, c.N, w.attn_ks)) : nullptr;
     w.stats_d = a.get<float>((size_t)w.rows * 2 * (D / 32));
     w.stats_f = a.get<float>((size_t)w.rows * 2 * (c.Fpad / 32));
+    w.rowstat = a.get<float>((size_t)w.rows * 2);
     HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
     HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
 
@@ -249,9 +251,10 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         // split-precision mode: every GEMM input is produced directly as (hi, lo) f16 planes (same bytes as the fp32 buffer they replace)
         if (split) {
             LnFold cons_x;   // consumer role behind a LayerNorm over the D residual columns
-            cons_x.in_stats = w.stats_d; cons_x.in_groups = D / 32; cons_x.in_count = D;
+            cons_x.in_stats = w.rowstat;
             const bool f0 = fold == 2 && x_planes_ready;   // (layer 0 reads the embedding: no projection produced it - its first LayerNorm stays a kernel)
             if (!f0) launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
             // to_q and to_kv read the same LayerNorm planes (muse_net:126-132): ONE projection over the concatenated weight, query / key / value preparation in its
             // epilogue ($BEVGEN_QKV_MERGE=0: the two launches of rounds 2-4, for A/B runs)
             // Measured (same box, profiles/r05_ab_qkv_merge*.txt): one scene 161.9 -> 160.4 ms (two small-problem launches become one), sixteen scenes 10.31 -> 10.21
@@ -315,8 +318,9 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         // ---- cross attention
         if (split) {
             LnFold cons_x;
-            cons_x.in_stats = w.stats_d; cons_x.in_groups = D / 32; cons_x.in_count = D; cons_x.in_cs = l.fold_q_cross_cs;
+            cons_x.in_stats = w.rowstat; cons_x.in_cs = l.fold_q_cross_cs;
             if (fold != 2) launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
+            else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
             gemm_planes_q(w.xn, D, fold == 2 ? l.fold_q_cross : l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw,
                           fold == 2 ? &cons_x : nullptr);
         } else {
@@ -341,6 +345,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         if (split) {
             gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr);
             if (fold != 2) launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
+            else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
             if (l.ff_w1_geglu) {
                 // GEGLU in the up-projection's epilogue: h = gate * gelu(x) as [rows, Fpad] (pad columns exactly 0), then the LayerNorm half on its own - or (fold >= 1)
                 // folded away: the epilogue writes the raw planes of h and its row statistics, the down-projection multiplies by W4 o gamma
@@ -351,17 +356,18 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
                 ge.lda = D; ge.ldb = D; ge.ldc = c.Fpad;
                 ge.epi = EPI_GEGLU;
                 LnFold fg;
-                if (fold == 2) { fg.in_stats = w.stats_d; fg.in_cs = l.fold_w1_cs; fg.in_groups = D / 32; fg.in_count = D; }
+                if (fold == 2) { fg.in_stats = w.rowstat; fg.in_cs = l.fold_w1_cs; }
                 if (fold >= 1) { fg.out_planes = w.g; fg.out_stats = w.stats_f; fg.out_ld = c.Fpad; }
                 if (fold >= 1) set_fold(ge, &fg, rows);
                 launch_gemm(ge, s);
                 if (fold == 0) launch_layernorm_planes(w.h, c.Fpad, l.ff_g3, nullptr, w.g, c.Fpad, rows, c.F, 1e-5f, s);
+                else launch_ln_stats_finalize(w.stats_f, w.rowstat, rows, c.Fpad / 32, c.F, 1e-5f, s);
             } else {
                 gemm_planes(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
                 launch_geglu_layernorm_planes(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
             }
             LnFold fd;   // the down-projection: consumer of the inner LayerNorm (fold >= 1), producer for the next layer's first LayerNorm (fold == 2, not behind the last layer)
-            if (fold >= 1 && l.ff_w1_geglu) { fd.in_stats = w.stats_f; fd.in_cs = l.fold_w4_cs; fd.in_groups = c.Fpad / 32; fd.in_count = c.F; }
+            if (fold >= 1 && l.ff_w1_geglu) { fd.in_stats = w.rowstat; fd.in_cs = l.fold_w4_cs; }
             const bool prod_next = fold == 2 && i + 1 < g.num_layers;
             if (prod_next) { fd.out_planes = w.xn; fd.out_stats = w.stats_d; fd.out_ld = D; }
             const bool any = fd.in_stats || fd.out_planes;

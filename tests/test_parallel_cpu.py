@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from bevgen_amd.parallel import gather_scenes, gather_token_ids, shard_range, to_uint8
+from bevgen_amd.parallel import GatherMismatch, gather_scenes, gather_token_ids, parse_cpulist, payload_checksum, shard_range, to_uint8
 
 
 def _free_port():
@@ -68,3 +68,50 @@ def test_gather_world2_gloo():
 def test_single_process_passthrough():
     px = torch.rand(3, 2, 3, 4, 4)
     assert torch.equal(gather_scenes(px, None), to_uint8(px))
+
+
+def _corrupting_worker(rank, world, port, q):
+    """Rank 1's payload is altered AFTER its checksum was taken (stand-in for a block damaged on the way): rank 0 must refuse the gather."""
+    import bevgen_amd.parallel as P
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    px = to_uint8(torch.stack([_scene_pixels(10 + rank)]))
+    if rank == 1:
+        real, intact = P.payload_checksum, px
+        P.payload_checksum = lambda t: real(intact)      # the checksum of the intact block ...
+        px = px.clone()
+        px.view(-1)[7] ^= 0x10                            # ... travels beside a block with one flipped bit
+    try:
+        gather_scenes(px, dist)
+        q.put((rank, "ok"))
+    except GatherMismatch as e:
+        q.put((rank, str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_checksum_catches_a_damaged_block():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_corrupting_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert "ranks [1]" in res[0], res
+    assert res[1] == "ok"
+
+
+def test_payload_checksum_and_cpulist():
+    a = torch.arange(24, dtype=torch.uint8).reshape(2, 3, 4)
+    assert not torch.equal(payload_checksum(a), payload_checksum(a.transpose(1, 2).contiguous()))   # same multiset, different order
+    assert not torch.equal(payload_checksum(a), payload_checksum(torch.zeros_like(a)))
+    assert torch.equal(payload_checksum(a), payload_checksum(a.clone()))
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parse_cpulist("5") == [5] and parse_cpulist("") == []
