@@ -385,10 +385,15 @@ def decode_leg(device, batch, steps, kv_cache="f32", S=1, top_k=None, stochastic
     kv_bytes *= visible_frac     # block-sparse layouts: only the rows of present blocks are algorithmic traffic
     ach *= visible_frac
     step_ach = (kv_bytes + w_bytes) / wall / 1e9
+    # what the fused launch actually streams: this layer's K/V rows (storage bytes, visible blocks only) PLUS its q / k / v weight rows (3 D^2 elements, once per launch, through
+    # the XCD L2s) - the fraction a prologue-bound launch (short or sparse contexts, fp32 K/V) should be judged by next to the SURVEY 8(d) figure, which counts K/V alone
+    qkv_w_bytes = 0.0 if path == "split" else 3.0 * cfg.num_embed * cfg.num_embed * (2 if weights == "f16" else 4) * da["launches"]
+    ach_kvw = (da["work"] * visible_frac + qkv_w_bytes) / (da["ms"] * 1e-3) / 1e9 if da["ms"] > 0 else 0.0
     out = {
         "ms_per_decode_step": wall * 1e3 / steps, "ms_per_decode_step_median": pct(st, 50), "ms_per_decode_step_p99": pct(st, 99), "decode_prefill_ms": prefill_ms,
         "roofline_decode_attention": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                       "frac_by_survey_8d_fp16_bytes": ach / HBM_PEAK_GBS * (2.0 / kvb),   # SURVEY 8(d) counts 98 304 n bytes per sequence-step (fp16 K/V) whatever the storage
+                                      "frac_kv_plus_qkv_weight_bytes": ach_kvw / HBM_PEAK_GBS,
 
                                       "traffic": pmc_traffic("ar_attn_fused_kernel") if kv_cache == "f32" and weights == "f32" and S == 1 else None, "kernel": "ar_attn_fused_kernel (ln1 + q/k/v projection + decode attention in one launch; achieved = K/V bytes / WHOLE kernel time)",
                                       # (no bandwidth is derived from this window any more: since the K/V staging, the leading pieces of every wave's key walk are requested
@@ -784,8 +789,8 @@ def main():
     def dshort(d):
         ra, rs = d["roofline_decode_attention"], d["decode_step_roofline"]
         return {"ms_step": rnd(d["ms_per_decode_step"]), "median": rnd(d["ms_per_decode_step_median"]), "p99": rnd(d["ms_per_decode_step_p99"]),
-                "attn_frac_8d_fp16_bytes": rnd(ra.get("frac_by_survey_8d_fp16_bytes")), "attn_frac_storage_bytes": rnd(ra["frac"]), "attn_avg_us": rnd(ra["avg_us"], 2),
-                "attn_walk_phase_us": rnd(ra["attention_phase"]["us"], 2), "step_frac": rnd(rs["frac"]),
+                "attn_frac_8d_fp16_bytes": rnd(ra.get("frac_by_survey_8d_fp16_bytes")), "attn_frac_storage_bytes": rnd(ra["frac"]), "attn_frac_kv_plus_qkv_w": rnd(ra.get("frac_kv_plus_qkv_weight_bytes")),
+                "attn_avg_us": rnd(ra["avg_us"], 2), "attn_walk_phase_us": rnd(ra["attention_phase"]["us"], 2), "step_frac": rnd(rs["frac"]),
                 **({"attn_trace_avg_us": rnd(ra["kernel_trace"]["avg_us"], 2), "attn_trace_frac_8d_fp16_bytes": rnd(ra["kernel_trace"]["frac_by_survey_8d_fp16_bytes"])}
                    if isinstance(ra.get("kernel_trace"), dict) and "avg_us" in ra["kernel_trace"] else {})}
 
