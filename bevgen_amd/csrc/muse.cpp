@@ -31,16 +31,18 @@ struct MuseWs {
 
 // LayerNorm folded across the GEMMs around it (GemmArgs::ln_*; needs the fold constants of bevgen_finalize: split-precision mode with fp32 weights).
 //   0  the LayerNorm kernels of rounds 1-5 everywhere
-//   1  the feed-forward's INNER LayerNorm (over F = 2730 columns, the widest pass: 3.3 % of the sixteen-scene step) disappears: the GEGLU epilogue writes raw planes +
-//      row statistics INSTEAD of its fp32 result (no extra bytes), the down-projection multiplies by W4 o gamma and applies rstd (acc - mean cs)
-//   2  all four LayerNorms of a layer (the residual-stream projections then write planes + statistics BESIDES their fp32 row)
-//   3  (default) 2 on the low-latency path (one or two scenes: every removed launch is a dependent ~5 us kernel + its ramp), 1 otherwise
-// $BEVGEN_LN_FOLD pins it (A/B runs, tests).
+//   1  (default) the feed-forward's INNER LayerNorm (over F = 2730 columns, the widest pass: 3.3 % of the sixteen-scene step) disappears: the GEGLU epilogue writes raw
+//      planes + per-32-column row sums INSTEAD of its fp32 result (no extra bytes), a one-thread-per-row kernel merges the sums (8 bytes read per 32 elements), the
+//      down-projection multiplies by W4 o gamma and applies rstd (acc - mean cs)
+//   2  all four LayerNorms of a layer (the residual-stream projections then write planes + sums BESIDES their fp32 row)
+// Measured, same box, scenes/s at 16 / 2 / 1 scenes per call (profiles/r06_ab_ln_fold.txt): level 0 10.29 / 7.88 / 6.04, level 1 **10.53 / 7.98 / 6.06**, level 2 10.10 / 7.85 /
+// 5.95 - the extra plane stores of the residual-stream epilogues cost more than the LayerNorm passes they replace (round 3 found the same with another design), at
+// every batch size; level 2 stays as a tested switch.  $BEVGEN_LN_FOLD pins the level (A/B runs, tests).
 int ln_fold_level(const Ctx& c, long rows) {
     const char* e = getenv("BEVGEN_LN_FOLD");   // (read per forward, not cached: the tests switch it inside one process)
-    const int env = e ? atoi(e) : 3;
+    const int env = e ? atoi(e) : 1;
+    (void)rows;
     if (c.muse.empty() || !c.muse[0].fold_w4) return 0;
-    if (env == 3) return rows <= 3072 ? 2 : 1;
     return std::max(0, std::min(env, 2));
 }
 
