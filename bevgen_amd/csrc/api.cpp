@@ -255,11 +255,12 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float*
         g.A = a; g.B = w; g.C = c; g.R = residual; g.bias_n = bias;
         g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N; g.ldr = N;
         g.act = act_gelu ? ACT_GELU : ACT_NONE;
-        if (skinny == 5) skinny = 3;   // 5 = mode 3 with the k range split over three slices (the low-latency path of small batches); needs M small enough for 128-row tiles
-        const bool ksplit3 = skinny_in == 5;
+        if (skinny == 5 || skinny == 6) skinny = 3;   // 5 = mode 3 with the k range split over three slices (the low-latency path of small batches); needs M small enough for
+        const bool ksplit3 = skinny_in == 5;           // 128-row tiles.  6 = mode 3 in its stream-K form (gemm_split_glds_sk_kernel), whatever the shape
+        const bool stream_k = skinny_in == 6;
         if (skinny == 4 || skinny == 3 || skinny == 2) {  // split-precision paths with on-the-fly operand splits (tests / roofline probes): 3 = LDS-DMA kernel, 4 = the same for
                                                           // an f16-representable w (two MFMAs per product: the weights='f16' mode's kernel)
-            ctx->arena.reserve(((size_t)N * K + (size_t)M * K) * 4 + (ksplit3 ? (size_t)3 * M * N * 4 : 0) + 4096);
+            ctx->arena.reserve(((size_t)N * K + (size_t)M * K) * 4 + (ksplit3 ? (size_t)3 * M * N * 4 : 0) + (stream_k ? gemm_sk_ws_bytes() : 0) + 8192);
             ctx->arena.reset();
             uint16_t* bp = reinterpret_cast<uint16_t*>(ctx->arena.alloc((size_t)N * K * 4));
             launch_split_weight(w, bp, (long)N * K, (hipStream_t)stream);
@@ -270,6 +271,11 @@ int bevgen_op_gemm(bevgen_ctx* ctx, const float* a, const float* w, const float*
                 launch_split_weight(a, ap, (long)M * K, (hipStream_t)stream);
                 g.A_hi = ap; g.A_lo = ap + 32;
                 if (ksplit3) { g.ksplit = 3; g.kpart = ctx->arena.get<float>((size_t)3 * M * N); }
+                if (stream_k) {
+                    g.sk_ws = ctx->arena.alloc(gemm_sk_ws_bytes());
+                    HIP_CHECK(hipMemsetAsync(g.sk_ws, 0, 1024 * sizeof(unsigned), (hipStream_t)stream));
+                    g.sk_epoch = 1; g.sk_force = true;
+                }
                 launch_gemm_split_glds(g, (hipStream_t)stream);
             } else {
                 launch_gemm_split(g, (hipStream_t)stream);

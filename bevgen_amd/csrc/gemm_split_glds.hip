@@ -74,8 +74,13 @@ __device__ __forceinline__ void wait_tiles(int n) {
 // both the MFMAs and the DMA instructions of a wave and give every SIMD a second wave to run while one issues.
 // TJ: 32-column MFMA tiles per wave along N (2 = the wave's 64 columns are one head / one x|gate pair, which the fused epilogues rely on; 1 = 32x32 patches, plain
 // epilogue only: the 64-row block of a lone small problem on eight waves instead of four)
-template <int MODE, int WM, int S, bool W16 = false, bool KS = false, int TI = 2, int TJ = 2>
-__global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
+// The body of one block tile: tile (tx, ty), k-tiles [kt_first, kt_first + nk).  ksl / kz: the split-K slice geometry of the KS instantiations (1 / 0 otherwise).
+// sk_role (stream-K launches, gemm_split_glds_sk_kernel below): 0 = the whole k range of the tile is here: the normal epilogue; 1 = a PART of the tile's k range whose last
+// part lies with a later workgroup: the raw tile sums go to this workgroup's slot of g.sk_ws and its flag is raised; 2 = the LAST part: the sums of the workgroups
+// sk_first .. blockIdx.x - 1 (ascending k) are added in that order, then the normal epilogue.
+template <int MODE, int WM, int S, bool W16, bool KS, int TI, int TJ>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const int ty, const int kt_first, const int nk, const int ksl, const int kz, const int sk_role,
+                                          const int sk_first, const int tid) {
     constexpr int TBM = WM * 64;                 // block rows
     constexpr int NW = WM * 8 / (TI * TJ);       // waves
     constexpr int WROWS = TI * 32;               // rows of a wave's patch
@@ -87,13 +92,10 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     constexpr int STAGE_H = AREGION + GBN * 2 * GBK;  // halves per stage
     constexpr int DMA = NAJ + NBJ;                    // DMA wave-instructions per k-tile
     extern __shared__ __attribute__((aligned(1024))) _Float16 smem_g[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
-    int tx, ty;
-    if (g.tile_band > 0) xcd_tile_banded(gridDim.x, gridDim.y, g.tile_band, tx, ty);
-    else xcd_tile(gridDim.x, gridDim.y, tx, ty);
     const int n0 = tx * GBN, m0 = ty * TBM + g.m_base;
     const int n0l = n0, m0l = m0;
 
@@ -145,9 +147,6 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
             a_img[j] = img; a_yx[j] = (y << 16) | (rem - y * g.conv_w);
         }
     }
-    // split-K (gridDim.z slices, small-M problems): this block owns k-tiles [kt_first, kt_first + nk)
-    const int nk_all = g.K / GBK, ksl = KS ? (int)gridDim.z : 1, kz = KS ? (int)blockIdx.z : 0;
-    const int kt_first = kz * (nk_all / ksl) + min(kz, nk_all % ksl);
     // DMA of the NEXT k-tile, in pieces (tiles are issued strictly in order)
     int k_issue = kt_first * GBK;
     const int n_img = CONVG ? g.M / (g.conv_h * g.conv_w) : 0;
@@ -249,7 +248,6 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
             for (int j = 0; j < TJ; ++j) accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], accC[i][j], 0, 0, 0);
     };
 
-    const int nk = nk_all / ksl + (kz < nk_all % ksl ? 1 : 0);
     // ---- prologue: tiles 0..S-1 in flight, tile 0 landed, F0 of tile 0 on its way
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -329,6 +327,67 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     }
     for (; kt < nk; ++kt) body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
 
+    // ---- stream-K (gemm_split_glds_sk_kernel): partial tile sums travel through g.sk_ws = [1024 flag words][workgroup slots of NW x TI x TJ x 16 x 64 floats].  Stores and
+    // loads carry sc1 (agent scope: they are performed at the memory side, whatever XCD the two workgroups run on - the protocol tools/gridbar/xchg_probe.hip verified,
+    // variant 1), the flag is an agent-scope atomic holding this launch's epoch.  A workgroup only ever waits for LOWER-indexed ones, which were dispatched no later than
+    // itself and never wait for it: no deadlock even if the grid is not resident at once.  The spin is bounded all the same (the status word reports a timeout).
+    if (MODE == MODE_PLAIN && sk_role != 0) {
+        constexpr int SLOT = NW * TI * TJ * 16 * 64;   // floats per workgroup
+        float* ws = reinterpret_cast<float*>(g.sk_ws) + 1024;
+        unsigned* flags = reinterpret_cast<unsigned*>(g.sk_ws);
+        // slot layout: [wave][tile i][tile j][register quad qq][lane][4]: one 16-byte access per lane and quad, a wave's instruction covers 1 KiB
+        const long lane_off = (long)wave * (TI * TJ * 16 * 64) + lane * 4;
+        if (sk_role == 1) {
+            float* mine = ws + (long)blockIdx.x * SLOT + lane_off;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = accM[i][j][qq * 4 + e] + accC[i][j][qq * 4 + e] * kGLoInv;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(mine + ((i * TJ + j) * 4 + qq) * 256), "v"(v) : "memory");
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (every wave: its stores are acknowledged)
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + blockIdx.x, g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // role 2: wait for the contributors (their partial was the FIRST thing they computed), add their sums in ascending k order, then this workgroup's own (the last k part)
+        if (tid == 0) {
+            const long long t_in = __builtin_amdgcn_s_memrealtime();
+            for (int w = sk_first; w < (int)blockIdx.x; ++w)
+                while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memrealtime() - t_in > 200LL * 1000 * 100) { status_raise(g.status, BG_ST_MLP_BARRIER); break; }   // 200 ms of the 100 MHz clock
+                }
+        }
+        __syncthreads();
+        // own sums first (main + correction accumulators merged: the correction registers are free from here on), then the contributors' added ONTO them from the nearest
+        // k range down to the first - a fixed order; four register quads (4 KiB per wave) in flight at a time: the accumulators leave no room for more
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { accM[i][j][q] += accC[i][j][q] * kGLoInv; accC[i][j][q] = 0.f; }
+        for (int w = (int)blockIdx.x - 1; w >= sk_first; --w) {
+            const float* theirs = ws + (long)w * SLOT + lane_off;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    f32x4 pv[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[qq]) : "v"(theirs + ((i * TJ + j) * 4 + qq) * 256) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]) : : "memory");   // (the values are defined behind the wait)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) accM[i][j][q] += pv[q >> 2][q & 3];
+                }
+        }
+    }
     // ---- folded LayerNorm, consumer side: LN(x) W^T = rstd (x (W o gamma)^T - mean cs) applied to the tile sums in place, so that every epilogue below sees the projection
     // of the normalised rows (it is linear in the sums: alpha, bias, activation and residual follow unchanged)
     if (MODE == MODE_PLAIN && g.ln_in_stats) {
@@ -630,6 +689,62 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     if (MODE == MODE_PLAIN && ln_bad) status_raise(g.status, BG_ST_F16_RANGE);
 }
 
+
+template <int MODE, int WM, int S, bool W16 = false, bool KS = false, int TI = 2, int TJ = 2>
+__global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) void gemm_split_glds_kernel(GemmArgs g) {
+    int tx, ty;
+    if (g.tile_band > 0) xcd_tile_banded(gridDim.x, gridDim.y, g.tile_band, tx, ty);
+    else xcd_tile(gridDim.x, gridDim.y, tx, ty);
+    // split-K (gridDim.z slices, small-M problems): this block owns k-tiles [kt_first, kt_first + nk)
+    const int nk_all = g.K / GBK, ksl = KS ? (int)gridDim.z : 1, kz = KS ? (int)blockIdx.z : 0;
+    const int kt_first = kz * (nk_all / ksl) + min(kz, nk_all % ksl);
+    const int nk = nk_all / ksl + (kz < nk_all % ksl ? 1 : 0);
+    gemm_tile<MODE, WM, S, W16, KS, TI, TJ>(g, tx, ty, kt_first, nk, ksl, kz, 0, 0, (int)threadIdx.x);
+}
+
+// Stream-K form for problems whose tile count does not fill whole rounds of the chip (one or two scenes: 144 / 48 / 258 tiles of 256 x 128 on 256 CUs).  The work is cut
+// into UNITS of one k-tile of one block tile, numbered tile-major / k-minor; gridDim.x persistent workgroups each take a contiguous, equally long range of units.  A range
+// covers at most: the HIGH-k end of one tile (whose low-k part lies with lower-indexed workgroups), some whole tiles, and the LOW-k start of one tile.  The range is walked
+// from its top down: the low-k start first - its raw sums go to the workgroup's slot and its flag is raised EARLY - and the high-k end last: by then the lower-indexed
+// contributors of that tile have long published theirs, and this workgroup (the "owner": it holds the last k part) adds them in ascending k order and runs the fused
+// epilogue.  Sums are added in a fixed order: results are run-to-run identical; they differ from the one-workgroup-per-tile launch only in fp32 association.
+template <int WM, int S, bool W16>
+__global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_sk_kernel(GemmArgs g) {
+    const int nk = g.K / GBK, gx = (g.N + GBN - 1) / GBN;
+    const long U = (long)g.sk_tiles * nk, G = gridDim.x;
+    const long ub = (long)blockIdx.x * U / G, ue = ((long)blockIdx.x + 1) * U / G;
+    if (ue <= ub) return;
+    for (long t = (ue - 1) / nk; t >= ub / nk; --t) {
+        const int k0 = (int)(max(ub, t * nk) - t * nk), k1 = (int)(min(ue, (t + 1) * nk) - t * nk);
+        int role = 0, first = 0;
+        if (k0 != 0 || k1 != nk) {
+            role = k1 == nk ? 2 : 1;
+            if (role == 2) {   // the contributors: every lower workgroup whose range reaches into this tile
+                first = (int)blockIdx.x;
+                while (first > 0 && (long)first * U / G > t * nk) --first;
+            }
+        }
+        // (the thread index is made opaque per segment: otherwise every per-lane address of the tile body - loop-invariant in this loop - is hoisted out of it and
+        // stays live across the whole body: 528 spilled VGPRs instead of none)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        gemm_tile<MODE_PLAIN, WM, S, W16, false, 2, 2>(g, (int)(t % gx), (int)(t / gx), k0, k1 - k0, 1, 0, role, first, tid);
+        __syncthreads();   // the next segment's first DMA overwrites stages the slowest wave may still be reading
+    }
+}
+
+size_t gemm_sk_ws_bytes() { return 1024 * sizeof(float) + (size_t)256 * (8 * 4 * 16 * 64) * sizeof(float); }   // 1024 flag words + 256 workgroup slots of 128 KiB
+
+// Does the stream-K form pay?  T tiles of 256 x 128 cost ceil(T / 256) rounds of the chip; the form removes the empty part of the last round (and the second launch of a
+// row-split problem) at the price of one partial-tile exchange per workgroup (~3 us) - worth it when at least 15 % of the rounds would be empty and every workgroup still
+// gets a few k-tiles.  One scene (rows 1536): q|k|v 144 tiles (44 % empty), the 1024-wide projections 48 (81 %), the up-projection 258 (50 % of two rounds); two scenes:
+// 288 / 96 / 516; sixteen scenes: 2304 = 9 rounds exactly, 768 = 3, 4128 = 16.1 (its row-split form stays).
+bool gemm_sk_pays(long rows, int N, int K) {
+    const long T = (long)cdiv(rows, 256) * cdiv(N, GBN), rounds = (T + 255) / 256;
+    const double empty = 1.0 - (double)T / (double)(rounds * 256);
+    return T >= 16 && empty >= 0.15 && T * (K / GBK) >= 1024;
+}
+
 void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     GemmArgs g = g_in;
     if (g.mode == MODE_CONV3) {
@@ -672,6 +787,36 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
                        (g.epi == EPI_GEGLU ? g.ln_out_ld * 2 >= g.N : (g.epi == 0 && g.ln_out_ld >= g.N && g.N % 32 == 0 && (g.ldc & 3) == 0 && (!g.R || (g.ldr & 3) == 0) &&
                                                                         (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.R || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0))),
                    "gemm_split_glds: bad folded-LayerNorm producer arguments (ld=%d N=%d epi=%d)", g.ln_out_ld, g.N, g.epi);
+    // ---- stream-K route (the caller provided a workspace: Route M's projections): problems whose 256 x 128 tiles would leave much of their last round of the chip empty
+    static const int sk_env = getenv("BEVGEN_GEMM_SK") ? atoi(getenv("BEVGEN_GEMM_SK")) : 1;   // 0 = never (A/B runs), 2 = whenever a workspace is given (tests)
+    if (g.sk_ws && sk_env && g.mode == MODE_PLAIN && g.ksplit <= 1 && g.m_base == 0 && !g.no_row_split && !g.bias_m &&
+        (sk_env == 2 || g.sk_force || gemm_sk_pays(g.M, g.N, g.K))) {
+        static std::atomic<int> cu_count[kMaxDevices];
+        static std::atomic<bool> sk_attr[kMaxDevices];
+        const int ds = device_slot();
+        int cus = cu_count[ds].load(std::memory_order_acquire);
+        if (cus == 0) {
+            int dev = 0;
+            HIP_CHECK(hipGetDevice(&dev));
+            HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            cu_count[ds].store(cus, std::memory_order_release);
+        }
+        const size_t lds_sk = (size_t)3 * 384 * 2 * GBK * 2 + 4096;
+        if (!sk_attr[ds].load(std::memory_order_acquire)) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_glds_sk_kernel<4, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sk));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_glds_sk_kernel<4, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sk));
+            sk_attr[ds].store(true, std::memory_order_release);
+        }
+        g.sk_tiles = cdiv(g.M, 256) * cdiv(g.N, GBN);
+        const long units = (long)g.sk_tiles * (g.K / GBK);
+        const int G = (int)std::max<long>(1, std::min<long>(std::min(cus, 256), units / 2));   // (at least two k-tiles per workgroup; the workspace holds 256 slots)
+        g.tile_band = 0;
+        ProfScope prof(PROF_GEMM_SMALL, 2.0 * g.M * (double)g.N * g.K, stream);
+        if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_sk_kernel<4, 3, true>), dim3(G), dim3(512), lds_sk, stream, g);
+        else hipLaunchKernelGGL((gemm_split_glds_sk_kernel<4, 3, false>), dim3(G), dim3(512), lds_sk, stream, g);
+        LAUNCH_CHECK();
+        return;
+    }
     g.tile_band = 4;   // band height of the XCD-aware tile order (measured optimum for 256 x 128 tiles)
     static const int band_env = getenv("BEVGEN_GEMM_BAND") ? atoi(getenv("BEVGEN_GEMM_BAND")) : 0;   // A/B switch (tools/ab.sh m env BEVGEN_GEMM_BAND=2,4,8)
     if (band_env > 0) g.tile_band = band_env;

@@ -88,6 +88,12 @@ struct GemmArgs {
     int ln_out_ld = 0;
     const float* ln_in_stats = nullptr;
     const float* ln_in_cs = nullptr;
+    // stream-K launch (gemm_split_glds_sk_kernel): workspace = 1024 flag words (zeroed by the caller once per workspace) + one partial-tile slot of 128 KiB per workgroup
+    // (gemm_sk_ws_bytes); sk_epoch = a value no earlier launch on this workspace used (the flags are never reset: a flag equal to the epoch = "published in THIS launch")
+    void* sk_ws = nullptr;
+    unsigned sk_epoch = 0;
+    int sk_tiles = 0;                 // filled in by the launcher
+    bool sk_force = false;            // take the stream-K form whatever gemm_sk_pays says (operator tests)
     int ln_rows = 0;                  // row stride of the producer's statistics array (the whole problem's rows: a row-split launch keeps indexing by absolute row)
 };
 // (sum, sum of squares) per (32 columns, row) [groups][rows][2] -> (mean, rstd) per row [rows][2]; `count` real columns (the zero padding of a padded row adds nothing to either sum)
@@ -96,6 +102,8 @@ void launch_ln_stats_finalize(const float* group_sums, float* row_stats, int row
 void launch_ln_fold_weight(const float* W, const float* gamma, float* Wg, float* cs, int N, int K, int Kg, hipStream_t s);
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
 void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);
+size_t gemm_sk_ws_bytes();                                // workspace of a stream-K launch (GemmArgs::sk_ws)
+bool gemm_sk_pays(long rows, int N, int K);               // the launcher's rule: does the 256-row tiling leave enough of its last round empty for the stream-K form to win
 
 // Split-precision (3x f16 MFMA, fp32-class accuracy) variant and its weight preparation
 struct SplitPlanes { const uint16_t* hi; const uint16_t* lo; bool lo_zero = false; /* the matrix was rounded to f16: its low plane is all zeros */ };

@@ -27,6 +27,8 @@ struct MuseWs {
     float* kpart = nullptr;   // split-K partial tiles of the narrow (N = D) projections when the batch is too small to fill the chip (low-latency path)
     float *stats_d = nullptr, *stats_f = nullptr;   // folded LayerNorms: per-(32 columns, row) (sum, sum of squares) of the residual rows [D / 32][rows][2] / of the GEGLU rows [Fpad / 32][rows][2]
     float* rowstat = nullptr;                       // ... merged to (mean, rstd) per row [rows][2] by launch_ln_stats_finalize
+    void* sk_ws = nullptr;                          // stream-K workspace of the projections (small batches; flags zeroed in muse_prepare), null = never stream-K
+    unsigned sk_epoch = 0;                          // bumped per projection launch
 };
 
 // LayerNorm folded across the GEMMs around it (GemmArgs::ln_*; needs the fold constants of bevgen_finalize: split-precision mode with fp32 weights).
@@ -56,6 +58,7 @@ int ln_fold_level(const Ctx& c, long rows) {
 // there the launcher's 64-row blocks double the grid without a reduce launch (one-scene down-projection, K = 2752: 37.9 + 7.1 -> 40 us; step 169.9 -> 167.9 ms).  (Round-3 history: with the four-wave
 // block - 12 us + 0.62 us per k-tile - two slices everywhere were the optimum, step 257 -> 241 ms.)
 constexpr int KSPLIT_MAX = 6;
+constexpr long kSkMaxRows = 8192;   // batches up to this many token rows carry a stream-K workspace (gemm_sk_pays decides per projection)
 int ksplit_env() { static const int v = getenv("BEVGEN_KSPLIT") ? atoi(getenv("BEVGEN_KSPLIT")) : 0; return v; }
 int pick_ksplit(long rows, int N, int K) {
     if ((long)cdiv(rows, 256) * cdiv(N, 128) >= 256) return 1;          // the 256-row tiling already fills the chip
@@ -97,7 +100,7 @@ size_t muse_ws_bytes(const Ctx& c, int B) {
         if (ks > 1) f += (size_t)attn_split_ws_floats(B, c.H, c.N, ks);
     }   // split-K partial tiles (small batches only)
     f += rows * (size_t)(2 * (c.D / 32) + 2 * (c.Fpad / 32) + 4);   // folded-LayerNorm row statistics
-    return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256;
+    return f * sizeof(float) + (64 + 4 * c.cfg.num_layers) * 256 + (rows <= kSkMaxRows ? gemm_sk_ws_bytes() + 256 : 0);
 }
 
 void gemm(const float* A, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s) {
@@ -115,6 +118,7 @@ struct LnFold {
     const float* in_stats = nullptr; const float* in_cs = nullptr;   // consumer: per-row (mean, rstd) [rows][2] and the column sums of W o gamma
     void* out_planes = nullptr; float* out_stats = nullptr; int out_ld = 0;
 };
+void set_sk(GemmArgs& g, MuseWs* w);
 void set_fold(GemmArgs& g, const LnFold* f, int rows) {
     if (!f) return;
     g.ln_in_stats = f->in_stats; g.ln_in_cs = f->in_cs;
@@ -123,21 +127,24 @@ void set_fold(GemmArgs& g, const LnFold* f, int rows) {
 }
 
 void gemm_planes(const void* Aplanes, int lda, const float* W, int ldb, float* C, int ldc, int M, int N, int K, const float* R, int ldr, hipStream_t s, float* kpart = nullptr,
-                 const LnFold* fold = nullptr) {
+                 const LnFold* fold = nullptr, MuseWs* sk = nullptr) {
     GemmArgs g;
     g.A_hi = reinterpret_cast<const uint16_t*>(Aplanes); g.A_lo = g.A_hi + 32;
     g.B = W; g.C = C; g.R = R;
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
-    if (kpart && N <= 1024 && !fold) { g.ksplit = pick_ksplit(M, N, K); g.kpart = kpart; }   // the workspace holds KSPLIT_MAX slices of [rows, D] (a folded projection keeps its
-    set_fold(g, fold, M);                                                                      // epilogue: the split-K reduce kernel has none of it)
+    const bool use_sk = sk && gemm_sk_pays(M, N, K);   // (stream-K where it pays: it keeps the fused epilogue and needs no reduce launch)
+    if (kpart && N <= 1024 && !fold && !use_sk) { g.ksplit = pick_ksplit(M, N, K); g.kpart = kpart; }   // the workspace holds KSPLIT_MAX slices of [rows, D] (a folded projection
+    set_fold(g, fold, M);                                                                                // keeps its epilogue: the split-K reduce kernel has none of it)
+    if (use_sk) set_sk(g, sk);
     launch_gemm(g, s);
 }
 
 // to_q projection with the query preparation (l2norm, q_scale, hi/lo split, head-major layout) fused into the GEMM epilogue
 void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_scale, void* Qh, void* Ql, int B, int H, int Nq, int D, hipStream_t s, float* kpart = nullptr,
-                   float* qraw = nullptr, const LnFold* fold = nullptr) {
-    if (!fold && kpart && qraw && H * 64 <= 1024 && pick_ksplit((long)B * Nq, H * 64, D) > 1) {
+                   float* qraw = nullptr, const LnFold* fold = nullptr, MuseWs* sk = nullptr) {
+    const bool use_sk = sk && gemm_sk_pays((long)B * Nq, H * 64, D);
+    if (!fold && !use_sk && kpart && qraw && H * 64 <= 1024 && pick_ksplit((long)B * Nq, H * 64, D) > 1) {
         // small batch: the projection split over K into qraw, then the query preparation as its own (tiny) kernel
         gemm_planes(Aplanes, lda, W, D, qraw, H * 64, B * Nq, H * 64, D, nullptr, 0, s, kpart);
         launch_muse_q_prep_split(qraw, q_scale, Qh, Ql, B, H, Nq, 8.0f * kLog2e, s);
@@ -151,7 +158,14 @@ void gemm_planes_q(const void* Aplanes, int lda, const float* W, const float* q_
     g.epi = EPI_MUSE_Q; g.epi_scale = q_scale; g.epi_hi = Qh; g.epi_lo = Ql; g.epi_rows = Nq; g.epi_heads = H;
     g.epi_post = 8.0f * kLog2e;   // sim = 8 q.k (muse_net:150) in the base-2 domain of the split attention kernel
     set_fold(g, fold, B * Nq);
+    if (use_sk) set_sk(g, sk);
     launch_gemm(g, s);
+}
+
+void set_sk(GemmArgs& g, MuseWs* w) {
+    if (!w || !w->sk_ws) return;
+    g.sk_ws = w->sk_ws;
+    g.sk_epoch = ++w->sk_epoch;
 }
 
 // per-batch constants: embeddings + cross-attention K/V
@@ -188,6 +202,12 @@ void muse_prepare(Ctx& c, MuseWs& w, const int64_t* cond, const float* I_inv, co
     w.stats_d = a.get<float>((size_t)w.rows * 2 * (D / 32));
     w.stats_f = a.get<float>((size_t)w.rows * 2 * (c.Fpad / 32));
     w.rowstat = a.get<float>((size_t)w.rows * 2);
+    w.sk_ws = nullptr;
+    if (w.rows <= kSkMaxRows && g.precision == BEVGEN_PRECISION_F16X3) {
+        w.sk_ws = a.alloc(gemm_sk_ws_bytes());
+        HIP_CHECK(hipMemsetAsync(w.sk_ws, 0, 1024 * sizeof(unsigned), s));   // the flag words: a flag equal to a launch's epoch means "published in this launch"
+        w.sk_epoch = 0;
+    }
     HIP_CHECK(hipMemsetAsync(w.Ks, 0, kvS * sizeof(float), s));  // rows beyond the real keys stay zero
     HIP_CHECK(hipMemsetAsync(w.Vs, 0, kvS * sizeof(float), s));
 
@@ -267,7 +287,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             if (!merged) {
                 cons_x.in_cs = l.fold_q_self_cs;
                 gemm_planes_q(w.xn, D, f0 ? l.fold_q_self : l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw,
-                              f0 ? &cons_x : nullptr);
+                              f0 ? &cons_x : nullptr, &w);
             }
             {   // to_kv with the key / value preparation in its epilogue: k planes [B, H, NkS_pad, 64], v planes transposed [B, H, 64, NkS_pad]
                 const size_t kvS_ = (size_t)B * H * c.NkS_pad * 64;
@@ -284,6 +304,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
                     gk.epi_post = 8.0f * kLog2e;   // sim = 8 q.k (muse_net:150) in the base-2 domain of the split attention kernel
                 }
                 if (f0) { cons_x.in_cs = merged ? l.fold_qkv_cs : l.fold_kv_self_cs; set_fold(gk, &cons_x, rows); }
+                if (gemm_sk_pays(rows, gk.N, gk.K)) set_sk(gk, &w);
                 launch_gemm(gk, s);
             }
         } else {
@@ -315,7 +336,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         a.ldbias = c.ldS; a.bias_head_stride = 0; a.scale = 8.0f;
         a.o_bstride = (long)N * D; a.o_qstride = D; a.o_hstride = 64;
         if (!split) launch_attention(a, s);
-        if (split) gemm_planes(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr);   // x = to_out(att) + x
+        if (split) gemm_planes(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr, &w);   // x = to_out(att) + x
         else gemm(w.att, D, l.to_out[0], D, w.x, D, rows, D, D, w.x, D, s);
         // ---- cross attention
         if (split) {
@@ -324,7 +345,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             if (fold != 2) launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
             else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
             gemm_planes_q(w.xn, D, fold == 2 ? l.fold_q_cross : l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw,
-                          fold == 2 ? &cons_x : nullptr);
+                          fold == 2 ? &cons_x : nullptr, &w);
         } else {
             launch_layernorm(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
             gemm(w.xn, D, l.to_q[1], D, w.qraw, D, rows, D, D, nullptr, 0, s);
@@ -345,7 +366,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         }
         // ---- feed forward
         if (split) {
-            gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr);
+            gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr, &w);
             if (fold != 2) launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
             else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
             if (l.ff_w1_geglu) {
@@ -361,6 +382,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
                 if (fold == 2) { fg.in_stats = w.rowstat; fg.in_cs = l.fold_w1_cs; }
                 if (fold >= 1) { fg.out_planes = w.g; fg.out_stats = w.stats_f; fg.out_ld = c.Fpad; }
                 if (fold >= 1) set_fold(ge, &fg, rows);
+                if (gemm_sk_pays(rows, ge.N, ge.K)) set_sk(ge, &w);
                 launch_gemm(ge, s);
                 if (fold == 0) launch_layernorm_planes(w.h, c.Fpad, l.ff_g3, nullptr, w.g, c.Fpad, rows, c.F, 1e-5f, s);
                 else launch_ln_stats_finalize(w.stats_f, w.rowstat, rows, c.Fpad / 32, c.F, 1e-5f, s);
@@ -373,7 +395,7 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             const bool prod_next = fold == 2 && i + 1 < g.num_layers;
             if (prod_next) { fd.out_planes = w.xn; fd.out_stats = w.stats_d; fd.out_ld = D; }
             const bool any = fd.in_stats || fd.out_planes;
-            gemm_planes(w.g, c.Fpad, fd.in_stats ? l.fold_w4 : l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s, w.kpart, any ? &fd : nullptr);
+            gemm_planes(w.g, c.Fpad, fd.in_stats ? l.fold_w4 : l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s, w.kpart, any ? &fd : nullptr, &w);
             x_planes_ready = prod_next;
         } else {
             gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);

@@ -254,7 +254,7 @@ int bevgen_vq_decode_latents(bevgen_ctx* ctx, const float* d_zq, int n, int lat_
  * Operator-level entry points (parity tests and roofline measurements call the kernels through these)             */
 int bevgen_op_gemm(bevgen_ctx* ctx, const float* d_a, const float* d_w, const float* d_bias, const float* d_residual, float* d_c,
                    int M, int N, int K, int act_gelu, int skinny, void* stream);            /* C = A W^T (+bias)(gelu)(+res); skinny: 0 tiled fp32, 1 M <= 64, 2-4 split-precision
-                                                                                               kernels (tests / probes), 5 = 3 with the k range split over three slices */
+                                                                                               kernels (tests / probes), 5 = 3 with the k range split over three slices, 6 = 3 in its stream-K form */
 /* Decode-step projection (decode_fused.hip): C = act(LayerNorm?(A) W^T + bias) for M <= 64 rows; d_ln_w NULL = no LayerNorm; ksplit > 1 (no LayerNorm, no bias / act):
  * d_c receives the split-K partial sums [ksplit, M, N] that the consumer adds; ksplit 0 = the library's choice for (N, K), returned through *ksplit_out if non-NULL;
  * ksplit -1 (LayerNorm with beta and bias): one K slice, the LayerNorm folded into the product the way the decode step launches ln2 + MLP-up. */

@@ -592,6 +592,31 @@ def test_gemm_split_precision_split_k(gpu_ctx, M, N, K):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 1024, 1024), (1536, 3072, 1024), (1536, 1024, 2752), (1536, 5504, 1024), (3072, 1024, 1024), (300, 384, 192), (1000, 136, 64), (256, 128, 32)])
+def test_gemm_split_precision_stream_k(gpu_ctx, M, N, K):
+    """The stream-K form of the LDS-DMA GEMM (gemm_split_glds_sk_kernel): units of one k-tile of one 256 x 128 tile dealt out evenly over the CUs, partial tiles published
+    through the workspace and added by the workgroup that holds a tile's last k range, fused epilogue there.  The one- and two-scene Route-M shapes (q|k|v, the 1024-wide
+    projections, the down- and up-projection), ragged shapes, and a problem smaller than one tile: same accuracy class as the one-workgroup-per-tile launch, bit-identical
+    run to run, equal to that launch up to fp32 association."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * 3.0
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = F.gelu((a.double() @ w.double().t()) + b.double()) + r.double()
+    from bevgen_amd.runtime import _ptr, _stream
+    da, dw, db, dr = dev(a), dev(w), dev(b), dev(r)
+    outs = {}
+    for mode in (6, 6, 3):
+        out = torch.empty(M, N, device="cuda")
+        gpu_ctx._check(gpu_ctx.lib.bevgen_op_gemm(gpu_ctx._h, _ptr(da), _ptr(dw), _ptr(db), _ptr(dr), _ptr(out), M, N, K, 1, mode, _stream()))
+        outs.setdefault(mode, []).append(out.cpu())
+    gpu_ctx.synchronize()
+    assert rel(outs[6][0].double(), ref) < 2e-6
+    assert torch.equal(outs[6][0], outs[6][1])
+    assert rel(outs[6][0].double(), outs[3][0].double()) < 1e-6
+
+
 @pytest.mark.parametrize("shape", ["2", "8", "16"])
 def test_gemm_small_problem_block_shapes(shape):
     """The LDS-DMA GEMM picks its small-problem block by the grid size (eight waves with 32x64 patches on a four-stage ring when every block has a CU to itself,
