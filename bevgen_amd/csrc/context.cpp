@@ -184,6 +184,7 @@ static void finalize_muse(Ctx& c) {
         expect_shape(c, "token_critic.to_pred.bias", {1});
     }
     const int inner = H * 64;
+    (void)xcd_placement_verified();   // (the device's one-time placement probe of the stream-K projections runs here, never on the sampling path)
     // the Route M workspace (qraw, att, split-K partial tiles) and every projection call size their rows by D: the released model has heads * 64 == dim
     BG_REQUIRE(inner == D, "Route M: num_heads * 64 = %d must equal dim = %d", inner, D);
     c.Fpad = (int)round_up(F, 32);

@@ -1540,6 +1540,8 @@ static bool xcd_placement_ok() {
     return st == 1;
 }
 
+bool xcd_placement_verified() { return xcd_placement_ok(); }
+
 bool mlp_fused_supported(int M, int D, bool w_f16) {
     static const int env = getenv("BEVGEN_MLP_FUSE") ? atoi(getenv("BEVGEN_MLP_FUSE")) : 1;
     if (!env || M < 1 || M > 64 || D != 1024) return false;   // (the K slices per wave - 128 of D, 64 of the XCD's D / 2 - are written out for D = 1024)

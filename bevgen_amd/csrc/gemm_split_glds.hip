@@ -327,10 +327,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     }
     for (; kt < nk; ++kt) body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
 
-    // ---- stream-K (gemm_split_glds_sk_kernel): partial tile sums travel through g.sk_ws = [1024 flag words][workgroup slots of NW x TI x TJ x 16 x 64 floats].  Stores and
-    // loads carry sc1 (agent scope: they are performed at the memory side, whatever XCD the two workgroups run on - the protocol tools/gridbar/xchg_probe.hip verified,
-    // variant 1), the flag is an agent-scope atomic holding this launch's epoch.  A workgroup only ever waits for LOWER-indexed ones, which were dispatched no later than
-    // itself and never wait for it: no deadlock even if the grid is not resident at once.  The spin is bounded all the same (the status word reports a timeout).
+    // ---- stream-K (gemm_split_glds_sk_kernel): partial tile sums travel through g.sk_ws = [1024 flag words][workgroup slots of NW x TI x TJ x 16 x 64 floats].  The
+    // workgroups that share a tile sit on ONE XCD (indices congruent mod 8: the kernel below deals whole tiles to XCDs), so the exchange stays in that XCD's L2 - plain
+    // stores (the vector L1 is write-through: an acknowledged store is in L2), one flag per workgroup holding this launch's epoch (L2 atomic), sc1 loads of the slot (served
+    // by the L2 whatever the reader's L1 holds): the protocol of ar_mlp_fused_kernel.  (First form of this kernel: consecutive workgroups = eight different XCDs, slots
+    // written and read with sc1 at the memory side - 64 MB of exchange traffic per projection, one scene 162 -> 209 ms; profiles/r06_ab_gemm_sk_memside.txt.)
+    // A workgroup only ever waits for LOWER-indexed ones, which were dispatched no later than itself and never wait for it: no deadlock even if the grid is not resident
+    // at once.  The spin is bounded all the same (the status word reports a timeout).
     if (MODE == MODE_PLAIN && sk_role != 0) {
         constexpr int SLOT = NW * TI * TJ * 16 * 64;   // floats per workgroup
         float* ws = reinterpret_cast<float*>(g.sk_ws) + 1024;
@@ -348,7 +351,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = accM[i][j][qq * 4 + e] + accC[i][j][qq * 4 + e] * kGLoInv;
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(mine + ((i * TJ + j) * 4 + qq) * 256), "v"(v) : "memory");
+                        *reinterpret_cast<f32x4*>(mine + ((i * TJ + j) * 4 + qq) * 256) = v;
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (every wave: its stores are acknowledged)
             __syncthreads();
@@ -358,7 +361,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         // role 2: wait for the contributors (their partial was the FIRST thing they computed), add their sums in ascending k order, then this workgroup's own (the last k part)
         if (tid == 0) {
             const long long t_in = __builtin_amdgcn_s_memrealtime();
-            for (int w = sk_first; w < (int)blockIdx.x; ++w)
+            for (int w = sk_first; w < (int)blockIdx.x; w += 8)
                 while (__hip_atomic_load(flags + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) {
                     __builtin_amdgcn_s_sleep(1);
                     if (__builtin_amdgcn_s_memrealtime() - t_in > 200LL * 1000 * 100) { status_raise(g.status, BG_ST_MLP_BARRIER); break; }   // 200 ms of the 100 MHz clock
@@ -373,7 +376,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { accM[i][j][q] += accC[i][j][q] * kGLoInv; accC[i][j][q] = 0.f; }
-        for (int w = (int)blockIdx.x - 1; w >= sk_first; --w) {
+        for (int w = (int)blockIdx.x - 8; w >= sk_first; w -= 8) {
             const float* theirs = ws + (long)w * SLOT + lane_off;
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -710,18 +713,23 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
 // epilogue.  Sums are added in a fixed order: results are run-to-run identical; they differ from the one-workgroup-per-tile launch only in fp32 association.
 template <int WM, int S, bool W16>
 __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_sk_kernel(GemmArgs g) {
+    // workgroup b runs on XCD b % 8 (checked per device: xcd_placement_verified): XCD x takes the whole tiles [x T / 8, (x + 1) T / 8) and its gridDim.x / 8 workgroups
+    // (local index b / 8) cut those tiles' units evenly - every exchange of partial sums stays inside one L2
     const int nk = g.K / GBK, gx = (g.N + GBN - 1) / GBN;
-    const long U = (long)g.sk_tiles * nk, G = gridDim.x;
-    const long ub = (long)blockIdx.x * U / G, ue = ((long)blockIdx.x + 1) * U / G;
+    const int x = blockIdx.x & 7, jl = blockIdx.x >> 3, Gx = gridDim.x >> 3;
+    const long T = g.sk_tiles, tb = x * T / 8, te = (x + 1) * T / 8;
+    const long Ux = (te - tb) * nk, u0 = tb * nk;
+    const long ub = u0 + (long)jl * Ux / Gx, ue = u0 + ((long)jl + 1) * Ux / Gx;
     if (ue <= ub) return;
     for (long t = (ue - 1) / nk; t >= ub / nk; --t) {
         const int k0 = (int)(max(ub, t * nk) - t * nk), k1 = (int)(min(ue, (t + 1) * nk) - t * nk);
         int role = 0, first = 0;
         if (k0 != 0 || k1 != nk) {
             role = k1 == nk ? 2 : 1;
-            if (role == 2) {   // the contributors: every lower workgroup whose range reaches into this tile
-                first = (int)blockIdx.x;
-                while (first > 0 && (long)first * U / G > t * nk) --first;
+            if (role == 2) {   // the contributors: every lower workgroup of this XCD whose range reaches into this tile
+                int fj = jl;
+                while (fj > 0 && u0 + (long)fj * Ux / Gx > t * nk) --fj;
+                first = 8 * fj + x;
             }
         }
         // (the thread index is made opaque per segment: otherwise every per-lane address of the tile body - loop-invariant in this loop - is hoisted out of it and
@@ -789,7 +797,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
                    "gemm_split_glds: bad folded-LayerNorm producer arguments (ld=%d N=%d epi=%d)", g.ln_out_ld, g.N, g.epi);
     // ---- stream-K route (the caller provided a workspace: Route M's projections): problems whose 256 x 128 tiles would leave much of their last round of the chip empty
     static const int sk_env = getenv("BEVGEN_GEMM_SK") ? atoi(getenv("BEVGEN_GEMM_SK")) : 1;   // 0 = never (A/B runs), 2 = whenever a workspace is given (tests)
-    if (g.sk_ws && sk_env && g.mode == MODE_PLAIN && g.ksplit <= 1 && g.m_base == 0 && !g.no_row_split && !g.bias_m &&
+    if (g.sk_ws && sk_env && g.mode == MODE_PLAIN && g.ksplit <= 1 && g.m_base == 0 && !g.no_row_split && !g.bias_m && xcd_placement_verified() &&
         (sk_env == 2 || g.sk_force || gemm_sk_pays(g.M, g.N, g.K))) {
         static std::atomic<int> cu_count[kMaxDevices];
         static std::atomic<bool> sk_attr[kMaxDevices];
@@ -809,7 +817,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
         }
         g.sk_tiles = cdiv(g.M, 256) * cdiv(g.N, GBN);
         const long units = (long)g.sk_tiles * (g.K / GBK);
-        const int G = (int)std::max<long>(1, std::min<long>(std::min(cus, 256), units / 2));   // (at least two k-tiles per workgroup; the workspace holds 256 slots)
+        const int G = (int)std::max<long>(8, std::min<long>(std::min(cus, 256), units / 2)) & ~7;   // (a multiple of 8: whole tiles per XCD; >= two k-tiles per workgroup; 256 slots)
         g.tile_band = 0;
         ProfScope prof(PROF_GEMM_SMALL, 2.0 * g.M * (double)g.N * g.K, stream);
         if (g.b_lo_zero) hipLaunchKernelGGL((gemm_split_glds_sk_kernel<4, 3, true>), dim3(G), dim3(512), lds_sk, stream, g);

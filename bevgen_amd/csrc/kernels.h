@@ -102,6 +102,7 @@ void launch_ln_stats_finalize(const float* group_sums, float* row_stats, int row
 void launch_ln_fold_weight(const float* W, const float* gamma, float* Wg, float* cs, int N, int K, int Kg, hipStream_t s);
 void launch_gemm(const GemmArgs& g, hipStream_t stream);
 void launch_gemm_split_glds(const GemmArgs& g, hipStream_t stream);
+bool xcd_placement_verified();                            // decode_fused.hip: workgroup i of a launch runs on XCD i % 8 on the current device (probed once)
 size_t gemm_sk_ws_bytes();                                // workspace of a stream-K launch (GemmArgs::sk_ws)
 bool gemm_sk_pays(long rows, int N, int K);               // the launcher's rule: does the 256-row tiling leave enough of its last round empty for the stream-K form to win
 
