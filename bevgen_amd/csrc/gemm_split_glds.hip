@@ -378,17 +378,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                 for (int q = 0; q < 16; ++q) { accM[i][j][q] += accC[i][j][q] * kGLoInv; accC[i][j][q] = 0.f; }
         for (int w = (int)blockIdx.x - 8; w >= sk_first; w -= 8) {
             const float* theirs = ws + (long)w * SLOT + lane_off;
+            // half of a contributor's slot in flight at a time (8 KiB per wave: two L2 round trips per contributor; four quads at a time made it sixteen, the whole slot
+            // does not fit beside the accumulators)
+            constexpr int NQ = TI * TJ * 4, HB = NQ >= 8 ? 8 : NQ;
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+            for (int u0 = 0; u0 < NQ; u0 += HB) {
+                f32x4 pv[HB];
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    f32x4 pv[4];
+                for (int u = 0; u < HB; ++u) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[u]) : "v"(theirs + (u0 + u) * 256) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[qq]) : "v"(theirs + ((i * TJ + j) * 4 + qq) * 256) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]) : : "memory");   // (the values are defined behind the wait)
+                for (int u = 0; u < HB; ++u) {
+                    asm volatile("" : "+v"(pv[u]));   // (defined behind the wait)
+                    const int uu = u0 + u;            // = (i TJ + j) 4 + qq
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) accM[i][j][q] += pv[q >> 2][q & 3];
+                    for (int e = 0; e < 4; ++e) accM[uu / (TJ * 4)][(uu / 4) % TJ][(uu & 3) * 4 + e] += pv[u][e];
                 }
+            }
         }
     }
     // ---- folded LayerNorm, consumer side: LN(x) W^T = rstd (x (W o gamma)^T - mean cs) applied to the tile sums in place, so that every epilogue below sees the projection
@@ -750,7 +756,10 @@ size_t gemm_sk_ws_bytes() { return 1024 * sizeof(float) + (size_t)256 * (8 * 4 *
 bool gemm_sk_pays(long rows, int N, int K) {
     const long T = (long)cdiv(rows, 256) * cdiv(N, GBN), rounds = (T + 255) / 256;
     const double empty = 1.0 - (double)T / (double)(rounds * 256);
-    return T >= 16 && empty >= 0.15 && T * (K / GBK) >= 1024;
+    // ... and only while a tile is shared by two or three workgroups (T >= 128): with fewer tiles every tile's last workgroup merges five or more 128 KiB partials while
+    // the others idle - measured slower than the 64-row blocks of the data-parallel launch at every such shape (profiles/r06_ab_gemm_sk_ops.txt)
+    (void)K;
+    return T >= 128 && empty >= 0.15;
 }
 
 void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
