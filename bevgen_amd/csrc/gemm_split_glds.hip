@@ -252,17 +252,38 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
 #pragma unroll
     for (int s = 0; s < S; ++s)
         if (s < nk) { issue_a_half(s, 0); issue_a_half(s, 1); issue_b(s); }
-    // Folded LayerNorm, consumer side (GemmArgs::ln_in_*): (mean, rstd) of this lane's TI rows (launch_ln_stats_finalize merged the producer's group sums) - requested
-    // HERE, in the shadow of the first tiles' DMA latency, and parked in LDS behind the stage ring (this wave's own slots: the throughput instantiation has no VGPR to
-    // carry four values through its main loop).
-    float* ln_slot = reinterpret_cast<float*>(smem_g + S * STAGE_H) + (wave * TI * 32 + r) * 2;
+    // Folded LayerNorm, consumer side (GemmArgs::ln_in_*): (mean, rstd) of this wave's rows, parked in LDS behind the stage ring (the wave's own 64 slots: the throughput
+    // instantiation has no VGPR to carry them through its main loop) - requested HERE, in the shadow of the first tiles' DMA latency.  Either launch_ln_stats_finalize has
+    // merged the producer's group sums (ln_in_stats: large batches - one small kernel per LayerNorm instead of a merge per tile), or this wave merges them itself
+    // (ln_in_gsums: one or two scenes, where every workgroup runs one tile and a launch costs more than the merge): lane l takes row l of the wave's 64 (32-row patches: the
+    // lane halves split the groups by parity), sixteen loads in flight, fp64 sums in a fixed order.
+    float* ln_slot = reinterpret_cast<float*>(smem_g + S * STAGE_H) + wave * 128;   // [64 rows][mean, rstd]
     if (MODE == MODE_PLAIN && g.ln_in_stats) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = min(m0 + wm * WROWS + i * 32 + r, g.M - 1);
             const float2 mr = reinterpret_cast<const float2*>(g.ln_in_stats)[m];
-            if (h == 0) *reinterpret_cast<float2*>(ln_slot + i * 64) = mr;
+            if (h == 0) *reinterpret_cast<float2*>(ln_slot + (i * 32 + r) * 2) = mr;
         }
+    } else if (MODE == MODE_PLAIN && g.ln_in_gsums) {
+        constexpr bool HALVES = WROWS == 32;                 // 32-row patches: rows l & 31, groups of parity l >> 5
+        const int row = HALVES ? r : lane;
+        const int m = min(m0 + wm * WROWS + row, g.M - 1);
+        const float2* st = reinterpret_cast<const float2*>(g.ln_in_gsums) + m;
+        const int G = g.ln_in_groups, step = HALVES ? 2 : 1;
+        double s1 = 0.0, s2 = 0.0;
+        for (int g0 = HALVES ? h : 0; g0 < G; g0 += 16 * step) {
+            float2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = st[(long)min(g0 + u * step, G - 1) * g.ln_rows];   // (clamped, never predicated: sixteen independent loads)
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (g0 + u * step < G) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
+        }
+        if (HALVES) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
+        const double mean = s1 / (double)g.ln_in_count;
+        const double var = fmax(s2 / (double)g.ln_in_count - mean * mean, 0.0);
+        if (!HALVES || h == 0) *reinterpret_cast<float2*>(ln_slot + row * 2) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)g.ln_eps)));
     }
     wait_tiles<DMA, S - 1>(nk - 1);   // tile 0 landed; the other tiles of the prologue stay in flight
     __builtin_amdgcn_s_barrier();
@@ -399,10 +420,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     }
     // ---- folded LayerNorm, consumer side: LN(x) W^T = rstd (x (W o gamma)^T - mean cs) applied to the tile sums in place, so that every epilogue below sees the projection
     // of the normalised rows (it is linear in the sums: alpha, bias, activation and residual follow unchanged)
-    if (MODE == MODE_PLAIN && g.ln_in_stats) {
+    if (MODE == MODE_PLAIN && (g.ln_in_stats || g.ln_in_gsums)) {
         float ln_mean[TI], ln_rstd[TI];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) { const float2 mr = *reinterpret_cast<const float2*>(ln_slot + i * 64); ln_mean[i] = mr.x; ln_rstd[i] = mr.y; }
+        for (int i = 0; i < TI; ++i) { const float2 mr = *reinterpret_cast<const float2*>(ln_slot + (i * 32 + r) * 2); ln_mean[i] = mr.x; ln_rstd[i] = mr.y; }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -797,8 +818,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     if (g.epi == EPI_MUSE_Q)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.N % 64 == 0 && g.epi_hi && g.epi_lo && g.epi_scale && g.epi_rows > 0 && g.epi_heads * 64 == g.N && !g.R && !g.bias_n && !g.bias_m,
                    "gemm_split_glds: bad fused q-preparation arguments");
-    if (g.ln_in_stats)
-        BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_in_cs && g.N % 4 == 0 && g.ksplit <= 1, "gemm_split_glds: bad folded-LayerNorm consumer arguments (N=%d ksplit=%d)", g.N, g.ksplit);
+    if (g.ln_in_stats || g.ln_in_gsums)
+        BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_in_cs && g.N % 4 == 0 && g.ksplit <= 1 && !(g.ln_in_stats && g.ln_in_gsums) &&
+                       (!g.ln_in_gsums || (g.ln_in_groups > 0 && g.ln_in_count > 0 && g.ln_rows >= g.M)),
+                   "gemm_split_glds: bad folded-LayerNorm consumer arguments (N=%d ksplit=%d groups=%d)", g.N, g.ksplit, g.ln_in_groups);
     if (g.ln_out_planes)
         BG_REQUIRE(g.mode == MODE_PLAIN && g.ln_out_stats && g.ln_rows >= g.M && g.ln_out_ld % 32 == 0 && g.ksplit <= 1 &&
                        (g.epi == EPI_GEGLU ? g.ln_out_ld * 2 >= g.N : (g.epi == 0 && g.ln_out_ld >= g.N && g.N % 32 == 0 && (g.ldc & 3) == 0 && (!g.R || (g.ldr & 3) == 0) &&
@@ -887,7 +910,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
     dim3 grid(cdiv(g.N, GBN), cdiv(rows, tbm), g.ksplit);
-    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16) + (g.ln_in_stats ? 4096 : 0);   // (+ the folded LayerNorm's per-row (mean, rstd) slots)
+    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16) + ((g.ln_in_stats || g.ln_in_gsums) ? 4096 : 0);   // (+ the folded LayerNorm's per-row (mean, rstd) slots)
     static std::atomic<bool> attr_set[kMaxDevices];
     const int dslot = device_slot();
     if (!attr_set[dslot].load(std::memory_order_acquire)) {

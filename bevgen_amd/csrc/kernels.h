@@ -87,6 +87,9 @@ struct GemmArgs {
     float* ln_out_stats = nullptr;
     int ln_out_ld = 0;
     const float* ln_in_stats = nullptr;
+    const float* ln_in_gsums = nullptr;   // alternative to ln_in_stats: the producer's group sums [ln_in_groups][ln_rows][2], merged by every workgroup itself (small batches)
+    int ln_in_groups = 0, ln_in_count = 0;
+    float ln_eps = 1e-5f;
     const float* ln_in_cs = nullptr;
     // stream-K launch (gemm_split_glds_sk_kernel): workspace = 1024 flag words (zeroed by the caller once per workspace) + one partial-tile slot of 128 KiB per workgroup
     // (gemm_sk_ws_bytes); sk_epoch = a value no earlier launch on this workspace used (the flags are never reset: a flag equal to the epoch = "published in THIS launch")

@@ -116,12 +116,14 @@ void gemm(const float* A, int lda, const float* W, int ldb, float* C, int ldc, i
 // (B must then be the W o gamma matrix, cs its row sums); `out_planes` = it produces raw planes + statistics of its own output rows
 struct LnFold {
     const float* in_stats = nullptr; const float* in_cs = nullptr;   // consumer: per-row (mean, rstd) [rows][2] and the column sums of W o gamma
+    const float* in_gsums = nullptr; int in_groups = 0, in_count = 0; // ... or (small batches) the producer's group sums, merged by the consuming workgroups themselves
     void* out_planes = nullptr; float* out_stats = nullptr; int out_ld = 0;
 };
 void set_sk(GemmArgs& g, MuseWs* w);
 void set_fold(GemmArgs& g, const LnFold* f, int rows) {
     if (!f) return;
     g.ln_in_stats = f->in_stats; g.ln_in_cs = f->in_cs;
+    g.ln_in_gsums = f->in_gsums; g.ln_in_groups = f->in_groups; g.ln_in_count = f->in_count;
     g.ln_out_planes = f->out_planes; g.ln_out_stats = f->out_stats; g.ln_out_ld = f->out_ld;
     g.ln_rows = rows;
 }
@@ -265,6 +267,17 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
     // fold == 2: the residual-stream projections (to_out of both attention modules, the feed-forward's down-projection) write, besides the fp32 row, the raw planes of the
     // row into w.xn and its statistics into w.stats_d: the next projection multiplies them by W o gamma.  `x_planes_ready`: w.xn / w.stats_d hold the current w.x
     bool x_planes_ready = false;
+    // who merges a LayerNorm's group sums: up to two scenes every workgroup of the consuming projection runs ONE tile and merges its rows itself (no launch between producer
+    // and consumer: at one scene a 9 us kernel + its ramp per LayerNorm); above that one finalize kernel per LayerNorm feeds all tiles ($BEVGEN_LN_MERGE = kernel | tile)
+    const char* merge_env = getenv("BEVGEN_LN_MERGE");   // (read per forward: the tests switch it inside one process)
+    const bool tile_merge = merge_env ? merge_env[0] == 't' : rows <= 3072;
+    auto consumer = [&](const float* gsums, int groups, int count, const float* cs) {
+        LnFold f;
+        f.in_cs = cs;
+        if (tile_merge) { f.in_gsums = gsums; f.in_groups = groups; f.in_count = count; }
+        else { launch_ln_stats_finalize(gsums, w.rowstat, rows, groups, count, 1e-5f, s); f.in_stats = w.rowstat; }
+        return f;
+    };
     LnFold prod_x;   // producer role of a residual-stream projection
     prod_x.out_planes = w.xn; prod_x.out_stats = w.stats_d; prod_x.out_ld = D;
     for (int i = 0; i < g.num_layers; ++i) {
@@ -272,11 +285,10 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         // ---- self attention
         // split-precision mode: every GEMM input is produced directly as (hi, lo) f16 planes (same bytes as the fp32 buffer they replace)
         if (split) {
-            LnFold cons_x;   // consumer role behind a LayerNorm over the D residual columns
-            cons_x.in_stats = w.rowstat;
             const bool f0 = fold == 2 && x_planes_ready;   // (layer 0 reads the embedding: no projection produced it - its first LayerNorm stays a kernel)
+            LnFold cons_x;   // consumer role behind a LayerNorm over the D residual columns
             if (!f0) launch_layernorm_planes(w.x, D, l.norm_g[0], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
+            else cons_x = consumer(w.stats_d, D / 32, D, nullptr);
             // to_q and to_kv read the same LayerNorm planes (muse_net:126-132): ONE projection over the concatenated weight, query / key / value preparation in its
             // epilogue ($BEVGEN_QKV_MERGE=0: the two launches of rounds 2-4, for A/B runs)
             // Measured (same box, profiles/r05_ab_qkv_merge*.txt): one scene 161.9 -> 160.4 ms (two small-problem launches become one), sixteen scenes 10.31 -> 10.21
@@ -341,9 +353,8 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         // ---- cross attention
         if (split) {
             LnFold cons_x;
-            cons_x.in_stats = w.rowstat; cons_x.in_cs = l.fold_q_cross_cs;
             if (fold != 2) launch_layernorm_planes(w.x, D, l.norm_g[1], nullptr, w.xn, D, rows, D, 1e-5f, s);
-            else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
+            else cons_x = consumer(w.stats_d, D / 32, D, l.fold_q_cross_cs);
             gemm_planes_q(w.xn, D, fold == 2 ? l.fold_q_cross : l.to_q[1], l.q_scale[1], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw,
                           fold == 2 ? &cons_x : nullptr, &w);
         } else {
@@ -368,7 +379,6 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
         if (split) {
             gemm_planes(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s, w.kpart, fold == 2 ? &prod_x : nullptr, &w);
             if (fold != 2) launch_layernorm_planes(w.x, D, l.ff_g0, nullptr, w.xn, D, rows, D, 1e-5f, s);
-            else launch_ln_stats_finalize(w.stats_d, w.rowstat, rows, D / 32, D, 1e-5f, s);
             if (l.ff_w1_geglu) {
                 // GEGLU in the up-projection's epilogue: h = gate * gelu(x) as [rows, Fpad] (pad columns exactly 0), then the LayerNorm half on its own - or (fold >= 1)
                 // folded away: the epilogue writes the raw planes of h and its row statistics, the down-projection multiplies by W4 o gamma
@@ -379,19 +389,18 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
                 ge.lda = D; ge.ldb = D; ge.ldc = c.Fpad;
                 ge.epi = EPI_GEGLU;
                 LnFold fg;
-                if (fold == 2) { fg.in_stats = w.rowstat; fg.in_cs = l.fold_w1_cs; }
+                if (fold == 2) fg = consumer(w.stats_d, D / 32, D, l.fold_w1_cs);
                 if (fold >= 1) { fg.out_planes = w.g; fg.out_stats = w.stats_f; fg.out_ld = c.Fpad; }
                 if (fold >= 1) set_fold(ge, &fg, rows);
                 if (gemm_sk_pays(rows, ge.N, ge.K)) set_sk(ge, &w);
                 launch_gemm(ge, s);
                 if (fold == 0) launch_layernorm_planes(w.h, c.Fpad, l.ff_g3, nullptr, w.g, c.Fpad, rows, c.F, 1e-5f, s);
-                else launch_ln_stats_finalize(w.stats_f, w.rowstat, rows, c.Fpad / 32, c.F, 1e-5f, s);
             } else {
                 gemm_planes(w.xn, D, l.ff_w1, D, w.h, 2 * c.F, rows, 2 * c.F, D, nullptr, 0, s);
                 launch_geglu_layernorm_planes(w.h, 2 * c.F, l.ff_g3, w.g, c.Fpad, rows, c.F, 1e-5f, s);
             }
             LnFold fd;   // the down-projection: consumer of the inner LayerNorm (fold >= 1), producer for the next layer's first LayerNorm (fold == 2, not behind the last layer)
-            if (fold >= 1 && l.ff_w1_geglu) { fd.in_stats = w.rowstat; fd.in_cs = l.fold_w4_cs; }
+            if (fold >= 1 && l.ff_w1_geglu) fd = consumer(w.stats_f, c.Fpad / 32, c.F, l.fold_w4_cs);
             const bool prod_next = fold == 2 && i + 1 < g.num_layers;
             if (prod_next) { fd.out_planes = w.xn; fd.out_stats = w.stats_d; fd.out_ld = D; }
             const bool any = fd.in_stats || fd.out_planes;
