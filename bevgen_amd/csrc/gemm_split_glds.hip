@@ -828,8 +828,12 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
                                                                         (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.R || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0))),
                    "gemm_split_glds: bad folded-LayerNorm producer arguments (ld=%d N=%d epi=%d)", g.ln_out_ld, g.N, g.epi);
     // ---- stream-K route (the caller provided a workspace: Route M's projections): problems whose 256 x 128 tiles would leave much of their last round of the chip empty
-    static const int sk_env = getenv("BEVGEN_GEMM_SK") ? atoi(getenv("BEVGEN_GEMM_SK")) : 1;   // 0 = never (A/B runs), 2 = whenever a workspace is given (tests)
-    if (g.sk_ws && sk_env && g.mode == MODE_PLAIN && g.ksplit <= 1 && g.m_base == 0 && !g.no_row_split && !g.bias_m && xcd_placement_verified() &&
+    // DEFAULT OFF: measured slower than the launcher's other choices at every Route-M shape of one, two and four scenes (profiles/r06_ab_gemm_sk_ops.txt: +4 .. +27 us per
+    // projection; one scene 163.8 -> 168.5 ms with the routing rule below, 214 ms with every projection): a partial 256 x 128 tile is 128 KiB to publish and to read back,
+    // every segment refills the three-stage ring, and the workgroup that holds a tile's last k range merges while its peers idle - together more than the empty part of
+    // the last round they remove.  $BEVGEN_GEMM_SK=1 routes by gemm_sk_pays, 2 takes the form whenever a workspace is given (the operator tests force it per call)
+    static const int sk_env = getenv("BEVGEN_GEMM_SK") ? atoi(getenv("BEVGEN_GEMM_SK")) : 0;
+    if (g.sk_ws && (sk_env || g.sk_force) && g.mode == MODE_PLAIN && g.ksplit <= 1 && g.m_base == 0 && !g.no_row_split && !g.bias_m && xcd_placement_verified() &&
         (sk_env == 2 || g.sk_force || gemm_sk_pays(g.M, g.N, g.K))) {
         static std::atomic<int> cu_count[kMaxDevices];
         static std::atomic<bool> sk_attr[kMaxDevices];

@@ -403,8 +403,8 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             if (fold >= 1 && l.ff_w1_geglu) fd = consumer(w.stats_f, c.Fpad / 32, c.F, l.fold_w4_cs);
             const bool prod_next = fold == 2 && i + 1 < g.num_layers;
             if (prod_next) { fd.out_planes = w.xn; fd.out_stats = w.stats_d; fd.out_ld = D; }
-            const bool any = fd.in_stats || fd.out_planes;
-            gemm_planes(w.g, c.Fpad, fd.in_stats ? l.fold_w4 : l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s, w.kpart, any ? &fd : nullptr, &w);
+            const bool cons = fd.in_stats || fd.in_gsums, any = cons || fd.out_planes;
+            gemm_planes(w.g, c.Fpad, cons ? l.fold_w4 : l.ff_w4_padded, c.Fpad, w.x, D, rows, D, c.Fpad, w.x, D, s, w.kpart, any ? &fd : nullptr, &w);
             x_planes_ready = prod_next;
         } else {
             gemm(w.att, D, l.to_out[1], D, w.x, D, rows, D, D, w.x, D, s);
