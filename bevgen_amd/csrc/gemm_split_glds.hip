@@ -775,6 +775,8 @@ size_t gemm_sk_ws_bytes() { return 1024 * sizeof(float) + (size_t)256 * (8 * 4 *
 // gets a few k-tiles.  One scene (rows 1536): q|k|v 144 tiles (44 % empty), the 1024-wide projections 48 (81 %), the up-projection 258 (50 % of two rounds); two scenes:
 // 288 / 96 / 516; sixteen scenes: 2304 = 9 rounds exactly, 768 = 3, 4128 = 16.1 (its row-split form stays).
 bool gemm_sk_pays(long rows, int N, int K) {
+    static const int sk_env = getenv("BEVGEN_GEMM_SK") ? atoi(getenv("BEVGEN_GEMM_SK")) : 0;   // (default off: see launch_gemm_split_glds)
+    if (!sk_env) return false;
     const long T = (long)cdiv(rows, 256) * cdiv(N, GBN), rounds = (T + 255) / 256;
     const double empty = 1.0 - (double)T / (double)(rounds * 256);
     // ... and only while a tile is shared by two or three workgroups (T >= 128): with fewer tiles every tile's last workgroup merges five or more 128 KiB partials while
