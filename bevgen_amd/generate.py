@@ -67,6 +67,35 @@ def _to_device(batch: Dict[str, Any], device) -> Dict[str, Any]:
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
 
 
+def _config_backend():
+    """Which composer / instantiator runs the configuration tree (reference generate.py:75-77 uses @hydra.main): REAL Hydra when it is importable - the drop-in classes are
+    ordinary `_target_`s, nothing here needs the built-in loader - else `bevgen_amd.hydra_lite` (the subset of Hydra the reference's tree uses; this image ships no Hydra).
+    $BEVGEN_HYDRA = lite | real pins the choice."""
+    want = os.environ.get("BEVGEN_HYDRA", "").lower()
+    if want != "lite":
+        try:
+            import hydra  # noqa: F401
+            import omegaconf  # noqa: F401
+            return "real"
+        except ImportError:
+            if want == "real":
+                raise
+    return "lite"
+
+
+def _compose(config_dir: str, config_name: str, overrides: List[str]):
+    """-> (plain nested dict, instantiate function)."""
+    if _config_backend() == "real":
+        import hydra
+        from hydra import compose, initialize_config_dir
+        from omegaconf import OmegaConf
+
+        with initialize_config_dir(config_dir=os.path.abspath(config_dir), version_base="1.2"):
+            cfg = compose(config_name=config_name, overrides=list(overrides), return_hydra_config=False)
+        return OmegaConf.to_container(cfg, resolve=True), (lambda node: hydra.utils.instantiate(node, _convert_="all"))
+    return hydra_lite.compose(config_dir, config_name, overrides), hydra_lite.instantiate
+
+
 def main(argv: List[str] = None) -> int:
     ap = argparse.ArgumentParser(prog="python -m bevgen_amd.generate", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--config-dir", required=True, help="the configuration tree (e.g. <reference>/configs)")
@@ -82,7 +111,7 @@ def main(argv: List[str] = None) -> int:
     ap.add_argument("overrides", nargs="*")
     args = ap.parse_args(argv)
 
-    cfg = hydra_lite.compose(args.config_dir, args.config_name, args.overrides)
+    cfg, instantiate = _compose(args.config_dir, args.config_name, args.overrides)
     if args.random_weights:
         _null_ckpts(cfg.get("model"))
     if args.synthetic_calibration:
@@ -116,8 +145,8 @@ def main(argv: List[str] = None) -> int:
     seed = cfg.get("seed", 0) if args.seed is None else args.seed
     torch.manual_seed(int(seed or 0))
 
-    model = hydra_lite.instantiate(cfg["model"]).to(device).eval()
-    callbacks = [hydra_lite.instantiate(c) for c in (cfg.get("callbacks") or {}).values() if isinstance(c, dict) and "GenerateImages" in str(c.get("_target_", ""))]
+    model = instantiate(cfg["model"]).to(device).eval()
+    callbacks = [instantiate(c) for c in (cfg.get("callbacks") or {}).values() if isinstance(c, dict) and "GenerateImages" in str(c.get("_target_", ""))]
     if not callbacks:
         raise hydra_lite.ConfigError("no GenerateImages callback in the configuration (callbacks.image_logger)")
 

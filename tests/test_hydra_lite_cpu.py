@@ -113,3 +113,46 @@ def test_instantiate_recursive_and_rewrite(tmp_path):
     assert type(w).__name__ == "GenerateImages" and w.rand_str is True
     p = H.instantiate({"_target_": "fractions.Fraction", "_partial_": True, "numerator": 1})
     assert p(denominator=2) == Fraction(1, 2)
+
+
+def test_generate_uses_real_hydra_when_installed_and_hydra_lite_otherwise(tmp_path, monkeypatch):
+    """reference generate.py:75-77 composes through @hydra.main.  bevgen_amd.generate hands the tree to REAL Hydra when it is importable (the drop-in classes are ordinary
+    `_target_`s) and to hydra_lite otherwise; this image has no Hydra, so the real branch is exercised against a stand-in module that records the calls."""
+    import sys
+    import types
+
+    from bevgen_amd import generate as G
+
+    monkeypatch.delenv("BEVGEN_HYDRA", raising=False)
+    for m in ("hydra", "omegaconf"):
+        monkeypatch.delitem(sys.modules, m, raising=False)
+    assert G._config_backend() == "lite"
+    monkeypatch.setenv("BEVGEN_HYDRA", "real")
+    with pytest.raises(ImportError):
+        G._config_backend()
+    calls = {}
+    hydra = types.ModuleType("hydra")
+
+    class _Init:
+        def __init__(self, config_dir, version_base):
+            calls["config_dir"], calls["version_base"] = config_dir, version_base
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    hydra.initialize_config_dir = _Init
+    hydra.compose = lambda config_name, overrides, return_hydra_config=False: calls.setdefault("compose", (config_name, list(overrides))) and {"model": {"_target_": "builtins.dict", "a": 1}}
+    hydra.utils = types.SimpleNamespace(instantiate=lambda node, _convert_=None: ("instantiated", node, _convert_))
+    omegaconf = types.ModuleType("omegaconf")
+    omegaconf.OmegaConf = types.SimpleNamespace(to_container=lambda cfg, resolve=True: dict(cfg, resolved=resolve))
+    monkeypatch.setitem(sys.modules, "hydra", hydra)
+    monkeypatch.setitem(sys.modules, "omegaconf", omegaconf)
+    assert G._config_backend() == "real"
+    cfg, inst = G._compose(str(tmp_path), "train.yaml", ["experiment=muse_stage_two_multi_view"])
+    assert calls["config_dir"] == str(tmp_path) and calls["version_base"] == "1.2" and calls["compose"] == ("train.yaml", ["experiment=muse_stage_two_multi_view"])
+    assert cfg["resolved"] is True and inst(cfg["model"]) == ("instantiated", cfg["model"], "all")
+    monkeypatch.setenv("BEVGEN_HYDRA", "lite")
+    assert G._config_backend() == "lite"
