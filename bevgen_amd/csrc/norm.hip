@@ -162,22 +162,33 @@ void launch_layernorm_planes(const float* x, int ldx, const float* gamma, const 
 // Folded LayerNorm (GemmArgs::ln_*): the producing epilogue left (sum, sum of squares) per (32 columns, row); one thread per row adds its groups in fp64, in group order
 // (consecutive threads read consecutive rows of a group: coalesced; deterministic), and leaves (mean, rstd) for the consuming projection's epilogue.
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float2* __restrict__ sums, float2* __restrict__ out, int rows, int groups, double inv_count, double eps) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= rows) return;
+    // 64 rows per workgroup, four threads per row (the row's groups dealt round-robin, eight loads in flight each): 24 576 rows = 384 workgroups instead of 96, and a
+    // thread's chain of dependent L2 round trips is a quarter as long.  The four partial sums are added in a fixed order: deterministic.
+    __shared__ double sh[4][64][2];
+    const int rl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int m = min(blockIdx.x * 64 + rl, rows - 1);
     double s1 = 0.0, s2 = 0.0;
-    int gi = 0;
-    for (; gi + 4 <= groups; gi += 4) {   // four loads in flight
-        const float2 a = sums[(long)gi * rows + m], b = sums[(long)(gi + 1) * rows + m], c = sums[(long)(gi + 2) * rows + m], d = sums[(long)(gi + 3) * rows + m];
-        s1 += (double)a.x; s2 += (double)a.y; s1 += (double)b.x; s2 += (double)b.y; s1 += (double)c.x; s2 += (double)c.y; s1 += (double)d.x; s2 += (double)d.y;
+    for (int g0 = part; g0 < groups; g0 += 32) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sums[(long)min(g0 + 4 * u, groups - 1) * rows + m];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (g0 + 4 * u < groups) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
     }
-    for (; gi < groups; ++gi) { const float2 a = sums[(long)gi * rows + m]; s1 += (double)a.x; s2 += (double)a.y; }
-    const double mean = s1 * inv_count;
-    const double var = fmax(s2 * inv_count - mean * mean, 0.0);
-    out[m] = make_float2((float)mean, (float)(1.0 / sqrt(var + eps)));
+    sh[part][rl][0] = s1; sh[part][rl][1] = s2;
+    __syncthreads();
+    if (part == 0 && blockIdx.x * 64 + rl < rows) {
+        const double t1 = ((sh[0][rl][0] + sh[1][rl][0]) + sh[2][rl][0]) + sh[3][rl][0];
+        const double t2 = ((sh[0][rl][1] + sh[1][rl][1]) + sh[2][rl][1]) + sh[3][rl][1];
+        const double mean = t1 * inv_count;
+        const double var = fmax(t2 * inv_count - mean * mean, 0.0);
+        out[m] = make_float2((float)mean, (float)(1.0 / sqrt(var + eps)));
+    }
 }
 void launch_ln_stats_finalize(const float* group_sums, float* row_stats, int rows, int groups, int count, float eps, hipStream_t s) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, reinterpret_cast<const float2*>(group_sums), reinterpret_cast<float2*>(row_stats), rows,
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(cdiv(rows, 64)), dim3(256), 0, s, reinterpret_cast<const float2*>(group_sums), reinterpret_cast<float2*>(row_stats), rows,
                        groups, 1.0 / (double)count, (double)eps);
     LAUNCH_CHECK();
 }

@@ -1,6 +1,6 @@
 """A/B of $BEVGEN_LN_FOLD on the Route-M step (generate + VQGAN decode) at a given batch: prints scenes/s and ms per step.  usage: python tools/ab_ln_fold.py BATCH [STEPS]"""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from bevgen_amd import synthetic
 B = int(sys.argv[1]); steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
