@@ -54,9 +54,8 @@ inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
 // for speed only), each with a private L2.  With the natural order the gx column tiles that share one A row-panel land on 8 different L2s
 // and the panel is fetched from HBM 8 times (measured: 4.5x the algorithmic traffic).  Re-labelling so that every XCD walks a CONTIGUOUS
 // range of tile ids keeps a panel's column tiles on one XCD, back to back.  Bijective for any grid size (MI355X guide, T1).
-__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
+__device__ __forceinline__ void xcd_tile_lin(int gx, int gy, int lin, int& tx, int& ty) {   // lin = dispatch-order index of the workgroup (or of a persistent workgroup's turn)
     const int total = gx * gy;
-    const int lin = blockIdx.y * gx + blockIdx.x;
     const int xcd = lin & 7, k = lin >> 3;
     const int q = total >> 3, r = total & 7;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -65,12 +64,14 @@ __device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) {
     tx = logical - ty * gx;
 }
 
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int& tx, int& ty) { xcd_tile_lin(gx, gy, blockIdx.y * gx + blockIdx.x, tx, ty); }
+
 // Same, but the contiguous id range of an XCD walks bands of R row-tiles column by column, so that the ~32 workgroups resident on one XCD form
 // an (R x 32/R) patch of the output: the patch's R A-panels and 32/R B-panels are each fetched once per k-slice and shared through that L2
 // (R = 4 with 256x128 tiles = 1024 + 1024 operand rows per patch, the minimum for 32 tiles), and the A band stays warm while B streams past.
-__device__ __forceinline__ void xcd_tile_banded(int gx, int gy, int R, int& tx, int& ty) {
+__device__ __forceinline__ void xcd_tile_banded_lin(int gx, int gy, int R, int lin, int& tx, int& ty) {
     int lx, ly;
-    xcd_tile(gx, gy, lx, ly);
+    xcd_tile_lin(gx, gy, lin, lx, ly);
     const int logical = ly * gx + lx;
     const int band = logical / (R * gx);
     const int within = logical - band * (R * gx);
@@ -78,6 +79,7 @@ __device__ __forceinline__ void xcd_tile_banded(int gx, int gy, int R, int& tx, 
     tx = within / h;
     ty = band * R + (within - tx * h);
 }
+__device__ __forceinline__ void xcd_tile_banded(int gx, int gy, int R, int& tx, int& ty) { xcd_tile_banded_lin(gx, gy, R, blockIdx.y * gx + blockIdx.x, tx, ty); }
 
 // -------- device status word: what the reference asserts on the host every step (gpt:383,388 finite inputs / logits, ar_lm:202 finite logits) is flagged on the DEVICE
 // here - no host synchronisation on the sampling path - into one host-visible word per context (mapped host memory, Ctx::status_host), read by the host wherever

@@ -768,6 +768,12 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_sk_kernel(GemmArg
     }
 }
 
+// (Round 6 also measured a PERSISTENT whole-tile form - one workgroup per CU walking the tiles of its dispatch slot, optionally with a start offset per workgroup so that
+// the 256 epilogue store bursts do not coincide: slower than letting the hardware dispatch a workgroup per tile at every shape (sixteen scenes, [24576, 1024] x 1024: 153 ->
+// 169 us; x 32: 39 -> 57 us, i.e. +6 us per round of tiles; offsets of 1.5 / 3 us changed nothing) - removed; profiles/r06_ab_gemm_persistent.txt.  What the same probe shows
+// about the throughput kernel: 35 us of fixed time per three-round launch (ring fill + epilogue drain, ~12 us per round) + 3.92 us per k-tile = 411 TF-equiv asymptotically,
+// 0.39 of the ceiling at K = 1024.)
+
 size_t gemm_sk_ws_bytes() { return 1024 * sizeof(float) + (size_t)256 * (8 * 4 * 16 * 64) * sizeof(float); }   // 1024 flag words + 256 workgroup slots of 128 KiB
 
 // Does the stream-K form pay?  T tiles of 256 x 128 cost ceil(T / 256) rounds of the chip; the form removes the empty part of the last round (and the second launch of a
