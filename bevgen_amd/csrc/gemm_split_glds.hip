@@ -644,11 +644,41 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     unsigned ln_bad = 0;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!Rp || (reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
+    // Every load of the epilogue is issued BEFORE its first store.  Loads and stores share one counter on this part (vmcnt) and the compiler cannot tell that the
+    // residual does not alias C (it usually IS C: x = x + proj), so with the loads inside the store loop every one of the sixteen (row tile, column quad) steps was
+    // "load R; s_waitcnt vmcnt(0); store C" - a wait for the PREVIOUS step's stores to complete each time, ~0.7 us of L2 round trip sixteen times per tile with every
+    // matrix pipe idle (the bias: four dword loads, each with its own wait).  Hoisted: one round trip for the tile, then the stores back to back.
+    f32x4 bias4[TJ][4];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int n = n0 + wn * WCOLS + j * 32 + 8 * qq + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias4[j][qq][e] = (g.bias_n && n + e < g.N) ? g.bias_n[n + e] : 0.f;
+        }
+    f32x4 rv[TI][TJ][4];
+    float bm[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int m = min(m0 + wm * WROWS + i * 32 + r, g.M - 1);
+        bm[i] = g.bias_m ? g.bias_m[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int n = n0 + wn * WCOLS + j * 32 + 8 * qq + 4 * h;
+                if (Rp && vec_ok && n + 3 < g.N) rv[i][j][qq] = *reinterpret_cast<const f32x4*>(Rp + (long)m * g.ldr + n);
+                else if (Rp) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[i][j][qq][e] = Rp[(long)m * g.ldr + min(n + e, g.N - 1)];
+                } else rv[i][j][qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int m = m0 + wm * WROWS + i * 32 + r;
         if (m >= g.M) continue;
-        const float bm = g.bias_m ? g.bias_m[m] : 0.f;
         float ln_s1[TJ], ln_s2[TJ];
 #pragma unroll
         for (int j = 0; j < TJ; ++j) { ln_s1[j] = 0.f; ln_s2[j] = 0.f; }
@@ -662,17 +692,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int q = qq * 4 + e;
-                    float t = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha + bm;
-                    if (g.bias_n && n + e < g.N) t += g.bias_n[n + e];
+                    float t = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha + bm[i];
+                    t += bias4[j][qq][e];
                     if (g.act == ACT_GELU) t = gelu_erf(t);
-                    v[e] = t;
+                    v[e] = t + rv[i][j][qq][e];
                 }
                 float* cp = C + (long)m * g.ldc + n;
                 if (vec_ok && n + 3 < g.N) {
-                    if (Rp) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(Rp + (long)m * g.ldr + n);
-                        v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
-                    }
                     f32x4 o; o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
                     *reinterpret_cast<f32x4*>(cp) = o;
                     if (MODE == MODE_PLAIN && g.ln_out_planes) {
@@ -706,7 +732,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n + e < g.N) cp[e] = v[e] + (Rp ? Rp[(long)m * g.ldr + n + e] : 0.f);
+                        if (n + e < g.N) cp[e] = v[e];
                 }
             }
             if (MODE == MODE_PLAIN && g.ln_out_planes) {   // the row's pair for the 32 columns of MFMA tile j: the two lane halves hold 16 columns each
