@@ -457,6 +457,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         const float* qsc = qkv ? g.epi_qscale : g.epi_scale;
         const int head = (n0 + wn * 64) >> 6;
         unsigned bad = 0;   // a prepared operand that is NaN / outside the f16 range (l2norm bounds q and k: only a non-finite projection gets here; v is unbounded)
+        f32x4 qsc4[2][4];   // (the per-dimension scales, loaded in front of the first store: loads and stores share vmcnt - see the plain epilogue)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) qsc4[j][qq] = *reinterpret_cast<const f32x4*>(qsc + j * 32 + 8 * qq + 4 * h);
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
@@ -479,7 +484,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const int d = j * 32 + 8 * qq + 4 * h;
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(qsc + d);
+                    const f32x4 sc = qsc4[j][qq];
                     half4_t hi4, lo4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -505,6 +510,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         const int head = (is_v ? ncol - HD : ncol) >> 6;
         const _Float16* aux = reinterpret_cast<const _Float16*>(g.epi_aux);
         unsigned bad = 0;
+        f32x4 ksc4[2][4];   // (k_scale in front of the first store, as above)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) ksc4[j][qq] = *reinterpret_cast<const f32x4*>(g.epi_scale + j * 32 + 8 * qq + 4 * h);
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
@@ -531,7 +541,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const int d = j * 32 + 8 * qq + 4 * h;
-                        const f32x4 sc = *reinterpret_cast<const f32x4*>(g.epi_scale + d);
+                        const f32x4 sc = ksc4[j][qq];
                         half4_t hi4, lo4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
