@@ -64,6 +64,16 @@ __device__ __forceinline__ void wait_tiles(int n) {
     }
 }
 
+// the same with X younger wave-instructions (the residual prefetch of the tail) allowed to stay in flight on top
+template <int DMA, int MAXN, int X>
+__device__ __forceinline__ void wait_tiles_x(int n) {
+    if constexpr (MAXN <= 0) wait_vmcnt<X>();
+    else {
+        if (n >= MAXN) wait_vmcnt<MAXN * DMA + X>();
+        else wait_tiles_x<DMA, MAXN - 1, X>(n);
+    }
+}
+
 // W16: the B operand (a weight matrix) is f16-representable, its low plane is zero: the product is  b_hi a_hi + 2^-11 b_hi a_lo  - TWO MFMAs per
 // k-step pair instead of three, and no low-plane fragment reads (weight_dtype = f16 contexts)
 // KS: the k range is cut into gridDim.z slices (small-M problems; a template flag so that the throughput instantiations carry none of it - the 256-row convolution
@@ -78,7 +88,7 @@ __device__ __forceinline__ void wait_tiles(int n) {
 // sk_role (stream-K launches, gemm_split_glds_sk_kernel below): 0 = the whole k range of the tile is here: the normal epilogue; 1 = a PART of the tile's k range whose last
 // part lies with a later workgroup: the raw tile sums go to this workgroup's slot of g.sk_ws and its flag is raised; 2 = the LAST part: the sums of the workgroups
 // sk_first .. blockIdx.x - 1 (ascending k) are added in that order, then the normal epilogue.
-template <int MODE, int WM, int S, bool W16, bool KS, int TI, int TJ>
+template <int MODE, int WM, int S, bool W16, bool KS, int TI, int TJ, bool SKK = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const int ty, const int kt_first, const int nk, const int ksl, const int kz, const int sk_role,
                                           const int sk_first, const int tid) {
     constexpr int TBM = WM * 64;                 // block rows
@@ -297,6 +307,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     //   2  tile kt+S-1 before the barrier, interleaved with the F0 MFMAs ("late" waves: the same tile, one phase later)
     // DMA issue is staggered because a glds costs its wave ~70 issue cycles during which the MFMAs queued behind it cannot start: of the
     // two waves sharing a SIMD one always runs bare MFMAs.   STEADY: tile kt+2 exists, so one tile may stay in flight across the barrier.
+    // Residual prefetch (GemmArgs::r_prefetch).  The epilogue's residual rows (x = x + proj) are the one operand nobody asked for before the k loop ends: 256 workgroups
+    // finish a round of tiles together and then all wait for 32 MB of residual lines at once with every matrix pipe idle.  In the FIRST iteration of the loop's tail
+    // (no operand DMA left to issue, S - 1 .. S k-tiles before the epilogue) every wave requests the 128 lines of its 64 x 64 patch - two LDS-DMA instructions of one
+    // 16-byte piece per line into the ring stage that has just become free; the data is never read from there, the lines are then in the XCD's L2 / the memory-side
+    // cache when the epilogue loads them.  The tail's waits let these RPF_N youngest instructions stay in flight.
+    constexpr bool RPF = MODE == MODE_PLAIN && TI == 2 && TJ == 2 && !KS && !SKK;   // (SKK: the call comes from the stream-K kernel)
+    constexpr int RPF_N = 2;
+    const bool rpf_on = RPF && g.r_prefetch && sk_role == 0 && nk >= S;
+    bool rpf_pending = false, rpf_flight = false;
+    auto issue_rpf = [&](int stg) {
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.R), 0, -1, 0x00020000);
+        const int row = min(m0 + wm * WROWS + lane, g.M - 1);
+        const int col = min(n0 + wn * WCOLS, g.N - 64);
+        const unsigned off = (unsigned)(((long)row * g.ldr + col) * 4);
+        _Float16* dst = smem_g + stg * STAGE_H + wave * 1024;   // (2 x 1 KiB per wave inside the free stage)
+        glds16_buf(r_rsrc, off, 0, dst);
+        glds16_buf(r_rsrc, off + 128u, 0, dst + 512);
+    };
+    // (Measured and removed, round 6: a NEXT-TILE prefetch on the same pattern - in the last tail iteration every wave requested the lines of the first k-tiles of the tile
+    // that the workgroup 256 places later runs on this XCD.  [24576, 1024] x 1024 153 -> 154 us, x 3072 475 -> 489 us, sixteen scenes 10.63 -> 10.56 scenes/s: the ring
+    // fill of a round is not what its first microseconds wait for; profiles/r06_ab_gemm_npf.txt.)
     int stage = 0;
     auto body = [&](auto where_c, auto steady_c, int kt) {
         constexpr int WHERE = decltype(where_c)::value;
@@ -319,6 +350,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (STEADY) wait_vmcnt<(S - 2) * DMA>();
+        else if (RPF && rpf_flight) wait_tiles_x<DMA, S - 2, RPF_N>(nk - kt - 2);
         else wait_tiles<DMA, S - 2>(nk - kt - 2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -328,6 +360,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         fetch(f0, stage_next, 0);        // unconditional (after the last tile it reads a stale stage and is never used): keeps the wait counters exact
         BG_FENCE();
         if (WHERE == 1) { issue_a_half(stage, 0); BG_FENCE(); }
+        if (RPF && WHERE == 0 && rpf_pending) { issue_rpf(stage); rpf_pending = false; rpf_flight = true; BG_FENCE(); }
         mma_c1(f1);
         BG_FENCE();
         if (WHERE == 1) { issue_a_half(stage, 1); BG_FENCE(); }
@@ -346,6 +379,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         if (nk > 0) { body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, 0); kt = 1; }
         for (; kt <= nk - S; ++kt) body(integral_constant<int, 2>{}, integral_constant<bool, true>{}, kt);  // tiles kt+S-1 <= nk-1 exist
     }
+    rpf_pending = rpf_on;
     for (; kt < nk; ++kt) body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
 
     // ---- stream-K (gemm_split_glds_sk_kernel): partial tile sums travel through g.sk_ws = [1024 flag words][workgroup slots of NW x TI x TJ x 16 x 64 floats].  The
@@ -799,7 +833,7 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_sk_kernel(GemmArg
         // stays live across the whole body: 528 spilled VGPRs instead of none)
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
-        gemm_tile<MODE_PLAIN, WM, S, W16, false, 2, 2>(g, (int)(t % gx), (int)(t / gx), k0, k1 - k0, 1, 0, role, first, tid);
+        gemm_tile<MODE_PLAIN, WM, S, W16, false, 2, 2, true>(g, (int)(t % gx), (int)(t / gx), k0, k1 - k0, 1, 0, role, first, tid);
         __syncthreads();   // the next segment's first DMA overwrites stages the slowest wave may still be reading
     }
 }
@@ -841,6 +875,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     }
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
     g.status = status_current();
+    static const int rpf_env = getenv("BEVGEN_GEMM_RPF") ? atoi(getenv("BEVGEN_GEMM_RPF")) : 1;   // residual prefetch in the k loop's tail (0: off, for A/B runs; profiles/r06_ab_gemm_rpf.txt)
+    g.r_prefetch = rpf_env && g.mode == MODE_PLAIN && g.R && (g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.R) & 15) == 0 && (long)g.M * g.ldr * 4 < 0x7FFFFFFFL && g.N >= 64;
     if (g.gn_part)
         BG_REQUIRE(g.mode == MODE_CONV3 && g.epi == 0 && g.ksplit <= 1 && g.M % 256 == 0 && g.m_base == 0 && g.N % GBN == 0 && g.ldc == g.N && (g.ldc & 3) == 0 &&
                        (!g.R || (g.ldr & 3) == 0) && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.R || (reinterpret_cast<uintptr_t>(g.R) & 15) == 0) && !g.bias_m,

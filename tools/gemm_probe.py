@@ -15,14 +15,17 @@ for (M, N, K) in shapes:
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.03
     if mode == 4: w = w.half().float()
     out = torch.empty(M, N, device="cuda")
+    res = _ptr(out) if os.environ.get("PROBE_RESIDUAL") else None   # x = x + proj, the shape of the residual-stream projections
     def run():
-        ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(a), _ptr(w), None, None, _ptr(out), M, N, K, 0, mode, _stream()))
+        ctx._check(ctx.lib.bevgen_op_gemm(ctx._h, _ptr(a), _ptr(w), None, res, _ptr(out), M, N, K, 0, mode, _stream()))
     run(); torch.cuda.synchronize()
     ctx.profile_begin()
     for _ in range(reps): run()
     torch.cuda.synchronize()
     pe = ctx.profile_end()
     dt = (pe["gemm"]["ms"] + pe["gemm_small"]["ms"]) * 1e-3 / reps   # (small-problem, stream-K and persistent launches are recorded as gemm_small)   # (a GEMM may be two launches: the LDS-DMA kernel's tail split)
+    if res is not None:
+        out.zero_(); run(); torch.cuda.synchronize()
     ref = (a[:64].double() @ w.double().t()).float()
     err = ((out[:64] - ref).abs().max() / ref.abs().max()).item()
     print(f"mode={mode} M={M} N={N} K={K}: {dt*1e6:.0f} us  {2*M*N*K/dt/1e12:.1f} TF (GEMM kernel only, HIP events)  rel err of 64 rows vs fp64 {err:.2e}")
