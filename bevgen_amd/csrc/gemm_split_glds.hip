@@ -43,6 +43,13 @@ __device__ __forceinline__ float row16_sum(float d) {
 }
 
 constexpr int GBN = 128, GBK = 32;
+#ifdef BEVGEN_GEMM_TRACE   // tools/gemm_trace: phase stamps (100 MHz clock) of the first 2048 workgroups of the LAST throughput launch: entry, first tile landed, loop done, epilogue issued, stores acknowledged
+__device__ unsigned long long g_gemm_trace[2048 * 8];
+__device__ unsigned long long g_gemm_tr_tmp[2];
+#define GT_STAMP(i) do { if (MODE == MODE_PLAIN && WM == 4) gt[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GT_STAMP(i) do { } while (0)
+#endif
 constexpr float kGLoInv = 1.f / 2048.f;
 
 __device__ __forceinline__ void glds16(const _Float16* src, _Float16* lds_wave_base) {
@@ -90,7 +97,11 @@ __device__ __forceinline__ void wait_tiles_x(int n) {
 // sk_first .. blockIdx.x - 1 (ascending k) are added in that order, then the normal epilogue.
 template <int MODE, int WM, int S, bool W16, bool KS, int TI, int TJ, bool SKK = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const int ty, const int kt_first, const int nk, const int ksl, const int kz, const int sk_role,
-                                          const int sk_first, const int tid) {
+                                          const int sk_first, const int tid
+#ifdef BEVGEN_GEMM_TRACE
+                                          , unsigned long long* gt
+#endif
+                                          ) {
     constexpr int TBM = WM * 64;                 // block rows
     constexpr int NW = WM * 8 / (TI * TJ);       // waves
     constexpr int WROWS = TI * 32;               // rows of a wave's patch
@@ -298,6 +309,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     wait_tiles<DMA, S - 1>(nk - 1);   // tile 0 landed; the other tiles of the prologue stay in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    GT_STAMP(1);
     Frag f0, f1;
     fetch(f0, 0, 0);
 
@@ -310,7 +322,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     // Residual prefetch (GemmArgs::r_prefetch).  The epilogue's residual rows (x = x + proj) are the one operand nobody asked for before the k loop ends: 256 workgroups
     // finish a round of tiles together and then all wait for 32 MB of residual lines at once with every matrix pipe idle.  In the FIRST iteration of the loop's tail
     // (no operand DMA left to issue, S - 1 .. S k-tiles before the epilogue) every wave requests the 128 lines of its 64 x 64 patch - two LDS-DMA instructions of one
-    // 16-byte piece per line into the ring stage that has just become free; the data is never read from there, the lines are then in the XCD's L2 / the memory-side
+    // 16-byte piece per line into a 2 KiB sink behind the ring; the data is never read from there, the lines are then in the XCD's L2 / the memory-side
     // cache when the epilogue loads them.  The tail's waits let these RPF_N youngest instructions stay in flight.
     constexpr bool RPF = MODE == MODE_PLAIN && TI == 2 && TJ == 2 && !KS && !SKK;   // (SKK: the call comes from the stream-K kernel)
     constexpr int RPF_N = 2;
@@ -321,7 +333,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         const int row = min(m0 + wm * WROWS + lane, g.M - 1);
         const int col = min(n0 + wn * WCOLS, g.N - 64);
         const unsigned off = (unsigned)(((long)row * g.ldr + col) * 4);
-        _Float16* dst = smem_g + stg * STAGE_H + wave * 1024;   // (2 x 1 KiB per wave inside the free stage)
+        // (the sink: 2 KiB behind the ring and the LayerNorm slots, shared by all waves - nobody reads it.  NOT a free ring stage: a slow wave's pieces could land
+        // there after a fast wave has begun to stage its epilogue tile in the ring)
+        _Float16* dst = smem_g + S * STAGE_H + 2048;
+        (void)stg;
         glds16_buf(r_rsrc, off, 0, dst);
         glds16_buf(r_rsrc, off + 128u, 0, dst + 512);
     };
@@ -381,6 +396,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     }
     rpf_pending = rpf_on;
     for (; kt < nk; ++kt) body(integral_constant<int, 0>{}, integral_constant<bool, false>{}, kt);
+    GT_STAMP(2);
 
     // ---- stream-K (gemm_split_glds_sk_kernel): partial tile sums travel through g.sk_ws = [1024 flag words][workgroup slots of NW x TI x TJ x 16 x 64 floats].  The
     // workgroups that share a tile sit on ONE XCD (indices congruent mod 8: the kernel below deals whole tiles to XCDs), so the exchange stays in that XCD's L2 - plain
@@ -688,6 +704,57 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     unsigned ln_bad = 0;
     const bool vec_ok = ((g.ldc & 3) == 0) && (!Rp || (g.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
                         (!Rp || (reinterpret_cast<uintptr_t>(Rp) & 15) == 0);
+    // Row-major store form (the throughput instantiation).  In the accumulator layout a store instruction covers 32 rows x 32 bytes: 32 PARTIAL lines, and a CU pushes
+    // at most ~34 GB/s that way however idle the rest of the chip is (tools/storebw: 128 KB per tile = 3.8 us; sixteen lanes x 16 bytes = 256 contiguous bytes of one
+    // row, four rows per instruction: 118 GB/s).  The phase stamps of the kernel (tools/gemm_trace.py) showed 6.5 us between the end of the k loop and the last store
+    // issue of every round, synchronised or not.  So the wave's 64 x 64 patch goes through its own 17 KB of the (now dead) stage ring - written in the accumulator
+    // layout, read back row-major; row stride 68 floats: both directions conflict-free for 16-lane groups of 16-byte accesses - and bias / activation / residual follow on
+    // the row-major side, element by element in the same order as below (bit-identical).  No barrier: after the last k-tile's barrier nobody reads operand data from the
+    // ring any more (the stale look-ahead fetch of the last iteration is never used), and a wave only touches its own slice.
+    if constexpr (MODE == MODE_PLAIN && WM == 4 && S == 3 && TI == 2 && TJ == 2 && !KS && !SKK) {
+        if (g.row_major_epi && vec_ok && (g.N & 3) == 0 && !g.ln_out_planes) {
+            float* pl = reinterpret_cast<float*>(smem_g) + wave * (64 * 68);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = accM[i][j][qq * 4 + e] + accC[i][j][qq * 4 + e] * kGLoInv;
+                        *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + j * 32 + 8 * qq + 4 * h) = v;
+                    }
+            const int c = lane & 15, rr = lane >> 4;
+            const int n = n0 + wn * 64 + 4 * c;
+            const int nc = min(n, g.N - 4);
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (g.bias_n) b4 = *reinterpret_cast<const f32x4*>(g.bias_n + nc);
+            f32x4 rres[16];
+            float bmr[16];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int m = min(m0 + wm * 64 + s2 * 4 + rr, g.M - 1);
+                bmr[s2] = g.bias_m ? g.bias_m[m] : 0.f;
+                rres[s2] = Rp ? *reinterpret_cast<const f32x4*>(Rp + (long)m * g.ldr + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int row = s2 * 4 + rr, m = m0 + wm * 64 + row;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pl + row * 68 + 4 * c);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = a[e] * g.alpha + bmr[s2];
+                    t += b4[e];
+                    if (g.act == ACT_GELU) t = gelu_erf(t);
+                    o[e] = t + rres[s2][e];
+                }
+                if (m < g.M && n < g.N) *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + n) = o;
+            }
+            return;
+        }
+    }
     // Every load of the epilogue is issued BEFORE its first store.  Loads and stores share one counter on this part (vmcnt) and the compiler cannot tell that the
     // residual does not alias C (it usually IS C: x = x + proj), so with the loads inside the store loop every one of the sixteen (row tile, column quad) steps was
     // "load R; s_waitcnt vmcnt(0); store C" - a wait for the PREVIOUS step's stores to complete each time, ~0.7 us of L2 round trip sixteen times per tile with every
@@ -799,7 +866,27 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     const int nk_all = g.K / GBK, ksl = KS ? (int)gridDim.z : 1, kz = KS ? (int)blockIdx.z : 0;
     const int kt_first = kz * (nk_all / ksl) + min(kz, nk_all % ksl);
     const int nk = nk_all / ksl + (kz < nk_all % ksl ? 1 : 0);
+#ifdef BEVGEN_GEMM_TRACE
+    unsigned long long gt[5] = {};
+    gt[0] = __builtin_amdgcn_s_memrealtime();
+    gemm_tile<MODE, WM, S, W16, KS, TI, TJ>(g, tx, ty, kt_first, nk, ksl, kz, 0, 0, (int)threadIdx.x, gt);
+    if (MODE == MODE_PLAIN && WM == 4) {
+        gt[3] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        gt[4] = __builtin_amdgcn_s_memrealtime();
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (threadIdx.x == 0 && lin < 2048) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            for (int i = 0; i < 5; ++i) g_gemm_trace[lin * 8 + i] = gt[i];
+            g_gemm_trace[lin * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+#else
     gemm_tile<MODE, WM, S, W16, KS, TI, TJ>(g, tx, ty, kt_first, nk, ksl, kz, 0, 0, (int)threadIdx.x);
+#endif
 }
 
 // Stream-K form for problems whose tile count does not fill whole rounds of the chip (one or two scenes: 144 / 48 / 258 tiles of 256 x 128 on 256 CUs).  The work is cut
@@ -833,7 +920,11 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_sk_kernel(GemmArg
         // stays live across the whole body: 528 spilled VGPRs instead of none)
         int tid = (int)threadIdx.x;
         asm volatile("" : "+v"(tid));
-        gemm_tile<MODE_PLAIN, WM, S, W16, false, 2, 2, true>(g, (int)(t % gx), (int)(t / gx), k0, k1 - k0, 1, 0, role, first, tid);
+        gemm_tile<MODE_PLAIN, WM, S, W16, false, 2, 2, true>(g, (int)(t % gx), (int)(t / gx), k0, k1 - k0, 1, 0, role, first, tid
+#ifdef BEVGEN_GEMM_TRACE
+                                                             , g_gemm_tr_tmp
+#endif
+                                                             );
         __syncthreads();   // the next segment's first DMA overwrites stages the slowest wave may still be reading
     }
 }
@@ -844,6 +935,13 @@ __global__ __launch_bounds__(WM * 128, 1) void gemm_split_glds_sk_kernel(GemmArg
 // about the throughput kernel: 35 us of fixed time per three-round launch (ring fill + epilogue drain, ~12 us per round) + 3.92 us per k-tile = 411 TF-equiv asymptotically,
 // 0.39 of the ceiling at K = 1024.)
 
+#ifdef BEVGEN_GEMM_TRACE
+}  // namespace bevgen
+extern "C" __attribute__((visibility("default"))) int bevgen_debug_gemm_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bevgen::g_gemm_trace), sizeof(bevgen::g_gemm_trace));
+}
+namespace bevgen {
+#endif
 size_t gemm_sk_ws_bytes() { return 1024 * sizeof(float) + (size_t)256 * (8 * 4 * 16 * 64) * sizeof(float); }   // 1024 flag words + 256 workgroup slots of 128 KiB
 
 // Does the stream-K form pay?  T tiles of 256 x 128 cost ceil(T / 256) rounds of the chip; the form removes the empty part of the last round (and the second launch of a
@@ -876,6 +974,8 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.A_hi && g.A_lo && g.B_hi && g.B_lo, "gemm_split_glds: both operands must be pre-split");
     g.status = status_current();
     static const int rpf_env = getenv("BEVGEN_GEMM_RPF") ? atoi(getenv("BEVGEN_GEMM_RPF")) : 1;   // residual prefetch in the k loop's tail (0: off, for A/B runs; profiles/r06_ab_gemm_rpf.txt)
+    static const int rme_env = getenv("BEVGEN_GEMM_RME") ? atoi(getenv("BEVGEN_GEMM_RME")) : 1;   // row-major store form of the plain epilogue (0: accumulator-layout stores, A/B runs)
+    g.row_major_epi = rme_env != 0;
     g.r_prefetch = rpf_env && g.mode == MODE_PLAIN && g.R && (g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.R) & 15) == 0 && (long)g.M * g.ldr * 4 < 0x7FFFFFFFL && g.N >= 64;
     if (g.gn_part)
         BG_REQUIRE(g.mode == MODE_CONV3 && g.epi == 0 && g.ksplit <= 1 && g.M % 256 == 0 && g.m_base == 0 && g.N % GBN == 0 && g.ldc == g.N && (g.ldc & 3) == 0 &&
@@ -994,21 +1094,21 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
     dim3 grid(cdiv(g.N, GBN), cdiv(rows, tbm), g.ksplit);
-    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16) + ((g.ln_in_stats || g.ln_in_gsums) ? 4096 : 0);   // (+ the folded LayerNorm's per-row (mean, rstd) slots)
+    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16) + ((g.ln_in_stats || g.ln_in_gsums || g.r_prefetch) ? 4096 : 0) + (g.r_prefetch ? 2048 : 0);   // (+ the folded LayerNorm's per-row (mean, rstd) slots)
     static std::atomic<bool> attr_set[kMaxDevices];
     const int dslot = device_slot();
     if (!attr_set[dslot].load(std::memory_order_acquire)) {
 #define BG_SET(K, BYTES) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2 + 6144);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2 + 6144);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3>), 3 * 384 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2 + 6144);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2 + 6144);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2 + 4096);

@@ -77,6 +77,7 @@ struct GemmArgs {
     bool no_row_split = false;        // launcher-internal
     int force_wm = 0;                 // launcher-internal: 4 = keep 256-row blocks (the whole-rounds part of a row-split launch)
     unsigned* status = nullptr;       // the context's device status word (common.h BG_ST_*), filled in by the launchers: an operand outside the f16 range raises BG_ST_F16_RANGE
+    bool row_major_epi = false;       // launcher-internal: the plain epilogue of the throughput instantiation stores row-major through LDS (see gemm_tile)
     bool r_prefetch = false;          // launcher-internal (LDS-DMA kernel, 64 x 64 wave patches): the tile's residual lines are requested during the last k-tiles (see gemm_tile)
     // LayerNorm folded across two LDS-DMA GEMMs (Route M, muse_net:62-69: gamma-only LayerNorm, beta is a zero buffer), no pass over the activation in between:
     //   PRODUCER (ln_out_planes != null; EPI_GEGLU, or the plain epilogue): the output rows leave (also / instead of C) as the RAW (hi, lo) planes [M][ln_out_ld / 32][hi | lo]
