@@ -42,9 +42,28 @@ __device__ __forceinline__ float row16_sum(float d) {
     return d;
 }
 
+// x / d for many x and ONE d (a row's l2norm): the compiler's IEEE division is ten instructions per quotient (v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup)
+// and the fused q / k epilogues do 128 of them per lane - 5 of the 8 us that epilogue held the CU's VALUs with every matrix pipe idle.  The scaling and fix-up steps only
+// serve operands near the ends of the exponent range; here d is in [1e-12, 1e6] and |x| below 1e6, so Markstein's sequence with a refined reciprocal gives the correctly
+// rounded quotient in three instructions: q0 = x r, e = x - d q0 (exact in fma), q = q0 + e r.
+struct RowDiv {
+    float d, r;
+    __device__ __forceinline__ explicit RowDiv(float d_) : d(d_) {
+        float r0 = __builtin_amdgcn_rcpf(d_);
+        const float e = fmaf(-d_, r0, 1.0f);
+        r0 = fmaf(e, r0, r0);
+        const float e2 = fmaf(-d_, r0, 1.0f);
+        r = fmaf(e2, r0, r0);
+    }
+    __device__ __forceinline__ float operator()(float x) const {
+        const float q0 = x * r;
+        const float e = fmaf(-d, q0, x);
+        return fmaf(e, r, q0);
+    }
+};
 constexpr int GBN = 128, GBK = 32;
 #ifdef BEVGEN_GEMM_TRACE   // tools/gemm_trace: phase stamps (100 MHz clock) of the first 2048 workgroups of the LAST throughput launch: entry, first tile landed, loop done, epilogue issued, stores acknowledged
-__device__ unsigned long long g_gemm_trace[2048 * 8];
+__device__ unsigned long long g_gemm_trace[5 * 2048 * 8];   // [epilogue kind][workgroup][stamp]
 __device__ unsigned long long g_gemm_tr_tmp[2];
 #define GT_STAMP(i) do { if (MODE == MODE_PLAIN && WM == 4) gt[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -494,6 +513,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
+    // Row-major store forms of the throughput instantiation (STG): a wave stages its 64 x 64 patch in its own 17 KB of the dead stage ring (row stride 68 floats) in the
+    // accumulator layout and stores it from a row-major view - see the plain epilogue below for the measurement behind it.  The per-row arithmetic (l2norm, GEGLU, the
+    // LayerNorm statistics) stays on the accumulator side, element for element as in the direct forms: results are bit-identical, only the store instructions change.
+    constexpr bool STG = MODE == MODE_PLAIN && WM == 4 && S == 3 && TI == 2 && TJ == 2 && !KS && !SKK;
+    float* const pl = reinterpret_cast<float*>(smem_g) + wave * (64 * 68);
+    // the row-major view of a 64-column patch: 8 lanes x 8 columns per row, 8 rows per pass
+    const int rm_row = lane >> 3, rm_c8 = lane & 7;
+    auto stage_read8 = [&](int row, f32x4& a0, f32x4& a1) {
+        a0 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * rm_c8);
+        a1 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * rm_c8 + 4);
+    };
+    auto split8 = [&](const f32x4& a0, const f32x4& a1, half8& hi8, half8& lo8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi8[e] = split_hi(a0[e]); lo8[e] = split_lo(a0[e], hi8[e]);
+            hi8[4 + e] = split_hi(a1[e]); lo8[4 + e] = split_lo(a1[e], hi8[4 + e]);
+        }
+    };
     if constexpr (TJ == 2) {   // the fused epilogues and the split-K partial store assume 64-column wave patches
     // (a width that is not a multiple of 128 - dim 192: three heads - leaves the last tile's second wave without columns: its 64-column patch is not a head / an x|gate pair)
     if (MODE == MODE_PLAIN && g.epi != EPI_PLAIN && n0 + wn * 64 >= g.N) return;
@@ -512,6 +549,52 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) qsc4[j][qq] = *reinterpret_cast<const f32x4*>(qsc + j * 32 + 8 * qq + 4 * h);
+        if constexpr (STG) {
+            if (g.row_major_epi) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    float v[2][16];
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            v[j][q] = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha * 8.0f;
+                            ss = fmaf(v[j][q], v[j][q], ss);
+                        }
+                    ss += xor32(ss);
+                    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                    const RowDiv rdiv(nrm);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const f32x4 sc = qsc4[j][qq];
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (rdiv(v[j][qq * 4 + e]) * sc[e]) * g.epi_post;
+                            *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + j * 32 + 8 * qq + 4 * h) = o;
+                        }
+                }
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int row = ps * 8 + rm_row, m = m0 + wm * 64 + row;
+                    f32x4 a0, a1;
+                    stage_read8(row, a0, a1);
+                    half8 hi8, lo8;
+                    split8(a0, a1, hi8, lo8);
+                    if (m < g.M) {
+                        guard_half8(hi8, bad);
+                        const int bb = m / g.epi_rows, nq = m - bb * g.epi_rows;
+                        const long dst = (((long)bb * g.epi_heads + head) * g.epi_rows + nq) * 64 + 8 * rm_c8;
+                        *reinterpret_cast<half8*>(Qh + dst) = hi8;
+                        *reinterpret_cast<half8*>(Ql + dst) = lo8;
+                    }
+                }
+                if (bad) status_raise(g.status, BG_ST_F16_RANGE);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
@@ -526,6 +609,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                 }
             ss += xor32(ss);
             const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                    const RowDiv rdiv(nrm);
             if (m >= g.M) continue;
             const int bb = m / g.epi_rows, nq = m - bb * g.epi_rows;
             const long dst = (((long)bb * g.epi_heads + head) * g.epi_rows + nq) * 64;
@@ -538,7 +622,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                     half4_t hi4, lo4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float qv = ((v[j][qq * 4 + e] / nrm) * sc[e]) * g.epi_post;   // epi_post: the attention's score scale, folded into q
+                        const float qv = (rdiv(v[j][qq * 4 + e]) * sc[e]) * g.epi_post;   // epi_post: the attention's score scale, folded into q
                         hi4[e] = split_hi(qv);
                         lo4[e] = split_lo(qv, hi4[e]);
                     }
@@ -565,6 +649,58 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) ksc4[j][qq] = *reinterpret_cast<const f32x4*>(g.epi_scale + j * 32 + 8 * qq + 4 * h);
+        if constexpr (STG) {
+            if (g.row_major_epi && !is_v) {   // (the key planes; the transposed value planes keep the direct form: 64 contiguous bytes per column and instruction already)
+                _Float16* Kh = reinterpret_cast<_Float16*>(g.epi_hi);
+                _Float16* Kl = reinterpret_cast<_Float16*>(g.epi_lo);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    float v[2][16];
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            v[j][q] = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha;
+                            ss = fmaf(v[j][q], v[j][q], ss);
+                        }
+                    ss += xor32(ss);
+                    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                    const RowDiv rdiv(nrm);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const f32x4 sc = ksc4[j][qq];
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = rdiv(v[j][qq * 4 + e]) * sc[e];
+                            *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + j * 32 + 8 * qq + 4 * h) = o;
+                        }
+                }
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int row = ps * 8 + rm_row, m = m0 + wm * 64 + row;
+                    f32x4 a0, a1;
+                    stage_read8(row, a0, a1);
+                    half8 hi8, lo8;
+                    split8(a0, a1, hi8, lo8);
+                    if (m < g.M) {
+                        guard_half8(hi8, bad);
+                        const int bb = m / g.epi_rows, nk = m - bb * g.epi_rows;
+                        const long dst = (((long)bb * g.epi_heads + head) * g.epi_ld + 1 + nk) * 64 + 8 * rm_c8;
+                        *reinterpret_cast<half8*>(Kh + dst) = hi8;
+                        *reinterpret_cast<half8*>(Kl + dst) = lo8;
+                        if (nk == 0) {   // the learned null key of this (batch, head): row 0
+                            *reinterpret_cast<half8*>(Kh + dst - 64) = *reinterpret_cast<const half8*>(aux + head * 64 + 8 * rm_c8);
+                            *reinterpret_cast<half8*>(Kl + dst - 64) = *reinterpret_cast<const half8*>(aux + HD + head * 64 + 8 * rm_c8);
+                        }
+                    }
+                }
+                if (bad) status_raise(g.status, BG_ST_F16_RANGE);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
@@ -583,6 +719,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
             if (m >= g.M) continue;
             if (!is_v) {
                 const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+                    const RowDiv rdiv(nrm);
                 _Float16* Kh = reinterpret_cast<_Float16*>(g.epi_hi);
                 _Float16* Kl = reinterpret_cast<_Float16*>(g.epi_lo);
                 const long dst = (((long)bb * g.epi_heads + head) * g.epi_ld + 1 + nk) * 64;
@@ -595,7 +732,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                         half4_t hi4, lo4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float kv = (v[j][qq * 4 + e] / nrm) * sc[e];
+                            const float kv = rdiv(v[j][qq * 4 + e]) * sc[e];
                             hi4[e] = split_hi(kv);
                             lo4[e] = split_lo(kv, hi4[e]);
                         }
@@ -637,6 +774,50 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
         float* C = g.C;
         _Float16* Pp = reinterpret_cast<_Float16*>(g.ln_out_planes);   // folded LayerNorm, producer side: raw planes + per-(row, 32 columns) statistics instead of fp32 C
         unsigned bad = 0;
+        if constexpr (STG) {
+            if (g.row_major_epi && Pp) {
+                // the wave's 32 outputs of a row are ONE 128-byte line of the plane image ([hi 32 | lo 32] halves): staged [64 rows][32 outputs], then 8 lanes per row
+                // (4 x 8 hi halves, 4 x 8 lo halves) write the whole line, 8 rows per instruction.  Statistics on the accumulator side, as in the direct form
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int m = m0 + wm * WROWS + i * 32 + r;
+                    const int mc = min(m, g.M - 1);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int q = qq * 4 + e;
+                            const float xa = (accM[i][0][q] + accC[i][0][q] * kGLoInv) * g.alpha;
+                            const float gt = (accM[i][1][q] + accC[i][1][q] * kGLoInv) * g.alpha;
+                            v[e] = gt * gelu_erf(xa);
+                        }
+                        s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                        s2 += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
+                        *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + 8 * qq + 4 * h) = v;
+                    }
+                    s1 += xor32(s1); s2 += xor32(s2);
+                    if (h == 0 && m < g.M) reinterpret_cast<float2*>(g.ln_out_stats)[(long)((n0 >> 6) + wn) * g.ln_rows + mc] = make_float2(s1, s2);
+                }
+                const int c4 = rm_c8 & 3, lo_half = rm_c8 >> 2;   // lanes 0-3 of a row: the hi halves of outputs 8 c4 .. 8 c4 + 7, lanes 4-7 the lo halves
+                const int c32 = (n0 >> 1) + wn * 32;              // first output column of the wave (a multiple of 32)
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int row = ps * 8 + rm_row, m = m0 + wm * 64 + row;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * c4);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * c4 + 4);
+                    half8 hi8, lo8;
+                    split8(a0, a1, hi8, lo8);
+                    if (m < g.M) {
+                        if (!lo_half) guard_half8(hi8, bad);
+                        *reinterpret_cast<half8*>(Pp + (long)m * 2 * g.ln_out_ld + (c32 >> 5) * 64 + 8 * c4 + (lo_half ? 32 : 0)) = lo_half ? lo8 : hi8;
+                    }
+                }
+                if (bad) status_raise(g.status, BG_ST_F16_RANGE);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int m = m0 + wm * WROWS + i * 32 + r;
@@ -713,7 +894,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     // ring any more (the stale look-ahead fetch of the last iteration is never used), and a wave only touches its own slice.
     if constexpr (MODE == MODE_PLAIN && WM == 4 && S == 3 && TI == 2 && TJ == 2 && !KS && !SKK) {
         if (g.row_major_epi && vec_ok && (g.N & 3) == 0 && !g.ln_out_planes) {
-            float* pl = reinterpret_cast<float*>(smem_g) + wave * (64 * 68);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -880,8 +1060,11 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             unsigned hwid;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            for (int i = 0; i < 5; ++i) g_gemm_trace[lin * 8 + i] = gt[i];
-            g_gemm_trace[lin * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
+            unsigned long long* rec = g_gemm_trace + ((long)g.epi * 2048 + lin) * 8;
+            for (int i = 0; i < 5; ++i) rec[i] = gt[i];
+            rec[5] = ((unsigned long long)xcc << 32) | hwid;
+            rec[6] = ((unsigned long long)gridDim.x << 32) | gridDim.y;
+            rec[7] = ((unsigned long long)(unsigned)g.K << 32) | (g.R ? 1u : 0u) | (g.ln_in_stats || g.ln_in_gsums ? 2u : 0u) | (g.ln_out_planes ? 4u : 0u);
         }
     }
 #else
