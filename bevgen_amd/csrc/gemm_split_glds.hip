@@ -33,6 +33,7 @@
 namespace bevgen {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // sum over an aligned row of 16 lanes with DPP row operations (every lane of the row ends with the row's sum)
 __device__ __forceinline__ float row16_sum(float d) {
     d += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(d), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
@@ -513,11 +514,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
-    // Row-major store forms of the throughput instantiation (STG): a wave stages its 64 x 64 patch in its own 17 KB of the dead stage ring (row stride 68 floats) in the
+    // Row-major store forms of the throughput instantiation (STG): a wave stages its 64 x 64 patch in its own 18 KB of the dead stage ring (row stride 68 floats) in the
     // accumulator layout and stores it from a row-major view - see the plain epilogue below for the measurement behind it.  The per-row arithmetic (l2norm, GEGLU, the
     // LayerNorm statistics) stays on the accumulator side, element for element as in the direct forms: results are bit-identical, only the store instructions change.
     constexpr bool STG = MODE == MODE_PLAIN && WM == 4 && S == 3 && TI == 2 && TJ == 2 && !KS && !SKK;
-    float* const pl = reinterpret_cast<float*>(smem_g) + wave * (64 * 68);
+    float* const pl = reinterpret_cast<float*>(smem_g) + wave * (64 * 72);   // (18 KB slices: the transposed value form below needs 64 x 72 words, and a tile may hold both kinds of waves)
     // the row-major view of a 64-column patch: 8 lanes x 8 columns per row, 8 rows per pass
     const int rm_row = lane >> 3, rm_c8 = lane & 7;
     auto stage_read8 = [&](int row, f32x4& a0, f32x4& a1) {
@@ -650,7 +651,76 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) ksc4[j][qq] = *reinterpret_cast<const f32x4*>(g.epi_scale + j * 32 + 8 * qq + 4 * h);
         if constexpr (STG) {
-            if (g.row_major_epi && !is_v) {   // (the key planes; the transposed value planes keep the direct form: 64 contiguous bytes per column and instruction already)
+            // The TRANSPOSED value planes [B, H, 64, ld]: the direct form is 128 two-byte store instructions per wave (32 tokens x 2 columns each) - the longest epilogue
+            // of the step (12 us + 4 us until the CU is free again, tools/gemm_trace.py).  Staged: the patch goes to LDS transposed, [column d][1 + token] as packed
+            // (hi | lo << 16) words - one column of padding in front because key position = 1 + token (position 0 of a batch element is the learned null value), so that
+            // the 16-byte groups of the PLANE rows are 16-byte groups of the LDS rows - and leaves as 8 positions per lane: one 16-byte store per plane for seven lanes of
+            // a column, the first lane its 7 real positions in pieces (or all 8 when position 0 is the null value), one lane the patch's last token.  80 store
+            // instructions per wave instead of 128, 1400 lane-stores instead of 8192.  Needs the patch inside one batch element and the problem (epi_rows % 64 == 0,
+            // epi_ld % 8 == 0, no ragged last tile); otherwise the direct form below.
+            const int prow0 = m0 + wm * 64;
+            if (g.row_major_epi && is_v && (g.epi_rows & 63) == 0 && (g.epi_ld & 7) == 0 && prow0 + 64 <= g.M) {
+                unsigned* plu = reinterpret_cast<unsigned*>(smem_g) + wave * (64 * 72);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float val = (accM[i][j][q] + accC[i][j][q] * kGLoInv) * g.alpha;
+                            const _Float16 hi = split_hi(val);
+                            const _Float16 lo = split_lo(val, hi);
+                            const int d = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                            plu[d * 72 + 1 + i * 32 + r] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                        }
+                const int bb = prow0 / g.epi_rows, nk0 = prow0 - bb * g.epi_rows;   // (wave-uniform)
+                _Float16* Vh = reinterpret_cast<_Float16*>(g.epi_hi2);
+                _Float16* Vl = reinterpret_cast<_Float16*>(g.epi_lo2);
+                const int gq = lane & 7;
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int d = ps * 8 + (lane >> 3);
+                    const u32x4 u0 = *reinterpret_cast<const u32x4*>(plu + d * 72 + 8 * gq);
+                    const u32x4 u1 = *reinterpret_cast<const u32x4*>(plu + d * 72 + 8 * gq + 4);
+                    u32x4 hw, lw;   // positions 8 gq .. 8 gq + 7 of column d: hi halves, lo halves
+                    hw[0] = __builtin_amdgcn_perm(u0[1], u0[0], 0x05040100u); lw[0] = __builtin_amdgcn_perm(u0[1], u0[0], 0x07060302u);
+                    hw[1] = __builtin_amdgcn_perm(u0[3], u0[2], 0x05040100u); lw[1] = __builtin_amdgcn_perm(u0[3], u0[2], 0x07060302u);
+                    hw[2] = __builtin_amdgcn_perm(u1[1], u1[0], 0x05040100u); lw[2] = __builtin_amdgcn_perm(u1[1], u1[0], 0x07060302u);
+                    hw[3] = __builtin_amdgcn_perm(u1[3], u1[2], 0x05040100u); lw[3] = __builtin_amdgcn_perm(u1[3], u1[2], 0x07060302u);
+                    const long rowp = (((long)bb * g.epi_heads + head) * 64 + d) * g.epi_ld + nk0 + 8 * gq;   // position nk0 + 8 gq of this column's plane row
+                    if (gq == 0) {
+                        if (nk0 == 0) {   // position 0 = the learned null value of this (batch, head)
+                            hw[0] = (hw[0] & 0xFFFF0000u) | (unsigned)__builtin_bit_cast(unsigned short, aux[2 * HD + head * 64 + d]);
+                            lw[0] = (lw[0] & 0xFFFF0000u) | (unsigned)__builtin_bit_cast(unsigned short, aux[3 * HD + head * 64 + d]);
+                            bad |= f16x2_nonfinite(hw[0] & 0xFFFF0000u) | f16x2_nonfinite(hw[1]) | f16x2_nonfinite(hw[2]) | f16x2_nonfinite(hw[3]);
+                            *reinterpret_cast<u32x4*>(Vh + rowp) = hw;
+                            *reinterpret_cast<u32x4*>(Vl + rowp) = lw;
+                        } else {          // position nk0 belongs to the patch above: 7 positions in pieces of 2, 4 and 8 bytes
+                            bad |= f16x2_nonfinite(hw[0] & 0xFFFF0000u) | f16x2_nonfinite(hw[1]) | f16x2_nonfinite(hw[2]) | f16x2_nonfinite(hw[3]);
+                            *reinterpret_cast<unsigned short*>(Vh + rowp + 1) = (unsigned short)(hw[0] >> 16);
+                            *reinterpret_cast<unsigned short*>(Vl + rowp + 1) = (unsigned short)(lw[0] >> 16);
+                            *reinterpret_cast<unsigned*>(Vh + rowp + 2) = hw[1];
+                            *reinterpret_cast<unsigned*>(Vl + rowp + 2) = lw[1];
+                            *reinterpret_cast<uint2*>(Vh + rowp + 4) = make_uint2(hw[2], hw[3]);
+                            *reinterpret_cast<uint2*>(Vl + rowp + 4) = make_uint2(lw[2], lw[3]);
+                        }
+                    } else {
+                        bad |= f16x2_nonfinite(hw[0]) | f16x2_nonfinite(hw[1]) | f16x2_nonfinite(hw[2]) | f16x2_nonfinite(hw[3]);
+                        *reinterpret_cast<u32x4*>(Vh + rowp) = hw;
+                        *reinterpret_cast<u32x4*>(Vl + rowp) = lw;
+                        if (gq == 1) {    // the patch's last token: position nk0 + 64
+                            const unsigned ut = plu[d * 72 + 64];
+                            bad |= f16x2_nonfinite(ut & 0xFFFFu);
+                            const long tp = (((long)bb * g.epi_heads + head) * 64 + d) * g.epi_ld + nk0 + 64;
+                            *reinterpret_cast<unsigned short*>(Vh + tp) = (unsigned short)(ut & 0xFFFFu);
+                            *reinterpret_cast<unsigned short*>(Vl + tp) = (unsigned short)(ut >> 16);
+                        }
+                    }
+                }
+                if (bad) status_raise(g.status, BG_ST_F16_RANGE);
+                return;
+            }
+            if (g.row_major_epi && !is_v) {   // the key planes
                 _Float16* Kh = reinterpret_cast<_Float16*>(g.epi_hi);
                 _Float16* Kl = reinterpret_cast<_Float16*>(g.epi_lo);
 #pragma unroll
