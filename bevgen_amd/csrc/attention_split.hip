@@ -60,6 +60,7 @@ __device__ unsigned long long g_attn_trace[8 * 16 * 8];   // [wave][tile][stamp]
 template <bool TRACE, bool KS = false>
 __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2][4][PP_PLANE];   // [stage][Kh, Kl, Vh, Vl]
+    __shared__ __attribute__((aligned(16))) float ostage[KS ? 1 : 8][KS ? 4 : 32 * 68];   // output rows of a wave on their way to row-major stores (epilogue)
 #ifdef BEVGEN_ATTN_LAB
     __shared__ unsigned long long trace_lds[TRACE ? 8 * 16 * 8 : 1];
 #endif
@@ -281,6 +282,45 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
         return;
     }
     const float inv = 1.f / l_tot;
+    if (!KS && a.Op) {
+        // Plane output, row-major.  In the accumulator layout a store instruction is 64 rows x 8 bytes - 64 partial lines - and sixteen of them per wave held the CU
+        // ~6 us per workgroup with nothing else to run (the LDS-DMA GEMM's epilogue had the same disease: tools/storebw, experiments/r06.md).  A (row, head) pair is
+        // 256 contiguous bytes of the plane image ([hi 32 | lo 32] of dims 0-31, then of dims 32-63): the wave's 32 rows go through its own LDS slice (row stride 68
+        // floats: conflict-free both ways) and leave as 16 lanes x 16 bytes per row, 4 rows per instruction - 8 store instructions of whole lines.  Same arithmetic per
+        // element: bit-identical output.
+        float* st = ostage[KS ? 0 : wave];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (oM[t][4 * g + j] + oC[t][4 * g + j] * kLoI) * inv;
+                *reinterpret_cast<f32x4*>(st + qi * 68 + 32 * t + 8 * g + 4 * h) = o;
+            }
+        const int c = lane & 15, rr = lane >> 4;
+        const int dsel = (c >> 3) * 32 + (c & 3) * 8;   // this lane's 8 dims; lanes with bit 2 of c set store their lo parts
+        const bool lo_sel = (c >> 2) & 1;
+        unsigned bad = 0;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 4 + rr, q = qblk * 256 + wave * 32 + row;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(st + row * 68 + dsel);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(st + row * 68 + dsel + 4);
+            half8 hi8, lo8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi8[e] = split_hi(a0[e]); lo8[e] = split_lo(a0[e], hi8[e]);
+                hi8[4 + e] = split_hi(a1[e]); lo8[4 + e] = split_lo(a1[e], hi8[4 + e]);
+            }
+            if (q < a.Nq) {
+                if (!lo_sel) guard_half8(hi8, bad);
+                *reinterpret_cast<half8*>(a.Op + ((long)b * a.Nq + q) * 2 * (a.H * 64) + head * 128 + c * 8) = lo_sel ? lo8 : hi8;
+            }
+        }
+        if (bad) status_raise(a.status, BG_ST_F16_RANGE);
+        return;
+    }
     if (qvalid) {
         unsigned bad = 0;
         const long orow = (long)b * a.o_bstride + (long)qrow * a.o_qstride + (long)head * a.o_hstride;
