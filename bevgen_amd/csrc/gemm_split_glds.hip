@@ -66,7 +66,7 @@ constexpr int GBN = 128, GBK = 32;
 #ifdef BEVGEN_GEMM_TRACE   // tools/gemm_trace: phase stamps (100 MHz clock) of the first 2048 workgroups of the LAST throughput launch: entry, first tile landed, loop done, epilogue issued, stores acknowledged
 __device__ unsigned long long g_gemm_trace[5 * 2048 * 8];   // [epilogue kind][workgroup][stamp]
 __device__ unsigned long long g_gemm_tr_tmp[2];
-#define GT_STAMP(i) do { if (MODE == MODE_PLAIN && WM == 4) gt[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GT_STAMP(i) do { if (MODE == MODE_PLAIN && !KS) gt[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GT_STAMP(i) do { } while (0)
 #endif
@@ -298,33 +298,44 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     // merged the producer's group sums (ln_in_stats: large batches - one small kernel per LayerNorm instead of a merge per tile), or this wave merges them itself
     // (ln_in_gsums: one or two scenes, where every workgroup runs one tile and a launch costs more than the merge): lane l takes row l of the wave's 64 (32-row patches: the
     // lane halves split the groups by parity), sixteen loads in flight, fp64 sums in a fixed order.
-    float* ln_slot = reinterpret_cast<float*>(smem_g + S * STAGE_H) + wave * 128;   // [64 rows][mean, rstd]
+    float* ln_rowstat = reinterpret_cast<float*>(smem_g + S * STAGE_H);   // [TBM rows][mean, rstd] of the block's rows
     if (MODE == MODE_PLAIN && g.ln_in_stats) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int m = min(m0 + wm * WROWS + i * 32 + r, g.M - 1);
-            const float2 mr = reinterpret_cast<const float2*>(g.ln_in_stats)[m];
-            if (h == 0) *reinterpret_cast<float2*>(ln_slot + (i * 32 + r) * 2) = mr;
+        if (tid < TBM) {
+            const int m = min(m0 + tid, g.M - 1);
+            *reinterpret_cast<float2*>(ln_rowstat + tid * 2) = reinterpret_cast<const float2*>(g.ln_in_stats)[m];
         }
     } else if (MODE == MODE_PLAIN && g.ln_in_gsums) {
-        constexpr bool HALVES = WROWS == 32;                 // 32-row patches: rows l & 31, groups of parity l >> 5
-        const int row = HALVES ? r : lane;
-        const int m = min(m0 + wm * WROWS + row, g.M - 1);
+        // the whole block merges together: thread -> (row tid % TBM, part tid / TBM); a part takes every PARTS-th group (one or two batches of loads in flight, where
+        // a wave merging its own rows needed three to six round trips: 5.3 -> ~2 us of ring-fill time at one scene's down-projection); fp64 partial sums meet in LDS
+        // (8 KB behind the LayerNorm slots and the prefetch sink) and are added in part order - a fixed order
+        constexpr int NT = NW * 64, PARTS = NT / TBM;
+        static_assert(NT % TBM == 0, "threads per block row");
+        const int row = tid % TBM, part = tid / TBM;
+        const int m = min(m0 + row, g.M - 1);
         const float2* st = reinterpret_cast<const float2*>(g.ln_in_gsums) + m;
-        const int G = g.ln_in_groups, step = HALVES ? 2 : 1;
+        const int G = g.ln_in_groups;
         double s1 = 0.0, s2 = 0.0;
-        for (int g0 = HALVES ? h : 0; g0 < G; g0 += 16 * step) {
+        for (int g0 = part; g0 < G; g0 += 16 * PARTS) {
             float2 v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = st[(long)min(g0 + u * step, G - 1) * g.ln_rows];   // (clamped, never predicated: sixteen independent loads)
+            for (int u = 0; u < 16; ++u) v[u] = st[(long)min(g0 + u * PARTS, G - 1) * g.ln_rows];   // (clamped, never predicated: sixteen independent loads)
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                if (g0 + u * step < G) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
+                if (g0 + u * PARTS < G) { s1 += (double)v[u].x; s2 += (double)v[u].y; }
         }
-        if (HALVES) { s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); }
-        const double mean = s1 / (double)g.ln_in_count;
-        const double var = fmax(s2 / (double)g.ln_in_count - mean * mean, 0.0);
-        if (!HALVES || h == 0) *reinterpret_cast<float2*>(ln_slot + row * 2) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)g.ln_eps)));
+        double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(smem_g + S * STAGE_H) + 6144);   // [PARTS][TBM][2]
+        partial[(part * TBM + row) * 2] = s1;
+        partial[(part * TBM + row) * 2 + 1] = s2;
+        __syncthreads();
+        if (tid < TBM) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int pp = 0; pp < PARTS; ++pp) { t1 += partial[(pp * TBM + tid) * 2]; t2 += partial[(pp * TBM + tid) * 2 + 1]; }
+            const double mean = t1 / (double)g.ln_in_count;
+            const double var = fmax(t2 / (double)g.ln_in_count - mean * mean, 0.0);
+            *reinterpret_cast<float2*>(ln_rowstat + tid * 2) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)g.ln_eps)));
+        }
+        // (the k loop's barriers order these writes before the epilogue's reads)
     }
     wait_tiles<DMA, S - 1>(nk - 1);   // tile 0 landed; the other tiles of the prologue stay in flight
     __builtin_amdgcn_s_barrier();
@@ -493,7 +504,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     if (MODE == MODE_PLAIN && (g.ln_in_stats || g.ln_in_gsums)) {
         float ln_mean[TI], ln_rstd[TI];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) { const float2 mr = *reinterpret_cast<const float2*>(ln_slot + (i * 32 + r) * 2); ln_mean[i] = mr.x; ln_rstd[i] = mr.y; }
+        for (int i = 0; i < TI; ++i) { const float2 mr = *reinterpret_cast<const float2*>(ln_rowstat + (wm * WROWS + i * 32 + r) * 2); ln_mean[i] = mr.x; ln_rstd[i] = mr.y; }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -1120,7 +1131,7 @@ __global__ __launch_bounds__(WM * 512 / (TI * TJ), (WM == 2 && S == 2) ? 2 : 1) 
     unsigned long long gt[5] = {};
     gt[0] = __builtin_amdgcn_s_memrealtime();
     gemm_tile<MODE, WM, S, W16, KS, TI, TJ>(g, tx, ty, kt_first, nk, ksl, kz, 0, 0, (int)threadIdx.x, gt);
-    if (MODE == MODE_PLAIN && WM == 4) {
+    if (MODE == MODE_PLAIN && !KS) {
         gt[3] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         gt[4] = __builtin_amdgcn_s_memrealtime();
@@ -1266,7 +1277,7 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     // every segment refills the three-stage ring, and the workgroup that holds a tile's last k range merges while its peers idle - together more than the empty part of
     // the last round they remove.  $BEVGEN_GEMM_SK=1 routes by gemm_sk_pays, 2 takes the form whenever a workspace is given (the operator tests force it per call)
     static const int sk_env = getenv("BEVGEN_GEMM_SK") ? atoi(getenv("BEVGEN_GEMM_SK")) : 0;
-    if (g.sk_ws && (sk_env || g.sk_force) && g.mode == MODE_PLAIN && g.ksplit <= 1 && g.m_base == 0 && !g.no_row_split && !g.bias_m && xcd_placement_verified() &&
+    if (g.sk_ws && (sk_env || g.sk_force) && g.mode == MODE_PLAIN && g.ksplit <= 1 && g.m_base == 0 && !g.no_row_split && !g.bias_m && !g.ln_in_gsums && xcd_placement_verified() &&
         (sk_env == 2 || g.sk_force || gemm_sk_pays(g.M, g.N, g.K))) {
         static std::atomic<int> cu_count[kMaxDevices];
         static std::atomic<bool> sk_attr[kMaxDevices];
@@ -1347,37 +1358,38 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
     BG_REQUIRE(g.ksplit >= 1 && (g.ksplit == 1 || (g.kpart && g.epi == 0 && g.mode == MODE_PLAIN && wm == 2 && !half && g.K / GBK >= 2 * g.ksplit && !g.bias_m)),
                "gemm_split_glds: split-K needs a workspace, the plain epilogue, the 128-row tile and >= 2 k-tiles per slice (ksplit=%d K=%d)", g.ksplit, g.K);
     dim3 grid(cdiv(g.N, GBN), cdiv(rows, tbm), g.ksplit);
-    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16) + ((g.ln_in_stats || g.ln_in_gsums || g.r_prefetch) ? 4096 : 0) + (g.r_prefetch ? 2048 : 0);   // (+ the folded LayerNorm's per-row (mean, rstd) slots)
+    const size_t lds = (size_t)stages * (tbm + GBN) * 2 * GBK * sizeof(_Float16) + ((g.ln_in_stats || g.ln_in_gsums || g.r_prefetch) ? 4096 : 0) + ((g.r_prefetch || g.ln_in_gsums) ? 2048 : 0) +
+                       (g.ln_in_gsums ? 8192 : 0);   // LayerNorm (mean, rstd) slots | prefetch sink | the block merge's fp64 partial sums   // (+ the folded LayerNorm's per-row (mean, rstd) slots)
     static std::atomic<bool> attr_set[kMaxDevices];
     const int dslot = device_slot();
     if (!attr_set[dslot].load(std::memory_order_acquire)) {
 #define BG_SET(K, BYTES) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2 + 6144);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2>), 2 * 256 * 2 * GBK * 2 + 14336);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2 + 6144);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3>), 3 * 384 * 2 * GBK * 2 + 14336);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3>), 3 * 384 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2 + 6144);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true>), 2 * 256 * 2 * GBK * 2 + 14336);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 2, true>), 2 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2 + 6144);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 4, 3, true>), 3 * 384 * 2 * GBK * 2 + 14336);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 4, 3, true>), 3 * 384 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), 2 * 256 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, false, true>), 2 * 256 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 2, true, true>), 2 * 256 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, false, true, 1>), 4 * 256 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 2, 4, true, true, 1>), 4 * 256 * 2 * GBK * 2 + 14336);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, false, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
         BG_SET((gemm_split_glds_kernel<MODE_CONV3S, 2, 4, true, false, 1>), 4 * 256 * 2 * GBK * 2);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
-        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1, 1>), 4 * 192 * 2 * GBK * 2 + 4096);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1>), 4 * 192 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1>), 4 * 192 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, false, false, 1, 1>), 4 * 192 * 2 * GBK * 2 + 14336);
+        BG_SET((gemm_split_glds_kernel<MODE_PLAIN, 1, 4, true, false, 1, 1>), 4 * 192 * 2 * GBK * 2 + 14336);
 #undef BG_SET
         attr_set[dslot].store(true, std::memory_order_release);
     }

@@ -316,6 +316,9 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
                     gk.epi_post = 8.0f * kLog2e;   // sim = 8 q.k (muse_net:150) in the base-2 domain of the split attention kernel
                 }
                 if (f0) { cons_x.in_cs = merged ? l.fold_qkv_cs : l.fold_kv_self_cs; set_fold(gk, &cons_x, rows); }
+                // one scene: 144 blocks of 256 x 128 (one per CU, the staged row-major epilogue) against 288 of 128 x 128 sharing CUs in pairs on a two-stage ring
+                static const int qkv_wm4 = getenv("BEVGEN_QKV_WM4") ? atoi(getenv("BEVGEN_QKV_WM4")) : 1;   // (one scene 158.9 -> 153.8 ms, profiles/r06_ab_b1_qkv_wm4.txt; 0: A/B runs)
+                if (qkv_wm4 && merged) gk.force_wm = 4;
                 if (gemm_sk_pays(rows, gk.N, gk.K)) set_sk(gk, &w);
                 launch_gemm(gk, s);
             }

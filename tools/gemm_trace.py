@@ -20,7 +20,7 @@ def report(t, label):
     flags = int(t[0, 7] & 0xFFFFFFFF)
     t0 = t[:, 0].min()
     print(f"{label}: grid {gx} x {gy}, K={int(t[0, 7] >> 32)}, residual={flags & 1} ln consumer={(flags >> 1) & 1} ln producer={(flags >> 2) & 1}: {n} workgroups traced, span {us(t[:, 4].max() - t0):.1f} us")
-    for r in range((n + 255) // 256):
+    for r in range(min(3, (n + 255) // 256)):
         s = t[r * 256:(r + 1) * 256]
         f = lambda v: f"{us(np.median(v)):6.2f} [{us(v.min()):6.2f} .. {us(v.max()):6.2f}]"
         print(f"  round {r}: entry at {f(s[:, 0] - t0)} us | fill {f(s[:, 1] - s[:, 0])} | loop {f(s[:, 2] - s[:, 1])} | epilogue issue {f(s[:, 3] - s[:, 2])} | drain {f(s[:, 4] - s[:, 3])}")
