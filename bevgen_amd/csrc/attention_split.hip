@@ -60,7 +60,7 @@ __device__ unsigned long long g_attn_trace[8 * 16 * 8];   // [wave][tile][stamp]
 template <bool TRACE, bool KS = false>
 __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2][4][PP_PLANE];   // [stage][Kh, Kl, Vh, Vl]
-    __shared__ __attribute__((aligned(16))) float ostage[KS ? 1 : 8][KS ? 4 : 32 * 68];   // output rows of a wave on their way to row-major stores (epilogue)
+    __shared__ __attribute__((aligned(16))) float ostage[8][32 * 68];   // output rows of a wave on their way to row-major stores (epilogue)
 #ifdef BEVGEN_ATTN_LAB
     __shared__ unsigned long long trace_lds[TRACE ? 8 * 16 * 8 : 1];
 #endif
@@ -266,18 +266,28 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
 #endif
 
     const float l_tot = l_run + xor32(l_run);
-    if (KS) {   // partial result of this key range: unnormalised output row (relative to m_run), m_run, row sum
-        if (qvalid) {
-            float* wrow = a.kws + ((((long)ks * a.B + b) * a.H + head) * a.Nq + qrow) * 66;
+    if (KS) {   // partial result of this key range: unnormalised output row (relative to m_run), m_run, row sum - rows of kAttnPartPitch floats, stored row-major like the planes below
+        float* st = ostage[wave];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = 32 * t + 8 * g + 4 * h;
-                    *reinterpret_cast<float2*>(wrow + d) = make_float2(oM[t][4 * g] + oC[t][4 * g] * kLoI, oM[t][4 * g + 1] + oC[t][4 * g + 1] * kLoI);
-                    *reinterpret_cast<float2*>(wrow + d + 2) = make_float2(oM[t][4 * g + 2] + oC[t][4 * g + 2] * kLoI, oM[t][4 * g + 3] + oC[t][4 * g + 3] * kLoI);
-                }
-            if (h == 0) *reinterpret_cast<float2*>(wrow + 64) = make_float2(m_run, l_tot);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = oM[t][4 * g + j] + oC[t][4 * g + j] * kLoI;
+                *reinterpret_cast<f32x4*>(st + qi * 68 + 32 * t + 8 * g + 4 * h) = o;
+            }
+        if (h == 0) *reinterpret_cast<float2*>(st + qi * 68 + 64) = make_float2(m_run, l_tot);
+        const int c = lane & 15, rr = lane >> 4;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 4 + rr, q = qblk * 256 + wave * 32 + row;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 68 + 4 * c);
+            if (q < a.Nq) {
+                float* wrow = a.kws + ((((long)ks * a.B + b) * a.H + head) * a.Nq + q) * kAttnPartPitch;
+                *reinterpret_cast<f32x4*>(wrow + 4 * c) = v;
+                if (c == 0) *reinterpret_cast<float2*>(wrow + 64) = *reinterpret_cast<const float2*>(st + row * 68 + 64);
+            }
         }
         return;
     }
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
         // 256 contiguous bytes of the plane image ([hi 32 | lo 32] of dims 0-31, then of dims 32-63): the wave's 32 rows go through its own LDS slice (row stride 68
         // floats: conflict-free both ways) and leave as 16 lanes x 16 bytes per row, 4 rows per instruction - 8 store instructions of whole lines.  Same arithmetic per
         // element: bit-identical output.
-        float* st = ostage[KS ? 0 : wave];
+        float* st = ostage[wave];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -382,8 +392,8 @@ __global__ __launch_bounds__(256) void attention_split_combine_kernel(AttnSplitA
     const int d = (int)(i & 15) * 4;
     const long row = i >> 4;   // (b * H + head) * Nq + q
     const int q = (int)(row % a.Nq), head = (int)((row / a.Nq) % a.H), b = (int)(row / ((long)a.Nq * a.H));
-    const long stride = (long)a.B * a.H * a.Nq * 66;
-    const float* w0 = a.kws + row * 66;
+    const long stride = (long)a.B * a.H * a.Nq * kAttnPartPitch;
+    const float* w0 = a.kws + row * kAttnPartPitch;
     float m = kNegBig;
     for (int k = 0; k < a.ksplit; ++k) m = fmaxf(m, w0[k * stride + 64]);
     float l = 0.f;

@@ -196,7 +196,8 @@ struct AttnSplitArgs {
     float* kws = nullptr;             // attn_split_ws_floats(B, H, Nq, ksplit) floats
     unsigned* status = nullptr;       // the context's device status word, filled in by the launcher (an output plane value outside the f16 range: BG_ST_F16_RANGE)
 };
-inline long attn_split_ws_floats(int B, int H, int Nq, int ksplit) { return (long)ksplit * B * H * Nq * 66; }
+constexpr int kAttnPartPitch = 68;   // floats per partial row of the key-split Route-M attention: 64 output columns, running maximum, row sum, 2 of padding (16-byte rows)
+inline long attn_split_ws_floats(int B, int H, int Nq, int ksplit) { return (long)ksplit * B * H * Nq * kAttnPartPitch; }
 long attn_bias_packed_floats(int Nq, int Nk_pad);
 void launch_pack_attn_bias(const float* bias, int ld, int Nq, int Nk_pad, float* out, hipStream_t s);
 void launch_attn_split_operands(const float* q, const float* k, const float* v, void* Qh, void* Ql, void* Kh, void* Kl, void* VTh, void* VTl, int B, int H, int Nq, int Nk_pad,
