@@ -186,7 +186,40 @@ __device__ __forceinline__ float exp_softmax(float x) {
 }
 
 // erf-based GELU (torch nn.GELU() / F.gelu default)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erff of the device library (OCML), branch-free.  The library form is two branches (|y| < 1: an odd polynomial; else 1 - exp(-p(|y|))) - under divergence a wave runs both
+// plus the exec-mask bookkeeping, 32 times per lane in the GEGLU epilogue of the LDS-DMA GEMM.  Same coefficients and the same operation order here, both sides computed
+// unconditionally and selected; of the two range checks of the library's expf the overflow one is dropped (p is never negative).  Bit-identical to
+// erff for every one of the 2^32 float inputs (tools/erfcheck, run on the MI355X).
+__device__ __forceinline__ float erf_ocml(float y) {
+#pragma clang fp contract(off)   // (the library's operation sequence exactly: the explicit fmaf calls stay fused, nothing else is)
+    const float t = fabsf(y);
+    // |y| >= 1
+    float p = fmaf(t, __uint_as_float(0x378e98abu), __uint_as_float(0xb9c68948u));
+    p = fmaf(t, p, __uint_as_float(0x3b7cd369u));
+    p = fmaf(t, p, __uint_as_float(0xbcc618b2u));
+    p = fmaf(t, p, __uint_as_float(0x3dda74e4u));
+    p = fmaf(t, p, __uint_as_float(0x3f228afdu));
+    p = fmaf(t, p, __uint_as_float(0x3e03c728u));
+    p = fmaf(t, p, t);
+    const float nl2e = __uint_as_float(0xbfb8aa3bu);              // -log2(e), high part
+    const float ph = p * nl2e;
+    float pl = fmaf(p, nl2e, -ph);
+    pl = fmaf(p, __uint_as_float(0xb2a5705fu), pl);               // + p * (-log2(e), low part)
+    const float pn = __builtin_rintf(ph);
+    float e = ldexpf(__builtin_amdgcn_exp2f((ph - pn) + pl), (int)pn);
+    e = p > __uint_as_float(0x42ce8ed0u) ? 0.0f : e;               // (the library's underflow check; also the polynomial's overflow for |y| > 4e6: 1 - 0)
+    const float big = 1.0f - e;
+    // |y| < 1
+    const float s2 = y * y;
+    float q = fmaf(s2, __uint_as_float(0xba1345e1u), __uint_as_float(0x3ba10414u));
+    q = fmaf(s2, q, __uint_as_float(0xbcdac9b8u));
+    q = fmaf(s2, q, __uint_as_float(0x3de703beu));
+    q = fmaf(s2, q, __uint_as_float(0xbec09330u));
+    q = fmaf(s2, q, __uint_as_float(0x3e0375d0u));
+    const float small = fmaf(t, q, t);
+    return copysignf(t < 1.0f ? small : big, y);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_ocml(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }
 
 // Philox4x32-10 counter-based generator (Salmon et al. 2011): uniform in [0,1) with 24 random bits for element `idx` of noise stream (iter, stream) under `seed`.
