@@ -525,16 +525,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     // tile: lane -> output row m = lane&31, register q -> column n = (q&3) + 8*(q>>2) + 4*(lane>>5).  Four consecutive registers are four
     // consecutive columns of one row: one 16-byte store per lane and register quad (16 store instructions per wave instead of 64 - the
     // store tail is instruction-issue bound, MI355X guide T21).
-    // Row-major store forms of the throughput instantiation (STG): a wave stages its 64 x 64 patch in its own 18 KB of the dead stage ring (row stride 68 floats) in the
+    // Row-major store forms (STG): a wave stages its patch (64 x 64 in the throughput instantiation: 18 KB) in its own slice of the dead stage ring (row stride 68 floats) in the
     // accumulator layout and stores it from a row-major view - see the plain epilogue below for the measurement behind it.  The per-row arithmetic (l2norm, GEGLU, the
     // LayerNorm statistics) stays on the accumulator side, element for element as in the direct forms: results are bit-identical, only the store instructions change.
-    constexpr bool STG = MODE == MODE_PLAIN && WM == 4 && S == 3 && TI == 2 && TJ == 2 && !KS && !SKK;
-    float* const pl = reinterpret_cast<float*>(smem_g) + wave * (64 * 72);   // (18 KB slices: the transposed value form below needs 64 x 72 words, and a tile may hold both kinds of waves)
+    // (Also the small-problem shapes - 32-row patches of the eight-wave / 64-row blocks, 32 x 32 patches with the plain epilogue - wherever the ring holds the slices; not
+    // the two-stage 128-row block, whose 64 KB ring is smaller than its four slices.)
+    constexpr int VT_LD = WROWS == 64 ? 72 : 40;          // transposed value stage: [64 columns][1 + WROWS tokens], padded (4 VT_LD = 32 mod 64 banks)
+    constexpr int RS = TJ == 2 ? 68 : 36;                 // row stride (floats) of the row-major stage
+    constexpr int SLICE_W = TJ == 2 ? (64 * VT_LD > WROWS * RS ? 64 * VT_LD : WROWS * RS) : WROWS * RS;   // words per wave (a tile may hold both kinds of waves: one size)
+    constexpr bool STG = MODE == MODE_PLAIN && !KS && !SKK && !(WM == 2 && S == 2) && (TI == 2 ? TJ == 2 : true) && (long)NW * SLICE_W * 4 <= (long)S * STAGE_H * 2;
+    float* const pl = reinterpret_cast<float*>(smem_g) + wave * SLICE_W;
     // the row-major view of a 64-column patch: 8 lanes x 8 columns per row, 8 rows per pass
     const int rm_row = lane >> 3, rm_c8 = lane & 7;
     auto stage_read8 = [&](int row, f32x4& a0, f32x4& a1) {
-        a0 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * rm_c8);
-        a1 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * rm_c8 + 4);
+        a0 = *reinterpret_cast<const f32x4*>(pl + row * RS + 8 * rm_c8);
+        a1 = *reinterpret_cast<const f32x4*>(pl + row * RS + 8 * rm_c8 + 4);
     };
     auto split8 = [&](const f32x4& a0, const f32x4& a1, half8& hi8, half8& lo8) {
 #pragma unroll
@@ -585,12 +590,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                             f32x4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = (rdiv(v[j][qq * 4 + e]) * sc[e]) * g.epi_post;
-                            *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + j * 32 + 8 * qq + 4 * h) = o;
+                            *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * RS + j * 32 + 8 * qq + 4 * h) = o;
                         }
                 }
 #pragma unroll
-                for (int ps = 0; ps < 8; ++ps) {
-                    const int row = ps * 8 + rm_row, m = m0 + wm * 64 + row;
+                for (int ps = 0; ps < WROWS / 8; ++ps) {
+                    const int row = ps * 8 + rm_row, m = m0 + wm * WROWS + row;
                     f32x4 a0, a1;
                     stage_read8(row, a0, a1);
                     half8 hi8, lo8;
@@ -669,9 +674,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
             // a column, the first lane its 7 real positions in pieces (or all 8 when position 0 is the null value), one lane the patch's last token.  80 store
             // instructions per wave instead of 128, 1400 lane-stores instead of 8192.  Needs the patch inside one batch element and the problem (epi_rows % 64 == 0,
             // epi_ld % 8 == 0, no ragged last tile); otherwise the direct form below.
-            const int prow0 = m0 + wm * 64;
-            if (g.row_major_epi && is_v && (g.epi_rows & 63) == 0 && (g.epi_ld & 7) == 0 && prow0 + 64 <= g.M) {
-                unsigned* plu = reinterpret_cast<unsigned*>(smem_g) + wave * (64 * 72);
+            const int prow0 = m0 + wm * WROWS;
+            if (g.row_major_epi && is_v && (g.epi_rows % WROWS) == 0 && (g.epi_ld & 7) == 0 && prow0 + WROWS <= g.M) {
+                unsigned* plu = reinterpret_cast<unsigned*>(pl);
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -682,17 +687,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                             const _Float16 hi = split_hi(val);
                             const _Float16 lo = split_lo(val, hi);
                             const int d = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                            plu[d * 72 + 1 + i * 32 + r] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+                            plu[d * VT_LD + 1 + i * 32 + r] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
                         }
                 const int bb = prow0 / g.epi_rows, nk0 = prow0 - bb * g.epi_rows;   // (wave-uniform)
                 _Float16* Vh = reinterpret_cast<_Float16*>(g.epi_hi2);
                 _Float16* Vl = reinterpret_cast<_Float16*>(g.epi_lo2);
-                const int gq = lane & 7;
+                constexpr int G8 = WROWS / 8;   // 16-byte position groups per column = lanes per column; 64 / G8 columns per pass
+                const int gq = lane % G8;
 #pragma unroll
-                for (int ps = 0; ps < 8; ++ps) {
-                    const int d = ps * 8 + (lane >> 3);
-                    const u32x4 u0 = *reinterpret_cast<const u32x4*>(plu + d * 72 + 8 * gq);
-                    const u32x4 u1 = *reinterpret_cast<const u32x4*>(plu + d * 72 + 8 * gq + 4);
+                for (int ps = 0; ps < G8; ++ps) {
+                    const int d = ps * (64 / G8) + lane / G8;
+                    const u32x4 u0 = *reinterpret_cast<const u32x4*>(plu + d * VT_LD + 8 * gq);
+                    const u32x4 u1 = *reinterpret_cast<const u32x4*>(plu + d * VT_LD + 8 * gq + 4);
                     u32x4 hw, lw;   // positions 8 gq .. 8 gq + 7 of column d: hi halves, lo halves
                     hw[0] = __builtin_amdgcn_perm(u0[1], u0[0], 0x05040100u); lw[0] = __builtin_amdgcn_perm(u0[1], u0[0], 0x07060302u);
                     hw[1] = __builtin_amdgcn_perm(u0[3], u0[2], 0x05040100u); lw[1] = __builtin_amdgcn_perm(u0[3], u0[2], 0x07060302u);
@@ -719,10 +725,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                         bad |= f16x2_nonfinite(hw[0]) | f16x2_nonfinite(hw[1]) | f16x2_nonfinite(hw[2]) | f16x2_nonfinite(hw[3]);
                         *reinterpret_cast<u32x4*>(Vh + rowp) = hw;
                         *reinterpret_cast<u32x4*>(Vl + rowp) = lw;
-                        if (gq == 1) {    // the patch's last token: position nk0 + 64
-                            const unsigned ut = plu[d * 72 + 64];
+                        if (gq == 1) {    // the patch's last token: position nk0 + WROWS
+                            const unsigned ut = plu[d * VT_LD + WROWS];
                             bad |= f16x2_nonfinite(ut & 0xFFFFu);
-                            const long tp = (((long)bb * g.epi_heads + head) * 64 + d) * g.epi_ld + nk0 + 64;
+                            const long tp = (((long)bb * g.epi_heads + head) * 64 + d) * g.epi_ld + nk0 + WROWS;
                             *reinterpret_cast<unsigned short*>(Vh + tp) = (unsigned short)(ut & 0xFFFFu);
                             *reinterpret_cast<unsigned short*>(Vl + tp) = (unsigned short)(ut >> 16);
                         }
@@ -756,12 +762,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                             f32x4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = rdiv(v[j][qq * 4 + e]) * sc[e];
-                            *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + j * 32 + 8 * qq + 4 * h) = o;
+                            *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * RS + j * 32 + 8 * qq + 4 * h) = o;
                         }
                 }
 #pragma unroll
-                for (int ps = 0; ps < 8; ++ps) {
-                    const int row = ps * 8 + rm_row, m = m0 + wm * 64 + row;
+                for (int ps = 0; ps < WROWS / 8; ++ps) {
+                    const int row = ps * 8 + rm_row, m = m0 + wm * WROWS + row;
                     f32x4 a0, a1;
                     stage_read8(row, a0, a1);
                     half8 hi8, lo8;
@@ -876,7 +882,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                         }
                         s1 += (v[0] + v[1]) + (v[2] + v[3]);
                         s2 += fmaf(v[0], v[0], v[1] * v[1]) + fmaf(v[2], v[2], v[3] * v[3]);
-                        *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + 8 * qq + 4 * h) = v;
+                        *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * RS + 8 * qq + 4 * h) = v;
                     }
                     s1 += xor32(s1); s2 += xor32(s2);
                     if (h == 0 && m < g.M) reinterpret_cast<float2*>(g.ln_out_stats)[(long)((n0 >> 6) + wn) * g.ln_rows + mc] = make_float2(s1, s2);
@@ -884,10 +890,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
                 const int c4 = rm_c8 & 3, lo_half = rm_c8 >> 2;   // lanes 0-3 of a row: the hi halves of outputs 8 c4 .. 8 c4 + 7, lanes 4-7 the lo halves
                 const int c32 = (n0 >> 1) + wn * 32;              // first output column of the wave (a multiple of 32)
 #pragma unroll
-                for (int ps = 0; ps < 8; ++ps) {
-                    const int row = ps * 8 + rm_row, m = m0 + wm * 64 + row;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * c4);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(pl + row * 68 + 8 * c4 + 4);
+                for (int ps = 0; ps < WROWS / 8; ++ps) {
+                    const int row = ps * 8 + rm_row, m = m0 + wm * WROWS + row;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(pl + row * RS + 8 * c4);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(pl + row * RS + 8 * c4 + 4);
                     half8 hi8, lo8;
                     split8(a0, a1, hi8, lo8);
                     if (m < g.M) {
@@ -973,36 +979,37 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int tx, const
     // layout, read back row-major; row stride 68 floats: both directions conflict-free for 16-lane groups of 16-byte accesses - and bias / activation / residual follow on
     // the row-major side, element by element in the same order as below (bit-identical).  No barrier: after the last k-tile's barrier nobody reads operand data from the
     // ring any more (the stale look-ahead fetch of the last iteration is never used), and a wave only touches its own slice.
-    if constexpr (MODE == MODE_PLAIN && WM == 4 && S == 3 && TI == 2 && TJ == 2 && !KS && !SKK) {
+    if constexpr (STG) {
         if (g.row_major_epi && vec_ok && (g.N & 3) == 0 && !g.ln_out_planes) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = accM[i][j][qq * 4 + e] + accC[i][j][qq * 4 + e] * kGLoInv;
-                        *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * 68 + j * 32 + 8 * qq + 4 * h) = v;
+                        *reinterpret_cast<f32x4*>(pl + (i * 32 + r) * RS + j * 32 + 8 * qq + 4 * h) = v;
                     }
-            const int c = lane & 15, rr = lane >> 4;
-            const int n = n0 + wn * 64 + 4 * c;
+            constexpr int LPR = WCOLS / 4, RPP = 64 / LPR, NP = WROWS / RPP;   // lanes per row (16 bytes each), rows per pass, passes
+            const int c = lane % LPR, rr = lane / LPR;
+            const int n = n0 + wn * WCOLS + 4 * c;
             const int nc = min(n, g.N - 4);
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
             if (g.bias_n) b4 = *reinterpret_cast<const f32x4*>(g.bias_n + nc);
-            f32x4 rres[16];
-            float bmr[16];
+            f32x4 rres[NP];
+            float bmr[NP];
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
-                const int m = min(m0 + wm * 64 + s2 * 4 + rr, g.M - 1);
+            for (int s2 = 0; s2 < NP; ++s2) {
+                const int m = min(m0 + wm * WROWS + s2 * RPP + rr, g.M - 1);
                 bmr[s2] = g.bias_m ? g.bias_m[m] : 0.f;
                 rres[s2] = Rp ? *reinterpret_cast<const f32x4*>(Rp + (long)m * g.ldr + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
-                const int row = s2 * 4 + rr, m = m0 + wm * 64 + row;
-                const f32x4 a = *reinterpret_cast<const f32x4*>(pl + row * 68 + 4 * c);
+            for (int s2 = 0; s2 < NP; ++s2) {
+                const int row = s2 * RPP + rr, m = m0 + wm * WROWS + row;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pl + row * RS + 4 * c);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
