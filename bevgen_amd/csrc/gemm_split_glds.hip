@@ -1337,6 +1337,10 @@ void launch_gemm_split_glds(const GemmArgs& g_in, hipStream_t stream) {
             top.force_wm = 4;                            // the part that was sized to fill whole rounds of 256-row blocks keeps them
             top.M = g.m_base + (int)gy_top * 256;        // end row of the first part
             bot.m_base = top.M;
+            // ... and the rest picks its block by its OWN size even when the caller pinned 256-row blocks for the whole problem (q | k | v of two scenes: 288 tiles = 240 +
+            // 48; the 48 as 256-row blocks kept 48 CUs busy for 33.5 us, as 192 blocks of 64 rows ~18 us; profiles/r06_ab_rowsplit_bot.txt).  $BEVGEN_ROWSPLIT_BOT_WM=4: as before
+            static const int bot_wm_env = getenv("BEVGEN_ROWSPLIT_BOT_WM") ? atoi(getenv("BEVGEN_ROWSPLIT_BOT_WM")) : 0;
+            if (bot_wm_env != 4) bot.force_wm = 0;
             // (the rest on a side stream BESIDE a first part that leaves CUs idle - one scene: 215 blocks on 256 CUs - was measured and rejected: the fork / join events cost
             // more than the overlap buys, one scene 162.9 -> 173.4 ms, sixteen scenes 10.34 -> 10.30 scenes/s; profiles/r05_ab_rowsplit_side_*.txt)
             launch_gemm_split_glds(top, stream);
