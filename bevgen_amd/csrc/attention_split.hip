@@ -49,6 +49,11 @@ constexpr float kLo = 2048.f, kLoI = 1.f / 2048.f;
 constexpr int PP_PLANE = SKT * SKLD;   // = 64 * SVLD = 2304 halves: one plane of one LDS stage
 static_assert(SKT * SKLD == 64 * SVLD, "K and V^T planes share one LDS stage layout");
 
+// tools/attn_lab only (-DBEVGEN_ATTN_DIAG=bits; wrong results by design, what each part of the loop costs): 1 no softmax arithmetic, 2 no tile / bias loads and no LDS
+// stores in the loop, 4 no matrix instructions, 8 no bias loads, 16 no tile loads / LDS stores.  0 (the product build) compiles every test away.
+#ifndef BEVGEN_ATTN_DIAG
+#define BEVGEN_ATTN_DIAG 0
+#endif
 #ifdef BEVGEN_ATTN_LAB
 __device__ unsigned long long g_attn_trace[8 * 16 * 8];   // [wave][tile][stamp]
 #define PP_STAMP(k) do { if (TRACE && lane == 0 && t < 16) trace_lds[(wave * 16 + t) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -122,17 +127,24 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     }
     uint4 rh, rl;
     auto gload = [&](int tile) {
+        if (BEVGEN_ATTN_DIAG & (2 | 16)) return;
         rh = *reinterpret_cast<const uint4*>(src_hi + (long)tile * src_step);
         rl = *reinterpret_cast<const uint4*>(src_lo + (long)tile * src_step);
     };
     auto lstore = [&](int stage) {   // rows are 144 / 72 bytes: 8-byte alignment is what both planes have
+        if (BEVGEN_ATTN_DIAG & (2 | 16)) return;
         uint2* dh = reinterpret_cast<uint2*>(&lds[stage][0][dst_off]);
         uint2* dl = reinterpret_cast<uint2*>(&lds[stage][1][dst_off]);
         dh[0] = make_uint2(rh.x, rh.y); dh[1] = make_uint2(rh.z, rh.w);
         dl[0] = make_uint2(rl.x, rl.y); dl[1] = make_uint2(rl.z, rl.w);
     };
     f32x16 bacc;   // bias segment of the next tile: this lane's 16 keys in accumulator order
+    if (BEVGEN_ATTN_DIAG) {   // (defined values for the parts a diagnostic build leaves out)
+        for (int r = 0; r < 16; ++r) bacc[r] = (float)(lane + r);
+        rh = make_uint4(lane, 1, 2, 3); rl = rh;
+    }
     auto gload_bias = [&](int tile) {
+        if (BEVGEN_ATTN_DIAG & (2 | 8)) return;
         const float* src = Bp + (long)tile * bstep;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
     for (int t = 0; t <= ntiles; ++t) {
         // ================================================ M-phase
         PP_STAMP(0);
-        if (t > 0) {   // O^T += V^T P^T of tile t-1.  k-step s covers keys [16s, 16s+16); lane half h owns keys 16s + {0..3} + 4h and 16s + 8 + {0..3} + 4h
+        if (t > 0 && !(BEVGEN_ATTN_DIAG & 4)) {   // O^T += V^T P^T of tile t-1.  k-step s covers keys [16s, 16s+16); lane half h owns keys 16s + {0..3} + 4h and 16s + 8 + {0..3} + 4h
             const _Float16* Vh = &lds[(t - 1) & 1][2][0];
             const _Float16* Vl = &lds[(t - 1) & 1][3][0];
 #pragma unroll
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
                 oM[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[1], pl[s], oM[1], 0, 0, 0);
             }
         }
-        if (t < ntiles) {   // S^T = bias + K Q^T
+        if (t < ntiles && !(BEVGEN_ATTN_DIAG & 4)) {   // S^T = bias + K Q^T
             const _Float16* kh = &lds[t & 1][0][qi * SKLD + 8 * h];
             const _Float16* kl = &lds[t & 1][1][qi * SKLD + 8 * h];
 #pragma unroll
@@ -190,6 +202,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
                 sM = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qs[s], sM, 0, 0, 0);
             }
         }
+        if ((BEVGEN_ATTN_DIAG & 4) && t < ntiles) { for (int r = 0; r < 16; ++r) sM[r] = bacc[r] + (float)t; asm volatile("" : "+v"(sM)); }
         PP_STAMP(1);
         __syncthreads();
 
@@ -201,6 +214,16 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
         lstore((t + 1) & 1);
         PP_STAMP(3);
         if (t < ntiles) {
+#if BEVGEN_ATTN_DIAG & 1
+            gload_bias(min(t + 1, ntiles - 1));
+            gload(min(t + 2, ntiles - 1));
+            const float m_new = m_run, alpha = 1.f, psum = 1.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                ph[s] = __builtin_bit_cast(half8, u32x4{__float_as_uint(sM[8 * s]), __float_as_uint(sM[8 * s + 1]), __float_as_uint(sM[8 * s + 2]), __float_as_uint(sM[8 * s + 3])});
+                pl[s] = __builtin_bit_cast(half8, u32x4{__float_as_uint(sM[8 * s + 4]), __float_as_uint(sM[8 * s + 5]), __float_as_uint(sM[8 * s + 6]), __float_as_uint(sM[8 * s + 7])});
+            }
+#else
             float mx = kNegBig;
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sM[r]);
@@ -243,6 +266,7 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
                 ph[s] = __builtin_bit_cast(half8, u32x4{hw[4 * s], hw[4 * s + 1], hw[4 * s + 2], hw[4 * s + 3]});
                 pl[s] = __builtin_bit_cast(half8, u32x4{lw[4 * s], lw[4 * s + 1], lw[4 * s + 2], lw[4 * s + 3]});
             }
+#endif
             PP_STAMP(7);
             l_run = l_run * alpha + psum;
             m_run = m_new;
