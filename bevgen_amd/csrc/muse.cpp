@@ -291,11 +291,12 @@ void muse_blocks(Ctx& c, MuseWs& w, const int64_t* ids, hipStream_t s) {
             else cons_x = consumer(w.stats_d, D / 32, D, nullptr);
             // to_q and to_kv read the same LayerNorm planes (muse_net:126-132): ONE projection over the concatenated weight, query / key / value preparation in its
             // epilogue ($BEVGEN_QKV_MERGE=0: the two launches of rounds 2-4, for A/B runs)
-            // Measured (same box, profiles/r05_ab_qkv_merge*.txt): one scene 161.9 -> 160.4 ms (two small-problem launches become one), sixteen scenes 10.31 -> 10.21
-            // scenes/s (2304 tiles in one launch against 768 + 1536: the A panels are re-fetched per 8-column step either way, EXPERIMENTS.md "fabric-traffic floor"):
-            // merged only on the low-latency path.  $BEVGEN_QKV_MERGE = 0 never, 2 always
+            // Measured, round 5 (profiles/r05_ab_qkv_merge*.txt): one scene 161.9 -> 160.4 ms, sixteen scenes 10.31 -> 10.21 scenes/s - merged only on the low-latency path then.
+            // Round 6, after the staged row-major epilogues and with the row-split rest choosing its own block shape (profiles/r06_ab_qkv_merge.txt, same box, ms per step
+            // separate -> merged): three scenes 387.0 -> 373.5 (+3.6 %), four 443.7 -> 437.2, six 614.0 -> 607.1, eight 771.0 -> 768.7, twelve 1122.0 -> 1108.7 (+1.2 %),
+            // sixteen 1424.0 -> 1422.2: merged at every batch size.  $BEVGEN_QKV_MERGE = 0 never, 3 only up to 3072 token rows (the round-5 rule; A/B runs)
             static const int qkv_merge = getenv("BEVGEN_QKV_MERGE") ? atoi(getenv("BEVGEN_QKV_MERGE")) : 1;
-            const bool merged = l.to_qkv_self && (qkv_merge == 2 || (qkv_merge == 1 && rows <= 3072));
+            const bool merged = l.to_qkv_self && qkv_merge != 0 && (qkv_merge != 3 || rows <= 3072);
             if (!merged) {
                 cons_x.in_cs = l.fold_q_self_cs;
                 gemm_planes_q(w.xn, D, f0 ? l.fold_q_self : l.to_q[0], l.q_scale[0], w.Q, reinterpret_cast<_Float16*>(w.Q) + (size_t)rows * D, B, H, N, D, s, w.kpart, w.qraw,
