@@ -54,6 +54,13 @@ static_assert(SKT * SKLD == 64 * SVLD, "K and V^T planes share one LDS stage lay
 #ifndef BEVGEN_ATTN_DIAG
 #define BEVGEN_ATTN_DIAG 0
 #endif
+// 1: tile and bias loads in the buffer form (wave-uniform resource + a per-lane 32-bit offset that never changes + a scalar tile offset: no 64-bit address arithmetic, the
+// four bias requests differ in a scalar only).  Lab, same box: 527 -> 521 us (profiles/r06_attn_lab_diag.txt; a 4-byte placement shift of the loop changes nothing: 520-523 us
+// at all four phases).  0 keeps the global_load form - note that THAT build is 12 % slower than the same form before this switch existed (586 us): two register copies and
+// one s_waitcnt land in the middle of the softmax and expose the tile loads' latency; the kernel's time hangs on where its waits fall.
+#ifndef BEVGEN_ATTN_BUF
+#define BEVGEN_ATTN_BUF 1
+#endif
 #ifdef BEVGEN_ATTN_LAB
 __device__ unsigned long long g_attn_trace[8 * 16 * 8];   // [wave][tile][stamp]
 #define PP_STAMP(k) do { if (TRACE && lane == 0 && t < 16) trace_lds[(wave * 16 + t) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -126,8 +133,22 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
         dst_off = 2 * PP_PLANE + vr * SVLD + vc * 8;
     }
     uint4 rh, rl;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // buffer form: K planes for waves 0-3, V^T planes for waves 4-7 (wave-uniform bases); the lane's piece is a constant byte offset, the tile a scalar one
+    const int step_u = wave_u < 4 ? SKT * 64 : SKT;   // (= src_step, as a scalar)
+    const _Float16* tb_hi = (wave_u < 4 ? a.Kh : a.VTh) + koff + (long)t_first * step_u;
+    const _Float16* tb_lo = (wave_u < 4 ? a.Kl : a.VTl) + koff + (long)t_first * step_u;
+    const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tb_hi), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(tb_lo), 0, -1, 0x00020000);
+    const int tv_off = wave_u < 4 ? ((st >> 3) * 64 + (st & 7) * 8) * 2 : ((st >> 2) * a.Nk_pad + (st & 3) * 8) * 2;
     auto gload = [&](int tile) {
         if (BEVGEN_ATTN_DIAG & (2 | 16)) return;
+        if (BEVGEN_ATTN_BUF) {
+            const int so = tile * step_u * 2;
+            rh = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, tv_off, so, 0));
+            rl = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_lo, tv_off, so, 0));
+            return;
+        }
         rh = *reinterpret_cast<const uint4*>(src_hi + (long)tile * src_step);
         rl = *reinterpret_cast<const uint4*>(src_lo + (long)tile * src_step);
     };
@@ -143,8 +164,19 @@ __global__ __launch_bounds__(512) void attention_split_kernel(AttnSplitArgs a) {
         for (int r = 0; r < 16; ++r) bacc[r] = (float)(lane + r);
         rh = make_uint4(lane, 1, 2, 3); rl = rh;
     }
+    const float* Bu = a.bias_pk + (long)head * a.bias_head_stride + (long)(qblk * 8 + wave_u) * a.bias_pk_qb_stride + (long)t_first * bstep;   // wave-uniform part of Bp
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bu), 0, -1, 0x00020000);
     auto gload_bias = [&](int tile) {
         if (BEVGEN_ATTN_DIAG & (2 | 8)) return;
+        if (BEVGEN_ATTN_BUF) {
+            const int so = tile * bstep * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane * 16, so + 1024 * g, 0);
+                bacc[4 * g] = __uint_as_float(v.x); bacc[4 * g + 1] = __uint_as_float(v.y); bacc[4 * g + 2] = __uint_as_float(v.z); bacc[4 * g + 3] = __uint_as_float(v.w);
+            }
+            return;
+        }
         const float* src = Bp + (long)tile * bstep;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
